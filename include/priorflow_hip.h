@@ -1,0 +1,151 @@
+/* priorflow_hip.h -- C-ABI of the MI355X-native PriOr-RAFT inner loop (libpriorflow_hip.so).
+ *
+ * The reference (longliangLiu/PriOr-Flow, directory PriOr-RAFT/) has no FFI / plugin
+ * boundary of its own: its hot path is a chain of Python functions calling torch ops.
+ * Each entry point below replaces one of those functions (cited file:line, relative to
+ * PriOr-RAFT/) with a hand-written gfx950 kernel.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a positive hipError_t on a HIP failure, or a
+ *     negative PF_ERR_* code on a bad argument; nothing throws, allocates or frees;
+ *   - all buffers are DEVICE pointers owned by the caller, fp32, 16-byte aligned;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) without synchronising;
+ *   - "planar" = [B,2,H8*W8] (NCHW with 2 channels); "channel-last" = [B*H8*W8][ld] with the
+ *     logical channels at columns [c_off, c_off+C) of each row (lets producers write straight
+ *     into slices of a wider concatenation buffer: torch.cat never materialises);
+ *   - n = y*W8 + x is the raster index of a 1/8-resolution pixel, N = H8*W8;
+ *   - sample grids are [2,H,W] (m', n') and shared by every batch element.
+ */
+#ifndef PRIORFLOW_HIP_H
+#define PRIORFLOW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_OK 0
+#define PF_ERR_BAD_ARG (-1)
+#define PF_ERR_BAD_SHAPE (-2)
+
+/* Library / build identification ("gfx950 fp32-mfma ..."). */
+const char* pf_version(void);
+
+/* ---- ERP geometry ---------------------------------------------------------------------- */
+
+/* generate_samplegrid (core/utils/projection_prim_ortho.py:432-443): ERP pixel -> sphere ->
+ * R -> ERP pixel.  R is 9 HOST floats, row-major.  grid: [2,H,W]. */
+int pf_sample_grid(float* grid, int H, int W, const float* R_host, void* stream);
+
+/* img_rotate (core/utils/projection_prim_ortho.py:507-514): wrap-x / zero-pad bilinear resample
+ * of an NCHW image stack with a sample grid.  img,out: [B,C,H,W]. */
+int pf_img_rotate(const float* img, const float* grid, float* out, int B, int C, int H, int W,
+                  void* stream);
+
+/* flow = coords1 - coords_grid (core/prior_raft.py:172,177).  coords1: planar.  flow_out
+ * (planar) and the two channel-last destinations are optional (NULL to skip). */
+int pf_flow_prep(const float* coords1, float* flow_out,
+                 float* d0, int d0_ld, int d0_off, float* d1, int d1_ld, int d1_off,
+                 int B, int H8, int W8, void* stream);
+
+/* flo_rotate (core/utils/projection_prim_ortho.py:531-546 + core/utils/my_cycle_sample.py:6-97):
+ * express a flow field of one view in the other view.  flow/out: planar. */
+int pf_flo_rotate(const float* flow, const float* g_w2c, const float* g_c2w, float* out,
+                  float* d0, int d0_ld, int d0_off, float* d1, int d1_ld, int d1_off,
+                  int B, int H8, int W8, void* stream);
+
+/* ---- correlation volume, pyramid, lookups ---------------------------------------------- */
+
+/* PriOr_RAFT.corr + DCCL.build_pyramid (core/prior_raft.py:69-75, core/corr.py:99-111), fused:
+ * level0[b][n1][n2] = <f1[b][n1][:], f2[b][n2][:]> / sqrt(C); level i+1 = 2x2 mean of level i
+ * over (y2,x2).  f1,f2: channel-last [B*N][C] (C % 32 == 0).  lvl[i]: [B*N][(H8>>i)*(W8>>i)].
+ * Requires H8 % 8 == 0 and W8 % 8 == 0 (the fused-pooling fast path needs W8 % 32 == 0;
+ * other widths take a two-kernel path). */
+int pf_corr_pyramid(const float* f1, const float* f2, float* lvl0, float* lvl1, float* lvl2,
+                    float* lvl3, int B, int H8, int W8, int C, void* stream);
+
+/* DCCL.__call__ steps 1-2 (core/corr.py:119-137): own-view 9x9x4 lookup and the raw
+ * cross-view lookup through g_w2c.  coords: planar.  own_out/raw_out: channel-last, 324
+ * channels = level*81 + a*9 + b (x += a-4, y += b-4), row stride ld >= 324. */
+int pf_dccl_lookup(const float* coords,
+                   const float* own0, const float* own1, const float* own2, const float* own3,
+                   const float* oth0, const float* oth1, const float* oth2, const float* oth3,
+                   const float* g_w2c, float* own_out, float* raw_out,
+                   int B, int H8, int W8, int ld, void* stream);
+
+/* DCCL.__call__ step 3 + the caller's add (core/corr.py:138, core/prior_raft.py:187-188):
+ * out = own + img_rotate(raw, g_back), channel-last. */
+int pf_dccl_combine(const float* own, const float* raw, const float* g_back, float* out,
+                    int B, int H8, int W8, int ld, int ld_out, void* stream);
+
+/* cycle_bilinear_sampler + groupwise_corr (core/prior_raft.py:173-174,180-182,77-83):
+ * dst[.., c_off+g] = mean_{c in group g} f1[c] * warp(f2, coords)[c], 4 groups.
+ * coords planar; if add_grid != 0 it is a flow and coords0 is added first. */
+int pf_warp_gcorr(const float* f1, const float* f2, const float* coords, int add_grid,
+                  float* dst, int dst_ld, int dst_off, int B, int H8, int W8, int C, void* stream);
+
+/* ---- update blocks ------------------------------------------------------------------------ */
+
+/* Epilogues of pf_conv2d. */
+#define PF_EPI_LINEAR 0   /* out = (acc + bias) * scale                                   */
+#define PF_EPI_RELU 1     /* out = relu(acc + bias)                                       */
+#define PF_EPI_GRU_ZR 2   /* cout [0,128): out = sigmoid(.) -> z; [128,256): aux_out = sigmoid(.)*h */
+#define PF_EPI_GRU_Q 3    /* q = tanh(.); out = (1-z)*h + z*q                              */
+
+/* One stride-1 "same" convolution on channel-last activations as an implicit GEMM on the
+ * matrix cores (nn.Conv2d forwards of core/update.py:6-14, 35-60, 81-99, 117-136, 139-201).
+ * The input is the virtual concatenation of two channel-last segments (in1 may be NULL);
+ * c0 must be a multiple of 32 when in1 is used.  Weights are pre-packed
+ * [Cout_pad][KH*KW][Cin_pad] (Cin_pad = c0 + c1 rounded up to 32, Cout_pad to 128, zero filled).
+ */
+typedef struct pf_conv_desc {
+    const float* in0; int ld0; int off0; int c0;
+    const float* in1; int ld1; int off1; int c1;
+    const float* weight; const float* bias;
+    float* out; int ld_out; int off_out; int cout;
+    int kh, kw;
+    int epilogue; float scale;
+    const float* h; int ld_h;        /* GRU_ZR / GRU_Q: hidden state [B*N][ld_h]            */
+    const float* z; int ld_z;        /* GRU_Q: update gate                                  */
+    float* aux_out; int ld_aux;      /* GRU_ZR: r*h                                         */
+} pf_conv_desc;
+
+/* Launch `ngroups` (1..4) same-geometry convolutions in ONE kernel (grid.z = group):
+ * branch A and branch B of an iteration run side by side. */
+int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream);
+
+/* Host-only introspection: which workgroup tile pf_conv2d would use for this launch
+ * (0: 128x32, 1: 64x64, 2: 64x128 pixels x channels), or a negative PF_ERR_* code.  Lets a
+ * profiler attribute measured time to the right kernel instantiation; launches nothing. */
+int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8);
+
+/* Tiny-Cin direct convolution (7x7 2->128, 3x3 8->32, 3x3 32->16; core/update.py:171-178,87).
+ * Weights packed [KH*KW][Cin][Cout]. */
+int pf_conv2d_direct(const float* in, int ld_in, int off_in, int cin,
+                     const float* weight, const float* bias,
+                     float* out, int ld_out, int off_out, int cout,
+                     int kh, int kw, int relu, int B, int H8, int W8, void* stream);
+
+/* coords1 += delta (core/prior_raft.py:193,196).  delta: channel-last, 2 channels at column 0. */
+int pf_coords_add(float* coords1, const float* delta, int ld, int B, int H8, int W8, void* stream);
+
+/* upsample_flow (core/prior_raft.py:58-67): convex 8x upsampling of flow = coords1 - coords0.
+ * mask: channel-last [B*N][ld] (576 logits, already scaled by 0.25).  out: [B,2,8*H8,8*W8]. */
+int pf_upsample_flow(const float* coords1, const float* mask, int ld, float* out,
+                     int B, int H8, int W8, void* stream);
+
+/* ---- layout plumbing ------------------------------------------------------------------------ */
+
+/* NCHW channel slice -> channel-last slice, with activation (0 none, 1 relu, 2 tanh)
+ * (core/prior_raft.py:136-142 splits/activations of the context features). */
+int pf_to_channel_last(const float* in, int c_total, int c_begin, int c, float* out, int ld_out,
+                       int off_out, int act, int B, int N, void* stream);
+
+/* channel-last slice -> NCHW. */
+int pf_to_nchw(const float* in, int ld_in, int off_in, int c, float* out, int B, int N,
+               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRIORFLOW_HIP_H */

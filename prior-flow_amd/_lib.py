@@ -1,0 +1,242 @@
+"""ctypes binding of ``libpriorflow_hip.so`` (C-ABI declared in ``include/priorflow_hip.h``).
+
+``load()`` fails loudly when the HIP library has not been built: there is no CPU or
+PyTorch fallback anywhere in the product path.  torch is plumbing only (device memory,
+streams): every wrapper passes ``tensor.data_ptr()`` and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpriorflow_hip.so")
+
+EPI_LINEAR, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+_fp = C.c_void_p
+_i = C.c_int
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``pf_conv_desc`` (include/priorflow_hip.h)."""
+    _fields_ = [
+        ("in0", _fp), ("ld0", _i), ("off0", _i), ("c0", _i),
+        ("in1", _fp), ("ld1", _i), ("off1", _i), ("c1", _i),
+        ("weight", _fp), ("bias", _fp),
+        ("out", _fp), ("ld_out", _i), ("off_out", _i), ("cout", _i),
+        ("kh", _i), ("kw", _i),
+        ("epilogue", _i), ("scale", C.c_float),
+        ("h", _fp), ("ld_h", _i),
+        ("z", _fp), ("ld_z", _i),
+        ("aux_out", _fp), ("ld_aux", _i),
+    ]
+
+
+_SIGNATURES = {
+    "pf_sample_grid": [_fp, _i, _i, C.POINTER(C.c_float), _fp],
+    "pf_img_rotate": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_flow_prep": [_fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
+    "pf_flo_rotate": [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
+    "pf_corr_pyramid": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
+    "pf_dccl_combine": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
+    "pf_warp_gcorr": [_fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _fp],
+    "pf_conv2d": [C.POINTER(ConvDesc), _i, _i, _i, _i, _fp],
+    "pf_conv2d_tile": [C.POINTER(ConvDesc), _i, _i, _i, _i],
+    "pf_conv2d_direct": [_fp, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
+    "pf_coords_add": [_fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_upsample_flow": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
+    "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
+    "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
+}
+EXPORTS = ["pf_version"] + list(_SIGNATURES)
+
+
+class PfError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class PfLib:
+    """Typed wrappers; one instance per loaded shared object."""
+
+    def __init__(self, path: str, require_cuda: bool = True, optional: Sequence[str] = ()):
+        if not os.path.exists(path):
+            raise PfError(
+                f"HIP library not found: {path}\n"
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        if require_cuda:
+            # bind against the HIP runtime torch already loaded (same SONAME libamdhip64.so.7)
+            torch_hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+            if os.path.exists(torch_hip):
+                C.CDLL(torch_hip, mode=C.RTLD_GLOBAL)
+        self.path = path
+        self.require_cuda = require_cuda
+        self._dll = C.CDLL(path)
+        self._dll.pf_version.restype = C.c_char_p
+        self.missing = []
+        for name, args in _SIGNATURES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError:
+                if name in optional:
+                    self.missing.append(name)
+                    continue
+                raise PfError(f"{path} does not export {name}")
+            fn.argtypes = args
+            fn.restype = _i
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def version(self) -> str:
+        return self._dll.pf_version().decode()
+
+    def _chk(self, *tensors: Optional[torch.Tensor]):
+        for t in tensors:
+            if t is None:
+                continue
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise PfError(f"expected contiguous fp32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+            if self.require_cuda and not t.is_cuda:
+                raise PfError("the HIP path needs tensors on a cuda (ROCm) device; there is no CPU fallback")
+
+    def _stream(self, t: torch.Tensor):
+        if t.is_cuda:
+            return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        return None
+
+    @staticmethod
+    def _rc(rc: int, what: str):
+        if rc != 0:
+            kind = "bad argument/shape" if rc < 0 else "hipError_t"
+            raise PfError(f"{what} failed: {kind} {rc}")
+
+    # ---- geometry ----------------------------------------------------------------------------
+    def sample_grid(self, grid: torch.Tensor, R: torch.Tensor):
+        self._chk(grid)
+        H, W = grid.shape[-2:]
+        r = (C.c_float * 9)(*[float(v) for v in R.reshape(-1).tolist()])
+        self._rc(self._dll.pf_sample_grid(_ptr(grid), H, W, r, self._stream(grid)), "pf_sample_grid")
+        return grid
+
+    def img_rotate(self, img, grid, out):
+        self._chk(img, grid, out)
+        B, Cc, H, W = img.shape
+        self._rc(self._dll.pf_img_rotate(_ptr(img), _ptr(grid), _ptr(out), B, Cc, H, W,
+                                         self._stream(img)), "pf_img_rotate")
+        return out
+
+    def flow_prep(self, coords1, flow_out=None, d0=None, d0_off=0, d1=None, d1_off=0):
+        self._chk(coords1, flow_out, d0, d1)
+        B, _, H, W = coords1.shape
+        self._rc(self._dll.pf_flow_prep(
+            _ptr(coords1), _ptr(flow_out),
+            _ptr(d0), 0 if d0 is None else d0.shape[-1], d0_off,
+            _ptr(d1), 0 if d1 is None else d1.shape[-1], d1_off,
+            B, H, W, self._stream(coords1)), "pf_flow_prep")
+
+    def flo_rotate(self, flow, g_w2c, g_c2w, out=None, d0=None, d0_off=0, d1=None, d1_off=0):
+        self._chk(flow, g_w2c, g_c2w, out, d0, d1)
+        B, _, H, W = flow.shape
+        self._rc(self._dll.pf_flo_rotate(
+            _ptr(flow), _ptr(g_w2c), _ptr(g_c2w), _ptr(out),
+            _ptr(d0), 0 if d0 is None else d0.shape[-1], d0_off,
+            _ptr(d1), 0 if d1 is None else d1.shape[-1], d1_off,
+            B, H, W, self._stream(flow)), "pf_flo_rotate")
+        return out
+
+    # ---- correlation -------------------------------------------------------------------------
+    def corr_pyramid(self, f1, f2, levels, B, H8, W8):
+        """f1,f2: channel-last [B*N, C]; levels: 4 tensors [B*N, (H8>>i)*(W8>>i)]."""
+        self._chk(f1, f2, *levels)
+        self._rc(self._dll.pf_corr_pyramid(_ptr(f1), _ptr(f2), *[_ptr(l) for l in levels],
+                                           B, H8, W8, f1.shape[-1], self._stream(f1)), "pf_corr_pyramid")
+
+    def dccl_lookup(self, coords, pyr_own, pyr_other, g_w2c, own_out, raw_out):
+        self._chk(coords, g_w2c, own_out, raw_out, *pyr_own, *pyr_other)
+        B, _, H, W = coords.shape
+        self._rc(self._dll.pf_dccl_lookup(
+            _ptr(coords), *[_ptr(p) for p in pyr_own], *[_ptr(p) for p in pyr_other],
+            _ptr(g_w2c), _ptr(own_out), _ptr(raw_out), B, H, W, own_out.shape[-1],
+            self._stream(coords)), "pf_dccl_lookup")
+
+    def dccl_combine(self, own, raw, g_back, out, B, H8, W8):
+        self._chk(own, raw, g_back, out)
+        self._rc(self._dll.pf_dccl_combine(_ptr(own), _ptr(raw), _ptr(g_back), _ptr(out), B, H8, W8,
+                                           own.shape[-1], out.shape[-1], self._stream(own)),
+                 "pf_dccl_combine")
+
+    def warp_gcorr(self, f1, f2, coords, add_grid, dst, dst_off):
+        self._chk(f1, f2, coords, dst)
+        B, _, H, W = coords.shape
+        self._rc(self._dll.pf_warp_gcorr(_ptr(f1), _ptr(f2), _ptr(coords), int(add_grid), _ptr(dst),
+                                         dst.shape[-1], dst_off, B, H, W, f1.shape[-1],
+                                         self._stream(f1)), "pf_warp_gcorr")
+
+    # ---- update blocks -----------------------------------------------------------------------
+    def conv2d(self, descs: Sequence[ConvDesc], B, H8, W8, like: torch.Tensor):
+        arr = (ConvDesc * len(descs))(*descs)
+        self._rc(self._dll.pf_conv2d(arr, len(descs), B, H8, W8, self._stream(like)), "pf_conv2d")
+
+    def conv2d_tile(self, descs: Sequence[ConvDesc], B, H8, W8) -> int:
+        arr = (ConvDesc * len(descs))(*descs)
+        rc = self._dll.pf_conv2d_tile(arr, len(descs), B, H8, W8)
+        if rc < 0:
+            self._rc(rc, "pf_conv2d_tile")
+        return rc
+
+    def conv2d_direct(self, x, off_in, cin, weight, bias, out, off_out, cout, kh, kw, relu, B, H8, W8):
+        self._chk(x, weight, bias, out)
+        self._rc(self._dll.pf_conv2d_direct(_ptr(x), x.shape[-1], off_in, cin, _ptr(weight), _ptr(bias),
+                                            _ptr(out), out.shape[-1], off_out, cout, kh, kw, int(relu),
+                                            B, H8, W8, self._stream(x)), "pf_conv2d_direct")
+
+    def coords_add(self, coords1, delta):
+        self._chk(coords1, delta)
+        B, _, H, W = coords1.shape
+        self._rc(self._dll.pf_coords_add(_ptr(coords1), _ptr(delta), delta.shape[-1], B, H, W,
+                                         self._stream(coords1)), "pf_coords_add")
+
+    def upsample_flow(self, coords1, mask, out):
+        self._chk(coords1, mask, out)
+        B, _, H, W = coords1.shape
+        self._rc(self._dll.pf_upsample_flow(_ptr(coords1), _ptr(mask), mask.shape[-1], _ptr(out),
+                                            B, H, W, self._stream(coords1)), "pf_upsample_flow")
+        return out
+
+    # ---- layout ------------------------------------------------------------------------------
+    def to_channel_last(self, x, c_begin, c, out, off_out, act=ACT_NONE):
+        """x: NCHW [B,Ct,H,W] -> out rows [B*H*W, ld] columns [off_out, off_out+c)."""
+        self._chk(x, out)
+        B, Ct = x.shape[:2]
+        N = x.shape[2] * x.shape[3]
+        self._rc(self._dll.pf_to_channel_last(_ptr(x), Ct, c_begin, c, _ptr(out), out.shape[-1], off_out,
+                                              act, B, N, self._stream(x)), "pf_to_channel_last")
+        return out
+
+    def to_nchw(self, x, off_in, c, out):
+        self._chk(x, out)
+        B = out.shape[0]
+        N = out.shape[2] * out.shape[3]
+        self._rc(self._dll.pf_to_nchw(_ptr(x), x.shape[-1], off_in, c, _ptr(out), B, N,
+                                      self._stream(x)), "pf_to_nchw")
+        return out
+
+
+_cached: Optional[PfLib] = None
+
+
+def load() -> PfLib:
+    """The product's library handle (built in-tree under prior-flow_amd/lib/)."""
+    global _cached
+    if _cached is None:
+        _cached = PfLib(LIB_PATH, require_cuda=True)
+    return _cached

@@ -1,0 +1,284 @@
+// pf_conv2d: stride-1 "same" convolution on channel-last activations as an implicit GEMM on the
+// gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32), with fused bias / activation /
+// SepConvGRU gating epilogues.  Replaces the nn.Conv2d forwards of the reference's update
+// blocks (PriOr-RAFT/core/update.py:6-14 FlowHead, :35-60 SepConvGRU, :81-99 and :162-201 motion
+// encoders, :124-127/:147-150 mask heads).
+//
+// GEMM view:  M = B*H8*W8 pixels,  N = Cout,  K = KH*KW*Cin (tap-major, channel-minor).
+//   A[m][k]  = input pixel (y+dy, x+dx) channel c   (zero outside the map), K-contiguous rows
+//   B[n][k]  = packed weight [Cout_pad][KH*KW][Cin_pad]                     K-contiguous rows
+// One K-step = one tap x one 32-channel chunk.  Both tiles are staged through LDS with
+// coalesced 16-byte loads (8 lanes per 128-byte row) and read back as MFMA operands with
+// ds_read_b128: the K index inside a chunk is PERMUTED so that lane (row i, half h) owns the
+// 16 consecutive channels [16h, 16h+16) -- MFMA step s multiplies channel 16h+s of A and B --
+// which turns the one-float-per-lane f32 operand into four 16-byte LDS reads per chunk.
+// Row stride 36 floats (144 B) makes those reads and the 16-byte staging writes bank-conflict
+// free (9*row mod 16 is a bijection over any 16 distinct rows).
+//
+// Software pipeline: global loads of K-step s+1 are issued before the MFMAs of step s and
+// written to the other LDS buffer at the top of the next iteration; one __syncthreads per K-step.
+#include "pf_common.h"
+#include "../../include/priorflow_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain 16-byte loads, no struct memcpy
+
+constexpr int KC = 32;        // channels per K-step
+constexpr int LDS_LD = 36;    // padded row stride (floats)
+constexpr int MAX_GROUPS = 4;
+
+struct ConvGroups { pf_conv_desc d[MAX_GROUPS]; };
+
+struct ConvGeom { int M, H, W, N; int taps, nchunks, cin_pad, kh, kw; };
+
+template <int WM, int WN, int NT>
+__global__ void __launch_bounds__(256, 2)   // 2 waves/SIMD -> 256-register budget, no spills
+pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * NT * WN;
+    constexpr int A_V4 = BM * 8 / 256;     // float4 per thread per K-step (A tile)
+    constexpr int B_V4 = BN * 8 / 256;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 loader threads");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;                // [2][BN][LDS_LD]
+
+    // static indices only: a dynamic index into the by-value kernarg struct would be
+    // lowered through scratch memory
+    pf_conv_desc d = groups.d[0];
+    if (blockIdx.z == 1) d = groups.d[1];
+    else if (blockIdx.z == 2) d = groups.d[2];
+    else if (blockIdx.z == 3) d = groups.d[3];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    if (n0 >= d.cout) return;                          // groups may have different Cout
+
+    // ---- loader assignment: A rows -----------------------------------------------------------
+    int a_y[A_V4], a_x[A_V4];
+    long a_pix[A_V4];                                  // global pixel index or -1
+#pragma unroll
+    for (int q = 0; q < A_V4; ++q) {
+        const int idx = tid + 256 * q;
+        const int r = idx >> 3;
+        const long p = (long)m0 + r;
+        if (p < g.M) {
+            const int n = (int)(p % g.N);
+            a_y[q] = n / g.W; a_x[q] = n % g.W; a_pix[q] = p;
+        } else {
+            a_y[q] = 0; a_x[q] = 0; a_pix[q] = -1;
+        }
+    }
+    const int c4 = (tid & 7) * 4;                      // channel offset inside the chunk
+    const int ctot = d.c0 + d.c1;
+    const int ph = g.kh / 2, pw = g.kw / 2;
+    const long wrow = (long)g.taps * g.cin_pad;        // floats per packed weight row
+
+    f32x4 ra[A_V4], rb[B_V4];
+    unsigned a_ok = 0;                                 // bit q: ra[q] is a real (not padded) load
+
+    auto load_step = [&](int step) __attribute__((always_inline)) {
+        const int tap = step / g.nchunks;
+        const int cbase = (step - tap * g.nchunks) * KC;
+        const int dy = tap / g.kw - ph, dx = tap % g.kw - pw;
+        const int c = cbase + c4;
+        const float* src; int ld, cc;
+        if (c < d.c0) { src = d.in0 + d.off0; ld = d.ld0; cc = c; }
+        else          { src = d.in1 + d.off1; ld = d.ld1; cc = c - d.c0; }
+        const bool cok = c < ctot;
+        unsigned okbits = 0;
+#pragma unroll
+        for (int q = 0; q < A_V4; ++q) {
+            const int yy = a_y[q] + dy, xx = a_x[q] + dx;
+            const bool ok = cok && a_pix[q] >= 0 && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+            // branch-free: masked lanes read a valid dummy address (row 0 of segment 0) and
+            // are zeroed afterwards, so the whole K-step stays in one basic block
+            const long sp = a_pix[q] + (long)dy * g.W + dx;
+            const float* ptr = ok ? src + sp * ld + cc : d.in0 + d.off0;
+            ra[q] = *reinterpret_cast<const f32x4*>(ptr);
+            okbits |= ok ? (1u << q) : 0u;
+        }
+        a_ok = okbits;   // the zeroing select happens at LDS-store time: nothing in the MFMA block
+                         // of this iteration waits on these loads
+        const float* wp = d.weight + (long)tap * g.cin_pad + cbase + c4;
+#pragma unroll
+        for (int q = 0; q < B_V4; ++q) {
+            const int r = (tid + 256 * q) >> 3;
+            rb[q] = *reinterpret_cast<const f32x4*>(wp + (long)(n0 + r) * wrow);
+        }
+    };
+    auto store_step = [&](int buf) __attribute__((always_inline)) {
+        float* as = As + buf * BM * LDS_LD;
+        float* bs = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int q = 0; q < A_V4; ++q) {
+            const int r = (tid + 256 * q) >> 3;
+            *reinterpret_cast<f32x4*>(as + r * LDS_LD + c4) =
+                ((a_ok >> q) & 1u) ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < B_V4; ++q) {
+            const int r = (tid + 256 * q) >> 3;
+            *reinterpret_cast<f32x4*>(bs + r * LDS_LD + c4) = rb[q];
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nsteps = g.taps * g.nchunks;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (32 * wm + li) * LDS_LD + 16 * lh;
+    const int b_off = (32 * NT * wn + li) * LDS_LD + 16 * lh;
+
+    // registers hold K-step `step` at the top of each iteration; its LDS buffer was last read
+    // two iterations ago (all waves have passed the previous barrier), so ONE barrier suffices
+    load_step(0);
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        store_step(buf);
+        __syncthreads();
+        // unconditional prefetch (the last one re-reads the final K-step; never stored)
+        load_step(step + 1 < nsteps ? step + 1 : step);
+        // keep the prefetch ABOVE the MFMA block: without this compiler-level barrier hipcc sinks
+        // the loads to their first use (top of the next iteration) and waits for them there
+        asm volatile("" ::: "memory");
+
+        const float* as = As + buf * BM * LDS_LD + a_off;
+        const float* bs = Bs + buf * BN * LDS_LD + b_off;
+        f32x4 af[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(as + 4 * q);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 bf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bf[q] = *reinterpret_cast<const f32x4*>(bs + t * 32 * LDS_LD + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[q].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf[q].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf[q].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf[q].w, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: acc[t][r] = D[row (r&3)+8(r>>2)+4h][col lane&31] ---------------------------
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = n0 + 32 * NT * wn + 32 * t + li;
+        const bool jok = j < d.cout;
+        const float bias = jok ? d.bias[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long p = (long)m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (!jok || p >= g.M) continue;
+            float v = acc[t][r] + bias;
+            if (d.epilogue == PF_EPI_LINEAR) {
+                d.out[p * d.ld_out + d.off_out + j] = v * d.scale;
+            } else if (d.epilogue == PF_EPI_RELU) {
+                d.out[p * d.ld_out + d.off_out + j] = fmaxf(v, 0.f);
+            } else if (d.epilogue == PF_EPI_GRU_ZR) {
+                const float s = 1.f / (1.f + expf(-v));
+                if (j < 128) {
+                    d.out[p * d.ld_out + d.off_out + j] = s;                 // z
+                } else {
+                    d.aux_out[p * d.ld_aux + (j - 128)] = s * d.h[p * d.ld_h + (j - 128)];  // r*h
+                }
+            } else {   // PF_EPI_GRU_Q
+                const float q = tanhf(v);
+                const float z = d.z[p * d.ld_z + j];
+                const float hh = d.h[p * d.ld_h + j];
+                d.out[p * d.ld_out + d.off_out + j] = (1.f - z) * hh + z * q;
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int NT>
+int launch_conv(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((max_cout + BN - 1) / BN), (unsigned)ngroups);
+    hipLaunchKernelGGL((pf_conv_mfma_kernel<WM, WN, NT>), grid, dim3(256), lds, stream, grp, g);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// validation + geometry shared by pf_conv2d and pf_conv2d_tile
+static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8,
+                        ConvGroups& grp, ConvGeom& g, int& max_cout) {
+    if (!descs || ngroups < 1 || ngroups > MAX_GROUPS) return PF_ERR_BAD_ARG;
+    if (B <= 0 || H8 <= 0 || W8 <= 0) return PF_ERR_BAD_SHAPE;
+    max_cout = 0;
+    const pf_conv_desc& f = descs[0];
+    for (int i = 0; i < ngroups; ++i) {
+        const pf_conv_desc& d = descs[i];
+        if (!d.in0 || !d.weight || !d.bias || !d.out) return PF_ERR_BAD_ARG;
+        if (d.c0 <= 0 || d.c1 < 0 || (d.c1 > 0 && !d.in1)) return PF_ERR_BAD_ARG;
+        // same geometry in every group: one kernel, one K loop
+        if (d.kh != f.kh || d.kw != f.kw || d.c0 + d.c1 != f.c0 + f.c1) return PF_ERR_BAD_SHAPE;
+        if (!(d.kh & 1) || !(d.kw & 1) || d.cout <= 0) return PF_ERR_BAD_SHAPE;
+        // 16-byte loads: every channel offset / stride must be a multiple of 4 floats
+        if ((d.ld0 | d.off0 | d.c0 | d.c1) & 3) return PF_ERR_BAD_SHAPE;
+        if (d.c1 > 0 && (((d.ld1 | d.off1) & 3) || (d.c0 % KC) != 0)) return PF_ERR_BAD_SHAPE;
+        if (d.off0 < 0 || d.off0 + d.c0 > d.ld0 || (d.c1 > 0 && (d.off1 < 0 || d.off1 + d.c1 > d.ld1)))
+            return PF_ERR_BAD_ARG;
+        if (d.epilogue < PF_EPI_LINEAR || d.epilogue > PF_EPI_GRU_Q) return PF_ERR_BAD_ARG;
+        if (d.off_out < 0 || d.off_out + (d.epilogue == PF_EPI_GRU_ZR ? 128 : d.cout) > d.ld_out)
+            return PF_ERR_BAD_ARG;
+        if (d.epilogue == PF_EPI_GRU_ZR && (d.cout != 256 || !d.h || !d.aux_out || d.ld_aux < 128 || d.ld_h < 128))
+            return PF_ERR_BAD_ARG;
+        if (d.epilogue == PF_EPI_GRU_Q && (d.cout != 128 || !d.h || !d.z || d.ld_z < 128 || d.ld_h < 128))
+            return PF_ERR_BAD_ARG;
+        grp.d[i] = d;
+        if (d.cout > max_cout) max_cout = d.cout;
+    }
+    for (int i = ngroups; i < MAX_GROUPS; ++i) grp.d[i] = descs[0];
+    g.H = H8; g.W = W8; g.N = H8 * W8; g.M = B * H8 * W8;
+    g.kh = f.kh; g.kw = f.kw; g.taps = f.kh * f.kw;
+    g.cin_pad = (f.c0 + f.c1 + KC - 1) / KC * KC;
+    g.nchunks = g.cin_pad / KC;
+    return PF_OK;
+}
+
+// Tile choice: the packed weights are zero-padded to a multiple of 128 output channels, so any
+// BN in {32,64,128} is legal.  Small problems (one 512x1024 pair = 8192 pixels per branch) need
+// the smaller tile to put >= 1 workgroup on each of the 256 CUs.
+// 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
+static int conv_tile(const ConvGeom& g, int ngroups, int max_cout) {
+    const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;
+    if (max_cout <= 32) return 0;
+    if (max_cout <= 64 || m_tiles64 * ((max_cout + 127) / 128) < 512) return 1;
+    return 2;
+}
+
+extern "C" int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
+    ConvGroups grp; ConvGeom g; int max_cout;
+    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
+    return rc != PF_OK ? rc : conv_tile(g, ngroups, max_cout);
+}
+
+extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream) {
+    ConvGroups grp; ConvGeom g; int max_cout;
+    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
+    if (rc != PF_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    switch (conv_tile(g, ngroups, max_cout)) {
+        case 0: return launch_conv<4, 1, 1>(grp, ngroups, g, max_cout, s);
+        case 1: return launch_conv<2, 2, 1>(grp, ngroups, g, max_cout, s);
+        default: return launch_conv<2, 2, 2>(grp, ngroups, g, max_cout, s);
+    }
+}

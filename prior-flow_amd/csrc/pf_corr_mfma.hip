@@ -1,0 +1,263 @@
+// pf_corr_pyramid: all-pairs correlation volume with the 4-level pyramid fused into the GEMM
+// epilogue (PriOr-RAFT/core/prior_raft.py:69-75 `corr`, core/corr.py:99-111 `build_pyramid`).
+//
+//   level0[b][n1][n2] = (1/sqrt(C)) * sum_c f1[b][n1][c] * f2[b][n2][c]
+//   level(i+1)        = 2x2 mean of level i over (y2, x2)
+//
+// The reference writes the volume with a matmul, re-reads and re-writes it for the divide, then
+// re-reads it three more times for the avg_pool2d chain.  Here every level is written exactly
+// once and nothing is re-read: algorithmic HBM traffic = 4*N^2*(85/64) + 2*4*N*C bytes.
+//
+// Tiling (fast path, W8 % 32 == 0, H8 % 8 == 0): one workgroup = 4 waves = 128 query pixels n1
+// x one 8-row x 32-column block of target pixels n2 (256 columns).  A wave owns 32 n1 rows and
+// ALL 256 n2 columns as eight 32x32 MFMA accumulators (one per target row), so
+//   * 2x2 pooling along y2 is a register-to-register add between accumulators t and t+1,
+//   * pooling along x2 is a lane shuffle (lane = x2 inside the block),
+//   * an 8x32 block is closed under three poolings -> levels 1..3 come out of registers,
+//   * level-0 stores are 128-byte row segments (32 lanes x 4 B), two rows per instruction.
+// Exact fp32: v_mfma_f32_32x32x2_f32 with the same K permutation / LDS staging as
+// pf_conv_mfma.hip (16-byte coalesced fills, ds_read_b128 operands, 144-byte padded rows).
+//
+// Generic path (any H8,W8 % 8 == 0): same GEMM on 256 consecutive n2 columns, level 0 only;
+// levels 1..3 then come from a small pooling kernel.
+#include "pf_common.h"
+#include "../../include/priorflow_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain 16-byte loads, no struct memcpy
+
+constexpr int KC = 32;
+constexpr int LDS_LD = 36;
+constexpr int BM = 128;     // n1 per workgroup
+constexpr int BN = 256;     // n2 per workgroup
+
+struct CorrArgs {
+    const float* f1; const float* f2;
+    float* lvl[4];
+    int B, H, W, N, C;
+    float inv_scale;      // sqrt(C): level0 = acc / inv_scale
+    int tiles_x;          // W/32 (fused path)
+    int n2_tiles;         // number of n2 tiles per batch element
+};
+
+template <bool FUSED_POOL>
+__global__ void __launch_bounds__(256)
+pf_corr_kernel(const CorrArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.x * BM;
+    const int tile = blockIdx.y;
+    // n2 of local column col (0..255)
+    int ty0 = 0, tx0 = 0;
+    if (FUSED_POOL) { ty0 = (tile / a.tiles_x) * 8; tx0 = (tile % a.tiles_x) * 32; }
+    auto n2_of = [&](int col) -> int {
+        if (FUSED_POOL) return (ty0 + (col >> 5)) * a.W + tx0 + (col & 31);
+        return tile * BN + col;
+    };
+
+    const float* f1b = a.f1 + (long)b * a.N * a.C;
+    const float* f2b = a.f2 + (long)b * a.N * a.C;
+    const int c4 = (tid & 7) * 4;
+    constexpr int A_V4 = BM * 8 / 256;   // 4
+    constexpr int B_V4 = BN * 8 / 256;   // 8
+    long a_src[A_V4], b_src[B_V4];       // row offsets (floats) or -1
+#pragma unroll
+    for (int q = 0; q < A_V4; ++q) {
+        const int r = (tid + 256 * q) >> 3;
+        a_src[q] = (m0 + r < a.N) ? (long)(m0 + r) * a.C : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < B_V4; ++q) {
+        const int r = (tid + 256 * q) >> 3;
+        const int n2 = n2_of(r);
+        b_src[q] = (n2 < a.N) ? (long)n2 * a.C : -1;
+    }
+    f32x4 ra[A_V4], rb[B_V4];
+    auto load_step = [&](int step) __attribute__((always_inline)) {
+        const int c = step * KC + c4;
+#pragma unroll
+        for (int q = 0; q < A_V4; ++q) {     // branch-free: out-of-range rows read row 0 and are zeroed at LDS-store time
+            ra[q] = *reinterpret_cast<const f32x4*>(f1b + (a_src[q] >= 0 ? a_src[q] : 0) + c);
+        }
+#pragma unroll
+        for (int q = 0; q < B_V4; ++q) {
+            rb[q] = *reinterpret_cast<const f32x4*>(f2b + (b_src[q] >= 0 ? b_src[q] : 0) + c);
+        }
+    };
+    auto store_step = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < A_V4; ++q)
+            *reinterpret_cast<f32x4*>(&As[buf][((tid + 256 * q) >> 3) * LDS_LD + c4]) =
+                a_src[q] >= 0 ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < B_V4; ++q)
+            *reinterpret_cast<f32x4*>(&Bs[buf][((tid + 256 * q) >> 3) * LDS_LD + c4]) =
+                b_src[q] >= 0 ? rb[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nsteps = a.C / KC;
+    const int a_off = (32 * wave + li) * LDS_LD + 16 * lh;
+    const int b_off = li * LDS_LD + 16 * lh;
+
+    load_step(0);
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        store_step(buf);
+        __syncthreads();
+        // unconditional prefetch (the last one re-reads the final K-step; never stored)
+        load_step(step + 1 < nsteps ? step + 1 : step);
+        asm volatile("" ::: "memory");   // keep the prefetch above the MFMA block (see pf_conv_mfma.hip)
+        f32x4 af[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(&As[buf][a_off + 4 * q]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x4 bf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bf[q] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_off + t * 32 * LDS_LD + 4 * q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[q].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf[q].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf[q].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf[q].w, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    // acc[t][r]: n1 = m0 + 32*wave + (r&3) + 8*(r>>2) + 4*lh ; n2 column = 32*t + li
+    const long N = a.N;
+    float* l0 = a.lvl[0] + (long)b * N * N;
+    if (!FUSED_POOL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n1 = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (n1 >= a.N) continue;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int n2 = tile * BN + 32 * t + li;
+                if (n2 < a.N) l0[(long)n1 * N + n2] = acc[t][r] / a.inv_scale;
+            }
+        }
+        return;
+    }
+    const int W1 = a.W >> 1, W2 = a.W >> 2, W3 = a.W >> 3;
+    const long N1 = N >> 2, N2 = N >> 4, N3 = N >> 6;
+    float* l1 = a.lvl[1] + (long)b * N * N1;
+    float* l2 = a.lvl[2] + (long)b * N * N2;
+    float* l3 = a.lvl[3] + (long)b * N * N3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n1 = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;   // < N: BM divides N here
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            v[t] = acc[t][r] / a.inv_scale;
+            l0[(long)n1 * N + (long)(ty0 + t) * a.W + tx0 + li] = v[t];
+        }
+        // level 1: ((v00 + v01) + v10) + v11, * 0.25  (avg_pool2d order: row-major window sum)
+        float p1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float top = v[2 * u], bot = v[2 * u + 1];
+            float s = top + __shfl_down(top, 1);
+            s = s + bot;
+            s = s + __shfl_down(bot, 1);
+            p1[u] = s * 0.25f;
+            if ((li & 1) == 0) l1[(long)n1 * N1 + (long)((ty0 >> 1) + u) * W1 + ((tx0 + li) >> 1)] = p1[u];
+        }
+        float p2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float top = p1[2 * u], bot = p1[2 * u + 1];
+            float s = top + __shfl_down(top, 2);
+            s = s + bot;
+            s = s + __shfl_down(bot, 2);
+            p2[u] = s * 0.25f;
+            if ((li & 3) == 0) l2[(long)n1 * N2 + (long)((ty0 >> 2) + u) * W2 + ((tx0 + li) >> 2)] = p2[u];
+        }
+        {
+            const float top = p2[0], bot = p2[1];
+            float s = top + __shfl_down(top, 4);
+            s = s + bot;
+            s = s + __shfl_down(bot, 4);
+            if ((li & 7) == 0) l3[(long)n1 * N3 + (long)(ty0 >> 3) * W3 + ((tx0 + li) >> 3)] = s * 0.25f;
+        }
+    }
+}
+
+// 2x2 mean of one level into the next (generic path only)
+__global__ void __launch_bounds__(256)
+pf_pool_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int Hs, int Ws) {
+    const int Hd = Hs >> 1, Wd = Ws >> 1;
+    const long total = rows * Hd * Wd;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; idx < total; idx += stride) {
+        const int x = (int)(idx % Wd);
+        const int y = (int)((idx / Wd) % Hd);
+        const long row = idx / ((long)Wd * Hd);
+        const float* s = src + row * Hs * Ws + (long)(2 * y) * Ws + 2 * x;
+        float v = s[0] + s[1];
+        v = v + s[Ws];
+        v = v + s[Ws + 1];
+        dst[idx] = v * 0.25f;
+    }
+}
+
+}  // namespace
+
+extern "C" int pf_corr_pyramid(const float* f1, const float* f2, float* lvl0, float* lvl1,
+                               float* lvl2, float* lvl3, int B, int H8, int W8, int C, void* stream) {
+    if (!f1 || !f2 || !lvl0 || !lvl1 || !lvl2 || !lvl3) return PF_ERR_BAD_ARG;
+    if (B <= 0 || H8 <= 0 || W8 <= 0 || C <= 0 || (C % KC) != 0) return PF_ERR_BAD_SHAPE;
+    if ((H8 % 8) != 0 || (W8 % 8) != 0) return PF_ERR_BAD_SHAPE;
+    CorrArgs a;
+    a.f1 = f1; a.f2 = f2;
+    a.lvl[0] = lvl0; a.lvl[1] = lvl1; a.lvl[2] = lvl2; a.lvl[3] = lvl3;
+    a.B = B; a.H = H8; a.W = W8; a.N = H8 * W8; a.C = C;
+    a.inv_scale = sqrtf((float)C);
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = (W8 % 32) == 0 && (a.N % BM) == 0;
+    if (fused) {
+        a.tiles_x = W8 / 32;
+        a.n2_tiles = (H8 / 8) * a.tiles_x;
+        dim3 grid((unsigned)(a.N / BM), (unsigned)a.n2_tiles, (unsigned)B);
+        hipLaunchKernelGGL(pf_corr_kernel<true>, grid, dim3(256), 0, s, a);
+        return (int)hipGetLastError();
+    }
+    a.tiles_x = 0;
+    a.n2_tiles = (a.N + BN - 1) / BN;
+    dim3 grid((unsigned)((a.N + BM - 1) / BM), (unsigned)a.n2_tiles, (unsigned)B);
+    hipLaunchKernelGGL(pf_corr_kernel<false>, grid, dim3(256), 0, s, a);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    float* lv[4] = {lvl0, lvl1, lvl2, lvl3};
+    const long rows = (long)B * a.N;
+    for (int i = 0; i < 3; ++i) {
+        const int Hs = H8 >> i, Ws = W8 >> i;
+        const long total = rows * (Hs >> 1) * (Ws >> 1);
+        long blocks = (total + 255) / 256;
+        if (blocks > 256L * 64) blocks = 256L * 64;
+        hipLaunchKernelGGL(pf_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lv[i], lv[i + 1],
+                           rows, Hs, Ws);
+        rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    return PF_OK;
+}

@@ -1,0 +1,425 @@
+// Per-element device functions of the non-MFMA kernels (samplers, ERP geometry,
+// DCCL lookups, convex upsampling, small direct convolutions).
+//
+// Each `*_elem(idx, args)` computes ONE output element (or one pixel) and is wrapped by
+// a __global__ kernel in pf_elem_kernels.hip.  The same functions compile for the host
+// (tests/emu) so that index / wrap / padding logic can be checked against the oracle
+// without a GPU; the product only ever runs the device build.
+//
+// Reference citations are relative to /root/reference/PriOr-RAFT.
+#pragma once
+#include "pf_common.h"
+
+// ----------------------------------------------------------------------------------------------
+// scalar helpers
+// ----------------------------------------------------------------------------------------------
+// Python-style float remainder in [0,b) for b>0 (`xgrid % W`, core/utils/utils.py:83;
+// ATen: fmod then +b when the signs differ).
+PF_HD float pf_pymod(float a, float b) {
+    float m = fmodf(a, b);
+    if (m != 0.f && m < 0.f) m += b;
+    return m;
+}
+
+// pixel -> [-1,1] -> pixel round trip of `2x/(W-1)-1` (core/utils/utils.py:85-86) followed
+// by grid_sample(align_corners=True)'s unnormalise, each step rounded to fp32.
+PF_HD float pf_roundtrip(float p, int size) {
+    const float s = (float)(size - 1);
+    float pn = (2.f * p) / s;
+    pn = pn - 1.f;
+    return (pn + 1.f) * (s * 0.5f);
+}
+
+struct PfTaps {          // 4 bilinear taps of a zero-padded sample
+    int idx[4];          // y*W+x (clamped into range; weight is 0 when out of bounds)
+    float w[4];          // nw, ne, sw, se
+};
+
+// Zero-padded bilinear taps at pixel coords (x,y) of an H x W map
+// (F.grid_sample bilinear / zeros / align_corners=True after the callers' normalisation).
+PF_HD PfTaps pf_taps0(float x, float y, int H, int W) {
+    PfTaps t;
+    const float ix = pf_roundtrip(x, W), iy = pf_roundtrip(y, H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float wx = ix - fx, wy = iy - fy;
+    const float ex = 1.f - wx, ey = 1.f - wy;
+    // NaN / huge coordinates: every comparison below is false -> all taps out of bounds
+    const bool xin0 = (fx >= 0.f) && (fx <= (float)(W - 1));
+    const bool xin1 = (fx >= -1.f) && (fx <= (float)(W - 2));
+    const bool yin0 = (fy >= 0.f) && (fy <= (float)(H - 1));
+    const bool yin1 = (fy >= -1.f) && (fy <= (float)(H - 2));
+    const int x0 = xin0 ? (int)fx : 0, x1 = xin1 ? (int)fx + 1 : 0;
+    const int y0 = yin0 ? (int)fy : 0, y1 = yin1 ? (int)fy + 1 : 0;
+    t.idx[0] = y0 * W + x0; t.w[0] = (xin0 && yin0) ? ey * ex : 0.f;
+    t.idx[1] = y0 * W + x1; t.w[1] = (xin1 && yin0) ? ey * wx : 0.f;
+    t.idx[2] = y1 * W + x0; t.w[2] = (xin0 && yin1) ? wy * ex : 0.f;
+    t.idx[3] = y1 * W + x1; t.w[3] = (xin1 && yin1) ? wy * wx : 0.f;
+    return t;
+}
+
+PF_HD float pf_apply(const PfTaps& t, const float* img) {
+    float acc = img[t.idx[0]] * t.w[0];
+    acc = acc + img[t.idx[1]] * t.w[1];
+    acc = acc + img[t.idx[2]] * t.w[2];
+    acc = acc + img[t.idx[3]] * t.w[3];
+    return acc;
+}
+// same, strided (channel-last maps: element (pixel, c) at img[pixel*ld + c])
+PF_HD float pf_apply_ld(const PfTaps& t, const float* img, long ld) {
+    float acc = img[(long)t.idx[0] * ld] * t.w[0];
+    acc = acc + img[(long)t.idx[1] * ld] * t.w[1];
+    acc = acc + img[(long)t.idx[2] * ld] * t.w[2];
+    acc = acc + img[(long)t.idx[3] * ld] * t.w[3];
+    return acc;
+}
+
+// True-wrap (x) / clamp (y) bilinear taps (core/utils/my_cycle_sample.py:31-60).
+struct PfWrapTaps { int ia, ib, ic, id; float wa, wb, wc, wd; };
+PF_HD PfWrapTaps pf_wraptaps(float gx, float gy, int H, int W) {
+    PfWrapTaps t;
+    gx = pf_pymod(gx, (float)W);
+    float fx = floorf(gx), fy = floorf(gy);
+    const float xw = gx - fx, yw = gy - fy;
+    // keep the integer conversion defined for NaN / huge values
+    if (!(fx >= 0.f && fx <= (float)W)) fx = 0.f;
+    if (!(fy >= -1.0e6f)) fy = -1.0e6f;
+    if (!(fy <= 1.0e6f)) fy = 1.0e6f;
+    int x0 = (int)fx, y0 = (int)fy;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 % W; x1 = x1 % W;                      // x0 >= 0 here
+    y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    t.ia = y0 * W + x0; t.ib = y1 * W + x0; t.ic = y0 * W + x1; t.id = y1 * W + x1;
+    t.wa = (1.f - xw) * (1.f - yw);
+    t.wb = (1.f - xw) * yw;
+    t.wc = xw * (1.f - yw);
+    t.wd = xw * yw;
+    return t;
+}
+PF_HD float pf_wrapmix(const PfWrapTaps& t, float a, float b, float c, float d) {
+    float acc = t.wa * a + t.wb * b;
+    acc = acc + t.wc * c;
+    acc = acc + t.wd * d;
+    return acc;
+}
+// seam un-wrapping of the m-channel (core/utils/my_cycle_sample.py:82-97)
+PF_HD float pf_unwrap_m(float anchor, float v, float W) {
+    float t = (v - anchor) + W * 0.5f;
+    t = pf_pymod(t, W);
+    return (anchor + t) - W * 0.5f;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K8: sample grid  (core/utils/projection_prim_ortho.py:432-443 and helpers)
+// ----------------------------------------------------------------------------------------------
+struct PfGridArgs { float* grid; int H, W; float R[9]; };
+PF_HD float pf_nudge(float t) {              // diverge_zero, :69-74
+    const float eps = 1e-6f;
+    const float sgn = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
+    return (fabsf(t) < eps) ? t + sgn * eps : t;
+}
+PF_HD void pf_sample_grid_elem(long idx, const PfGridArgs& a) {
+    const float PI = 3.14159274101257324f;       // float32(np.pi)
+    const float TWO_PI = 6.28318548202514648f;   // float32(2*np.pi)
+    const int m = (int)(idx % a.W), n = (int)(idx / a.W);
+    float u = ((float)m + 0.5f) / (float)a.W;
+    float theta = ((u - 0.5f) * 2.f) * PI;
+    float v = ((float)n + 0.5f) / (float)a.H;
+    float phi = (0.5f - v) * PI;
+    const float cp = cosf(phi);
+    const float x = cp * cosf(theta), y = cp * sinf(theta), z = sinf(phi);
+    const float* R = a.R;
+    float xr = R[0] * x + R[1] * y; xr = xr + R[2] * z;
+    float yr = R[3] * x + R[4] * y; yr = yr + R[5] * z;
+    float zr = R[6] * x + R[7] * y; zr = zr + R[8] * z;
+    const float phi2 = asinf(zr);
+    const float theta2 = atan2f(pf_nudge(yr), pf_nudge(xr));
+    float m2 = theta2 / TWO_PI + 0.5f;
+    m2 = m2 * (float)a.W - 0.5f;
+    float n2 = 0.5f - phi2 / PI;
+    n2 = n2 * (float)a.H - 0.5f;
+    const long hw = (long)a.H * a.W;
+    a.grid[idx] = m2;
+    a.grid[hw + idx] = n2;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K7: img_rotate, NCHW (core/utils/projection_prim_ortho.py:507-514, :119-135)
+// ----------------------------------------------------------------------------------------------
+struct PfImgRotArgs { const float* img; const float* grid; float* out; int B, C, H, W; };
+PF_HD void pf_img_rotate_elem(long idx, const PfImgRotArgs& a) {
+    const long hw = (long)a.H * a.W;
+    const long pix = idx % hw;
+    const long bc = idx / hw;
+    const float gx = pf_pymod(a.grid[pix], (float)a.W);
+    const float gy = a.grid[hw + pix];
+    const PfTaps t = pf_taps0(gx, gy, a.H, a.W);
+    a.out[idx] = pf_apply(t, a.img + bc * hw);
+}
+
+// ----------------------------------------------------------------------------------------------
+// flow = coords1 - coords0, scattered to planar + up to two channel-last destinations
+// (core/prior_raft.py:172,177; coords_grid core/utils/utils.py:98-101)
+// ----------------------------------------------------------------------------------------------
+struct PfDst { float* ptr; int ld; int c_off; };     // channel-last [B*N][ld] destination slice
+struct PfFlowPrepArgs { const float* coords1; float* flow; PfDst d0, d1; int B, H, W; };
+PF_HD void pf_store_dst2(const PfDst& d, long row, float u, float v) {
+    if (d.ptr) { d.ptr[row * d.ld + d.c_off] = u; d.ptr[row * d.ld + d.c_off + 1] = v; }
+}
+PF_HD void pf_flow_prep_elem(long idx, const PfFlowPrepArgs& a) {   // idx over B*N
+    const long N = (long)a.H * a.W;
+    const long b = idx / N, n = idx % N;
+    const float x = (float)(n % a.W), y = (float)(n / a.W);
+    const float u = a.coords1[(b * 2 + 0) * N + n] - x;
+    const float v = a.coords1[(b * 2 + 1) * N + n] - y;
+    if (a.flow) { a.flow[(b * 2 + 0) * N + n] = u; a.flow[(b * 2 + 1) * N + n] = v; }
+    pf_store_dst2(a.d0, idx, u, v);
+    pf_store_dst2(a.d1, idx, u, v);
+}
+
+// ----------------------------------------------------------------------------------------------
+// K6: flo_rotate (core/utils/projection_prim_ortho.py:531-546, :200-218, :234-244;
+//     core/utils/my_cycle_sample.py:6-97)
+// ----------------------------------------------------------------------------------------------
+struct PfFloRotArgs {
+    const float* flow;       // planar [B,2,N]
+    const float* g_w2c;      // [2,N]
+    const float* g_c2w;      // [2,N]
+    float* out;              // planar [B,2,N] (may be null)
+    PfDst d0, d1;
+    int B, H, W;
+};
+// camera-frame flow F at pixel p of batch b
+PF_HD void pf_flow_c_at(const PfFloRotArgs& a, long b, int p, float& f0, float& f1) {
+    const long N = (long)a.H * a.W;
+    const float Wf = (float)a.W;
+    const float px = (float)(p % a.W), py = (float)(p / a.W);
+    float ex = (px + a.flow[(b * 2 + 0) * N + p]) + 0.5f;
+    ex = pf_pymod(ex, Wf) - 0.5f;
+    float ey = py + a.flow[(b * 2 + 1) * N + p];
+    ey = fminf(fmaxf(ey, -0.5f), (float)a.H - 0.5f);
+    const PfWrapTaps t = pf_wraptaps(ex, ey, a.H, a.W);
+    const float* g0 = a.g_w2c;
+    const float* g1 = a.g_w2c + N;
+    const float a0 = g0[t.ia];
+    const float e0 = pf_wrapmix(t, a0, pf_unwrap_m(a0, g0[t.ib], Wf), pf_unwrap_m(a0, g0[t.ic], Wf),
+                                pf_unwrap_m(a0, g0[t.id], Wf));
+    const float e1 = pf_wrapmix(t, g1[t.ia], g1[t.ib], g1[t.ic], g1[t.id]);
+    f0 = e0 - g0[p];
+    f0 = pf_pymod(f0 + Wf * 0.5f, Wf) - Wf * 0.5f;     // u_clip
+    f1 = e1 - g1[p];
+}
+PF_HD void pf_flo_rotate_elem(long idx, const PfFloRotArgs& a) {  // idx over B*N
+    const long N = (long)a.H * a.W;
+    const long b = idx / N, n = idx % N;
+    const PfWrapTaps t = pf_wraptaps(a.g_c2w[n], a.g_c2w[N + n], a.H, a.W);
+    float a0, a1, b0, b1, c0, c1, d0, d1;
+    pf_flow_c_at(a, b, t.ia, a0, a1);
+    pf_flow_c_at(a, b, t.ib, b0, b1);
+    pf_flow_c_at(a, b, t.ic, c0, c1);
+    pf_flow_c_at(a, b, t.id, d0, d1);
+    const float u = pf_wrapmix(t, a0, b0, c0, d0);
+    const float v = pf_wrapmix(t, a1, b1, c1, d1);
+    if (a.out) { a.out[(b * 2 + 0) * N + n] = u; a.out[(b * 2 + 1) * N + n] = v; }
+    pf_store_dst2(a.d0, idx, u, v);
+    pf_store_dst2(a.d1, idx, u, v);
+}
+
+// ----------------------------------------------------------------------------------------------
+// K3 + K4(a,b): own-view and raw cross-view lookups (core/corr.py:113-137)
+// ----------------------------------------------------------------------------------------------
+struct PfLookupArgs {
+    const float* coords;            // planar [B,2,N]
+    const float* own[PF_CORR_LEVELS];    // level i: [B*N][H_i*W_i]
+    const float* other[PF_CORR_LEVELS];
+    const float* g_w2c;             // [2,N]
+    float* own_out;                 // channel-last [B*N][ld]
+    float* raw_out;                 // channel-last [B*N][ld]
+    int B, H, W, ld;
+};
+PF_HD void pf_lookup_elem(long idx, const PfLookupArgs& a) {  // idx over B*N*324
+    const long N = (long)a.H * a.W;
+    const int k = (int)(idx % PF_CORR_CH);
+    const long row = idx / PF_CORR_CH;                 // b*N + n
+    const long b = row / N, n = row % N;
+    const int lvl = k / PF_TAPS, tap = k % PF_TAPS;
+    const int ta = tap / 9, tb = tap % 9;              // slow axis a offsets x (core/corr.py:120-126)
+    const int Hl = a.H >> lvl, Wl = a.W >> lvl;
+    const float inv = 1.f / (float)(1 << lvl);         // coords / 2**i : exact
+    const float cx = a.coords[(b * 2 + 0) * N + n] * inv + (float)(ta - PF_CORR_RADIUS);
+    const float cy = a.coords[(b * 2 + 1) * N + n] * inv + (float)(tb - PF_CORR_RADIUS);
+    const long lsz = (long)Hl * Wl;
+    // own view: x wrapped mod W_i, zero padded
+    {
+        const PfTaps t = pf_taps0(pf_pymod(cx, (float)Wl), cy, Hl, Wl);
+        a.own_out[row * a.ld + k] = pf_apply(t, a.own[lvl] + row * lsz);
+    }
+    // cross view: level-i coordinates index the LEVEL-0 grid (core/corr.py:132-133) ...
+    const PfTaps tg = pf_taps0(pf_pymod(cx, (float)a.W), cy, a.H, a.W);
+    const float gx = pf_apply(tg, a.g_w2c);
+    const float gy = pf_apply(tg, a.g_w2c + N);
+    // ... and the result indexes row n of the OTHER branch's volume (core/corr.py:135-136)
+    {
+        const PfTaps t = pf_taps0(pf_pymod(gx, (float)Wl), gy, Hl, Wl);
+        a.raw_out[row * a.ld + k] = pf_apply(t, a.other[lvl] + row * lsz);
+    }
+}
+
+// K4(c): rotate the raw cross-view lookup back and add the own-view lookup
+// (core/corr.py:138; core/prior_raft.py:187-188).
+struct PfCombineArgs {
+    const float* own; const float* raw;   // channel-last [B*N][ld]
+    const float* g_back;                  // [2,N]
+    float* out;                           // channel-last [B*N][ld_out]
+    int B, H, W, ld, ld_out;
+};
+PF_HD void pf_combine_elem(long idx, const PfCombineArgs& a) {  // idx over B*N*324
+    const long N = (long)a.H * a.W;
+    const int k = (int)(idx % PF_CORR_CH);
+    const long row = idx / PF_CORR_CH;
+    const long b = row / N, n = row % N;
+    const PfTaps t = pf_taps0(pf_pymod(a.g_back[n], (float)a.W), a.g_back[N + n], a.H, a.W);
+    const float cross = pf_apply_ld(t, a.raw + b * N * a.ld + k, a.ld);
+    a.out[row * a.ld_out + k] = a.own[row * a.ld + k] + cross;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K12: convex 8x upsampling (core/prior_raft.py:58-67); flow = coords1 - coords0
+// ----------------------------------------------------------------------------------------------
+struct PfUpsampleArgs {
+    const float* coords1;   // planar [B,2,N]
+    const float* mask;      // channel-last [B*N][ld], channel = 64k + 8i + j (already x0.25)
+    float* out;             // NCHW [B,2,8H,8W]
+    int B, H, W, ld;
+};
+PF_HD void pf_upsample_elem(long idx, const PfUpsampleArgs& a) {  // idx over B*8H*8W
+    const int W8 = 8 * a.W, H8 = 8 * a.H;
+    const long N = (long)a.H * a.W;
+    const int X = (int)(idx % W8);
+    const int Y = (int)((idx / W8) % H8);
+    const long b = idx / ((long)W8 * H8);
+    const int x = X >> 3, j = X & 7, y = Y >> 3, i = Y & 7;
+    const float* mrow = a.mask + (b * N + (long)y * a.W + x) * a.ld + 8 * i + j;
+    float lg[9];
+    float mx = -INFINITY;
+    for (int k = 0; k < 9; ++k) { lg[k] = mrow[64 * k]; mx = fmaxf(mx, lg[k]); }
+    float den = 0.f;
+    for (int k = 0; k < 9; ++k) { lg[k] = expf(lg[k] - mx); den = den + lg[k]; }
+    float su = 0.f, sv = 0.f;
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        float fu = 0.f, fv = 0.f;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {      // F.unfold zero padding
+            const long p = (long)yy * a.W + xx;
+            fu = 8.f * (a.coords1[(b * 2 + 0) * N + p] - (float)xx);
+            fv = 8.f * (a.coords1[(b * 2 + 1) * N + p] - (float)yy);
+        }
+        const float wk = lg[k] / den;
+        su = su + wk * fu;
+        sv = sv + wk * fv;
+    }
+    const long plane = (long)W8 * H8;
+    a.out[(b * 2 + 0) * plane + (long)Y * W8 + X] = su;
+    a.out[(b * 2 + 1) * plane + (long)Y * W8 + X] = sv;
+}
+
+// coords1 += delta  (core/prior_raft.py:193,196); delta is channel-last [B*N][ld]
+struct PfCoordsAddArgs { float* coords1; const float* delta; int B, N, ld; };
+PF_HD void pf_coords_add_elem(long idx, const PfCoordsAddArgs& a) {   // idx over B*N
+    const long b = idx / a.N, n = idx % a.N;
+    a.coords1[(b * 2 + 0) * a.N + n] += a.delta[idx * a.ld + 0];
+    a.coords1[(b * 2 + 1) * a.N + n] += a.delta[idx * a.ld + 1];
+}
+
+// ----------------------------------------------------------------------------------------------
+// small direct convolution, channel-last, stride 1, "same" zero padding, optional ReLU.
+// Used for the tiny-Cin layers (7x7 2->128, 3x3 8->32, 3x3 32->16; core/update.py:171-178,
+// :87).  Weights packed [KH*KW][Cin][Cout].
+// ----------------------------------------------------------------------------------------------
+struct PfDirectConvArgs {
+    const float* in; int ld_in, c_in_off, Cin;
+    const float* w; const float* bias;
+    float* out; int ld_out, c_out_off, Cout;
+    int B, H, W, KH, KW, relu;
+};
+PF_HD void pf_direct_conv_elem(long idx, const PfDirectConvArgs& a) {  // idx over B*N*Cout
+    const long N = (long)a.H * a.W;
+    const int co = (int)(idx % a.Cout);
+    const long row = idx / a.Cout;
+    const long b = row / N, n = row % N;
+    const int y = (int)(n / a.W), x = (int)(n % a.W);
+    const int ph = a.KH / 2, pw = a.KW / 2;
+    float acc = 0.f;
+    for (int kh = 0; kh < a.KH; ++kh) {
+        const int yy = y + kh - ph;
+        if (yy < 0 || yy >= a.H) continue;
+        for (int kw = 0; kw < a.KW; ++kw) {
+            const int xx = x + kw - pw;
+            if (xx < 0 || xx >= a.W) continue;
+            const float* ip = a.in + (b * N + (long)yy * a.W + xx) * a.ld_in + a.c_in_off;
+            const float* wp = a.w + ((long)(kh * a.KW + kw) * a.Cin) * a.Cout + co;
+            for (int c = 0; c < a.Cin; ++c) acc = acc + ip[c] * wp[(long)c * a.Cout];
+        }
+    }
+    acc = acc + a.bias[co];
+    if (a.relu) acc = fmaxf(acc, 0.f);
+    a.out[row * a.ld_out + a.c_out_off + co] = acc;
+}
+
+// ----------------------------------------------------------------------------------------------
+// NCHW -> channel-last slice copy with optional activation (0 none, 1 relu, 2 tanh)
+// (core/prior_raft.py:136-142: net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]))
+// ----------------------------------------------------------------------------------------------
+struct PfToNhwcArgs { const float* in; float* out; int B, C_total, c_begin, C, N, ld_out, c_out_off, act; };
+PF_HD float pf_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return tanhf(v);
+    return v;
+}
+PF_HD void pf_to_nhwc_elem(long idx, const PfToNhwcArgs& a) {   // idx over B*N*C
+    const int c = (int)(idx % a.C);
+    const long row = idx / a.C;
+    const long b = row / a.N, n = row % a.N;
+    const float v = a.in[(b * a.C_total + a.c_begin + c) * (long)a.N + n];
+    a.out[row * a.ld_out + a.c_out_off + c] = pf_act(v, a.act);
+}
+
+// channel-last -> NCHW (debug / boundary export)
+struct PfToNchwArgs { const float* in; float* out; int B, C, N, ld_in, c_in_off; };
+PF_HD void pf_to_nchw_elem(long idx, const PfToNchwArgs& a) {   // idx over B*C*N
+    const long n = idx % a.N;
+    const long bc = idx / a.N;
+    const long b = bc / a.C, c = bc % a.C;
+    a.out[idx] = a.in[(b * a.N + n) * a.ld_in + a.c_in_off + c];
+}
+
+// ----------------------------------------------------------------------------------------------
+// K5: warp + groupwise correlation, per pixel (core/prior_raft.py:173-174, :77-83).
+// One output pixel = 4 group means; the device kernel spreads the 256 channels over one
+// wavefront (see pf_elem_kernels.hip); this scalar form is the host/emu statement.
+// ----------------------------------------------------------------------------------------------
+struct PfWarpGcorrArgs {
+    const float* f1; const float* f2;   // channel-last [B*N][C]
+    const float* coords;                // planar [B,2,N]: absolute coords, or a flow when add_grid
+    PfDst dst;                          // 4 channels written at dst.c_off
+    int B, H, W, C, add_grid;
+};
+PF_HD PfTaps pf_warp_taps(const PfWarpGcorrArgs& a, long b, long n) {
+    const long N = (long)a.H * a.W;
+    float x = a.coords[(b * 2 + 0) * N + n], y = a.coords[(b * 2 + 1) * N + n];
+    if (a.add_grid) { x = (float)(n % a.W) + x; y = (float)(n / a.W) + y; }   // coords0 + flow
+    return pf_taps0(pf_pymod(x, (float)a.W), y, a.H, a.W);
+}
+PF_HD void pf_warp_gcorr_elem(long idx, const PfWarpGcorrArgs& a) {   // idx over B*N*4
+    const long N = (long)a.H * a.W;
+    const int g = (int)(idx % 4);
+    const long row = idx / 4;
+    const long b = row / N, n = row % N;
+    const PfTaps t = pf_warp_taps(a, b, n);
+    const int cg = a.C / 4;
+    const float* f2b = a.f2 + b * N * a.C;
+    float acc = 0.f;
+    for (int c = g * cg; c < (g + 1) * cg; ++c)
+        acc = acc + a.f1[row * a.C + c] * pf_apply_ld(t, f2b + c, a.C);
+    a.dst.ptr[row * a.dst.ld + a.dst.c_off + g] = acc / (float)cg;
+}

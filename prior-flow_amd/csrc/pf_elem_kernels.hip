@@ -1,0 +1,88 @@
+// __global__ wrappers + C-ABI launchers of the per-element kernels (gfx950).
+// The math lives in pf_elem.h; see include/priorflow_hip.h for the ABI contract.
+#include "pf_elem.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr long kMaxBlocks = 256L * 64;   // 256 CUs x 64 blocks, grid-stride beyond that
+
+template <class Args, void (*F)(long, const Args&)>
+__global__ void __launch_bounds__(kBlock) pf_elem_kernel(const Args a, const long total) {
+    long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long stride = (long)gridDim.x * kBlock;
+    for (; idx < total; idx += stride) F(idx, a);
+}
+
+template <class Args, void (*F)(long, const Args&)>
+int pf_launch_elem(const Args& a, long total, void* stream) {
+    if (total <= 0) return PF_OK;
+    long blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL((pf_elem_kernel<Args, F>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       (hipStream_t)stream, a, total);
+    return (int)hipGetLastError();
+}
+
+// K5 on a wavefront: one pixel per wave, 4 channels per lane (C == 256), the four 64-channel
+// group sums reduced with 16-lane butterfly shuffles.
+__global__ void __launch_bounds__(kBlock) pf_warp_gcorr_wave(const PfWarpGcorrArgs a, const long rows) {
+    const int lane = threadIdx.x & 63;
+    const long N = (long)a.H * a.W;
+    long row = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * (kBlock / 64);
+    for (; row < rows; row += stride) {
+        const long b = row / N, n = row % N;
+        const PfTaps t = pf_warp_taps(a, b, n);
+        const float4 v1 = reinterpret_cast<const float4*>(a.f1 + row * 256)[lane];
+        const float* f2b = a.f2 + b * N * 256;
+        float4 s;
+        {
+            const float4 v = reinterpret_cast<const float4*>(f2b + (long)t.idx[0] * 256)[lane];
+            s.x = v.x * t.w[0]; s.y = v.y * t.w[0]; s.z = v.z * t.w[0]; s.w = v.w * t.w[0];
+        }
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 v = reinterpret_cast<const float4*>(f2b + (long)t.idx[q] * 256)[lane];
+            s.x = s.x + v.x * t.w[q]; s.y = s.y + v.y * t.w[q];
+            s.z = s.z + v.z * t.w[q]; s.w = s.w + v.w * t.w[q];
+        }
+        float p = v1.x * s.x;
+        p = p + v1.y * s.y;
+        p = p + v1.z * s.z;
+        p = p + v1.w * s.w;
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        p += __shfl_xor(p, 4);
+        p += __shfl_xor(p, 8);
+        if ((lane & 15) == 0) a.dst.ptr[row * a.dst.ld + a.dst.c_off + (lane >> 4)] = p / 64.f;
+    }
+}
+
+}  // namespace
+
+#define PF_LAUNCH(name, args, total, stream) \
+    pf_launch_elem<decltype(args), pf_##name##_elem>(args, total, stream)
+
+#include "pf_api_elem.inc"
+
+extern "C" int pf_warp_gcorr(const float* f1, const float* f2, const float* coords, int add_grid,
+                             float* dst, int dst_ld, int dst_off, int B, int H8, int W8, int C,
+                             void* stream) {
+    PfWarpGcorrArgs a;
+    const int rc = pf_warp_gcorr_fill(a, f1, f2, coords, add_grid, dst, dst_ld, dst_off, B, H8, W8, C);
+    if (rc != PF_OK) return rc;
+    const long rows = (long)B * H8 * W8;
+    if (C == 256) {
+        long blocks = (rows + 3) / 4;
+        if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+        hipLaunchKernelGGL(pf_warp_gcorr_wave, dim3((unsigned)blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, a, rows);
+        return (int)hipGetLastError();
+    }
+    return PF_LAUNCH(warp_gcorr, a, rows * 4, stream);
+}
+
+extern "C" const char* pf_version(void) {
+    return "priorflow-hip r1 gfx950 (fp32 MFMA 32x32x2 implicit-GEMM convs, fused corr+pyramid)";
+}

@@ -1,0 +1,352 @@
+"""Launch plan of the PriOr-RAFT inner loop on the HIP library.
+
+``Engine`` owns (per input shape) the device workspace -- every buffer of the loop is
+allocated once through torch and stays resident in HBM -- and the packed weights, and
+turns one forward into a fixed sequence of C-ABI launches on the current stream
+(capturable into a HIP graph, see ``PriOr_RAFT``).  All arithmetic of the loop runs in
+``libpriorflow_hip.so``; torch only provides memory and streams here.
+
+Layouts: activations are channel-last rows ``[B*N, ld]``; concatenations of the reference
+(``torch.cat`` in core/update.py:96-99,155,195-201) never materialise -- producers write
+into column slices of the consumer's row buffer.
+
+    x_a  = [ inp_A (128) | conv_A out (124) | flow_A (2) | flow_B_A (2) ]   GRU input of ODDC
+    x_b  = [ inp_B (128) | conv out   (126) | flow_B (2) ]                  GRU input of update_block
+    catA = [ cor (128) | floA (64) | floB (64) | conf (16) ]                input of conv_A
+    catB = [ cor (192) | flo (64) ]                                         input of conv
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from ._lib import (ACT_RELU, ACT_TANH, EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_RELU, ConvDesc,
+                   PfError, PfLib)
+
+CORR_CH = 324
+
+
+def rotation_x(theta: float) -> torch.Tensor:
+    """R = Rz(0) Ry(0) Rx(theta) built in fp32 like generate_rotation_metrix
+    (core/utils/projection_prim_ortho.py:23-48): cos(fp32(+-pi/2)) = -4.371139e-8, not 0."""
+    c = torch.cos(torch.tensor(theta)).float().item()
+    s = torch.sin(torch.tensor(theta)).float().item()
+    return torch.tensor([[1.0, 0.0, 0.0], [0.0, c, -s], [0.0, s, c]], dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------
+# weight packing (host-side plumbing; runs once per weight version)
+# ------------------------------------------------------------------------------------------
+def pack_mfma(w: torch.Tensor, b: torch.Tensor):
+    """[Cout,Cin,KH,KW] -> [Cout_pad128][KH*KW][Cin_pad32] (zero filled), bias [Cout_pad128]."""
+    cout, cin, kh, kw = w.shape
+    cp = (cin + 31) // 32 * 32
+    op = (cout + 127) // 128 * 128
+    wp = torch.zeros(op, kh * kw, cp, dtype=torch.float32, device=w.device)
+    wp[:cout, :, :cin] = w.detach().float().permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    bp = torch.zeros(op, dtype=torch.float32, device=w.device)
+    bp[:cout] = b.detach().float()
+    return wp.contiguous(), bp.contiguous()
+
+
+def pack_direct(w: torch.Tensor, b: torch.Tensor):
+    """[Cout,Cin,KH,KW] -> [KH*KW][Cin][Cout]."""
+    cout, cin, kh, kw = w.shape
+    wp = w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, cin, cout).contiguous()
+    return wp, b.detach().float().contiguous()
+
+
+class Conv:
+    """One packed convolution (MFMA implicit-GEMM path)."""
+
+    def __init__(self, w, b, kh, kw, cin, cout):
+        self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
+
+    @staticmethod
+    def of(mod) -> "Conv":
+        w, b = pack_mfma(mod.weight, mod.bias)
+        return Conv(w, b, mod.weight.shape[2], mod.weight.shape[3], mod.weight.shape[1], mod.weight.shape[0])
+
+    @staticmethod
+    def fused(mod_z, mod_r) -> "Conv":
+        """convz|convr share their input (core/update.py:48-49): one 384->256 GEMM."""
+        w = torch.cat([mod_z.weight, mod_r.weight], 0)
+        b = torch.cat([mod_z.bias, mod_r.bias], 0)
+        wp, bp = pack_mfma(w, b)
+        return Conv(wp, bp, w.shape[2], w.shape[3], w.shape[1], w.shape[0])
+
+    def desc(self, in0, off0, c0, out, off_out, epilogue, in1=None, off1=0, c1=0, scale=1.0,
+             h=None, z=None, aux=None) -> ConvDesc:
+        assert c0 + c1 == self.cin, (c0, c1, self.cin)
+        d = ConvDesc()
+        d.in0, d.ld0, d.off0, d.c0 = in0.data_ptr(), in0.shape[-1], off0, c0
+        d.in1 = in1.data_ptr() if in1 is not None else None
+        d.ld1, d.off1, d.c1 = (in1.shape[-1] if in1 is not None else 0), off1, c1
+        d.weight, d.bias = self.w.data_ptr(), self.b.data_ptr()
+        d.out, d.ld_out, d.off_out, d.cout = out.data_ptr(), out.shape[-1], off_out, self.cout
+        d.kh, d.kw, d.epilogue, d.scale = self.kh, self.kw, epilogue, scale
+        d.h = h.data_ptr() if h is not None else None
+        d.ld_h = h.shape[-1] if h is not None else 0
+        d.z = z.data_ptr() if z is not None else None
+        d.ld_z = z.shape[-1] if z is not None else 0
+        d.aux_out = aux.data_ptr() if aux is not None else None
+        d.ld_aux = aux.shape[-1] if aux is not None else 0
+        return d
+
+
+class DirectConv:
+    def __init__(self, mod):
+        self.w, self.b = pack_direct(mod.weight, mod.bias)
+        self.cout, self.cin, self.kh, self.kw = mod.weight.shape
+
+
+def pack_update_blocks(oddc, upd) -> Dict[str, object]:
+    ea, eb = oddc.encoder, upd.encoder
+    P: Dict[str, object] = {
+        "a.c1": Conv.of(ea.convc1_A), "a.c2": Conv.of(ea.convc2_A),
+        "a.f1a": DirectConv(ea.convf1_A), "a.f2a": Conv.of(ea.convf2_A),
+        "a.f1b": DirectConv(ea.convf1_B), "a.f2b": Conv.of(ea.convf2_B),
+        "a.cf1": DirectConv(ea.conv_conf1), "a.cf2": DirectConv(ea.conv_conf2),
+        "a.out": Conv.of(ea.conv_A),
+        "b.c1": Conv.of(eb.convc1), "b.c2": Conv.of(eb.convc2),
+        "b.f1": DirectConv(eb.convf1), "b.f2": Conv.of(eb.convf2), "b.out": Conv.of(eb.conv),
+    }
+    for tag, blk in (("a", oddc), ("b", upd)):
+        g = blk.gru
+        P[f"{tag}.zr1"] = Conv.fused(g.convz1, g.convr1)
+        P[f"{tag}.q1"] = Conv.of(g.convq1)
+        P[f"{tag}.zr2"] = Conv.fused(g.convz2, g.convr2)
+        P[f"{tag}.q2"] = Conv.of(g.convq2)
+        P[f"{tag}.fh1"] = Conv.of(blk.flow_head.conv1)
+        P[f"{tag}.fh2"] = Conv.of(blk.flow_head.conv2)
+        P[f"{tag}.m0"] = Conv.of(blk.mask[0])
+        P[f"{tag}.m2"] = Conv.of(blk.mask[2])
+    return P
+
+
+# ------------------------------------------------------------------------------------------
+class Workspace:
+    """All device buffers of one (B, H, W) problem; allocated once, reused every call."""
+
+    def __init__(self, lib: PfLib, B: int, H: int, W: int, device):
+        if H % 64 or W % 64:
+            raise PfError(f"image size {H}x{W}: the HIP path needs H and W to be multiples of 64 "
+                          "(H/8 and W/8 multiples of 8 so that every pyramid level pools exactly)")
+        self.B, self.H, self.W = B, H, W
+        self.H8, self.W8 = H // 8, W // 8
+        self.N = self.H8 * self.W8
+        self.device = device
+        N, H8, W8 = self.N, self.H8, self.W8
+        rows = B * N
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)  # noqa: E731
+        # ---- sample grids (constant per shape; K8).  grid(R_A2B^T) == grid(R_B2A) bit-exactly,
+        # so only the two directions are generated (core/prior_raft.py:115-125 builds 8).
+        self.g_a2b = z(2, H, W)
+        self.g_a2b_8 = z(2, H8, W8)
+        self.g_b2a_8 = z(2, H8, W8)
+        r_a2b, r_b2a = rotation_x(-math.pi / 2), rotation_x(math.pi / 2)
+        lib.sample_grid(self.g_a2b, r_a2b)
+        lib.sample_grid(self.g_a2b_8, r_a2b)
+        lib.sample_grid(self.g_b2a_8, r_b2a)
+        # ---- encoders' side
+        self.img_stack = z(B, 6, H, W)
+        self.img_rot = z(B, 6, H, W)
+        self.f = {k: z(rows, 256) for k in ("f1a", "f2a", "f1b", "f2b")}
+        # ---- pyramids: level i rows [B*N, (H8>>i)*(W8>>i)]
+        self.pyr_a = [z(rows, (H8 >> i) * (W8 >> i)) for i in range(4)]
+        self.pyr_b = [z(rows, (H8 >> i) * (W8 >> i)) for i in range(4)]
+        # ---- loop state
+        self.c1a = z(B, 2, H8, W8)
+        self.c1b = z(B, 2, H8, W8)
+        self.flow_b = z(B, 2, H8, W8)
+        self.flow_ba = z(B, 2, H8, W8)
+        self.flow_tmp = z(B, 2, H8, W8)
+        self.net_a = [z(rows, 128), z(rows, 128)]
+        self.net_b = [z(rows, 128), z(rows, 128)]
+        self.x_a = z(rows, 256)
+        self.x_b = z(rows, 256)
+        self.z_a, self.z_b = z(rows, 128), z(rows, 128)
+        self.rh_a, self.rh_b = z(rows, 128), z(rows, 128)
+        self.own, self.raw = z(rows, CORR_CH), z(rows, CORR_CH)
+        self.corr_a, self.corr_b = z(rows, CORR_CH), z(rows, CORR_CH)
+        self.c1_a, self.c1_b = z(rows, 256), z(rows, 256)
+        self.cat_a, self.cat_b = z(rows, 272), z(rows, 256)
+        self.flow4_a = z(rows, 4)          # [flow_A | flow_B_A]
+        self.flow2_b = z(rows, 2)
+        self.t_a, self.t_ba, self.t_b = z(rows, 128), z(rows, 128), z(rows, 128)
+        self.conf_in, self.conf_mid = z(rows, 8), z(rows, 32)
+        self.fh_a, self.fh_b, self.mh_a, self.mh_b = z(rows, 256), z(rows, 256), z(rows, 256), z(rows, 256)
+        self.delta_a, self.delta_b = z(rows, 4), z(rows, 4)
+        self.mask_a, self.mask_b = z(rows, 576), z(rows, 576)
+
+    def nbytes(self) -> int:
+        tot = 0
+        for v in self.__dict__.values():
+            for t in (v if isinstance(v, (list, tuple)) else (v.values() if isinstance(v, dict) else [v])):
+                if isinstance(t, torch.Tensor):
+                    tot += t.numel() * t.element_size()
+        return tot
+
+
+class Engine:
+    def __init__(self, lib: PfLib):
+        self.lib = lib
+
+    # ---- stage 0: view B images --------------------------------------------------------------
+    def rotate_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
+        """img_rotate(cat[image1,image2], A2B) (core/prior_raft.py:127).  Inputs already
+        normalised to [-1,1].  Returns views (image1_B, image2_B)."""
+        ws.img_stack[:, :3].copy_(image1)
+        ws.img_stack[:, 3:].copy_(image2)
+        self.lib.img_rotate(ws.img_stack, ws.g_a2b, ws.img_rot)
+        return ws.img_rot[:, :3], ws.img_rot[:, 3:]
+
+    # ---- stage 1: features -> channel-last, corr volumes + pyramids --------------------------
+    def load_features(self, ws: Workspace, fmaps: torch.Tensor, cnet: torch.Tensor):
+        """fmaps: NCHW [4B,256,H8,W8] = (f1A,f2A,f1B,f2B); cnet: NCHW [2B,256,H8,W8] = (A,B).
+        net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) (core/prior_raft.py:136-142)."""
+        B, lib = ws.B, self.lib
+        for i, k in enumerate(("f1a", "f2a", "f1b", "f2b")):
+            lib.to_channel_last(fmaps[i * B:(i + 1) * B].contiguous(), 0, 256, ws.f[k], 0)
+        ca, cb = cnet[:B].contiguous(), cnet[B:].contiguous()
+        lib.to_channel_last(ca, 0, 128, ws.net_a[0], 0, ACT_TANH)
+        lib.to_channel_last(ca, 128, 128, ws.x_a, 0, ACT_RELU)
+        lib.to_channel_last(cb, 0, 128, ws.net_b[0], 0, ACT_TANH)
+        lib.to_channel_last(cb, 128, 128, ws.x_b, 0, ACT_RELU)
+
+    def build_pyramids(self, ws: Workspace):
+        """corr + build_pyramid for both views (core/prior_raft.py:151-159)."""
+        self.lib.corr_pyramid(ws.f["f1a"], ws.f["f2a"], ws.pyr_a, ws.B, ws.H8, ws.W8)
+        self.lib.corr_pyramid(ws.f["f1b"], ws.f["f2b"], ws.pyr_b, ws.B, ws.H8, ws.W8)
+
+    def init_coords(self, ws: Workspace, init_flow: Optional[torch.Tensor]):
+        """initialize_flow (+ init_flow) (core/prior_raft.py:161-165)."""
+        B, H8, W8 = ws.B, ws.H8, ws.W8
+        xs = torch.arange(W8, device=ws.device, dtype=torch.float32).view(1, 1, 1, W8).expand(B, 1, H8, W8)
+        ys = torch.arange(H8, device=ws.device, dtype=torch.float32).view(1, 1, H8, 1).expand(B, 1, H8, W8)
+        c0 = torch.cat([xs, ys], 1)
+        ws.c1a.copy_(c0)
+        ws.c1b.copy_(c0)
+        if init_flow is not None:
+            fl = init_flow.to(torch.float32).contiguous()
+            ws.c1a.add_(fl)
+            # flo_rotate(init_flow, W2C = grid(R_A2B^T) == grid(R_B2A), C2W = grid(R_A2B))
+            self.lib.flo_rotate(fl, ws.g_b2a_8, ws.g_a2b_8, ws.flow_tmp)
+            ws.c1b.add_(ws.flow_tmp)
+
+    # ---- one refinement iteration (core/prior_raft.py:170-211) --------------------------------
+    def iteration(self, ws: Workspace, P: Dict[str, object], cur: int, need_b: bool, mask_a: bool,
+                  mask_b: bool) -> int:
+        """Runs one iteration; hidden states are read from net_x[cur] and end in net_x[cur]
+        (two GRU half-steps ping-pong).  need_b=False skips branch B's update (its result is
+        dead in the last test_mode iteration); mask_x selects the mask heads."""
+        self.prep_and_lookup(ws, need_b)
+        cur = self.update_blocks(ws, P, cur, need_b, mask_a, mask_b)
+        self.lib.coords_add(ws.c1a, ws.delta_a)           # coords1 += delta_flow (:193,196)
+        if need_b:
+            self.lib.coords_add(ws.c1b, ws.delta_b)
+        return cur
+
+    def prep_and_lookup(self, ws: Workspace, need_b: bool):
+        """flows, flo_rotate, feature warps and the DCCL lookups of one iteration (:171-188)."""
+        lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
+        # flows (K6), warps (K5)
+        lib.flow_prep(ws.c1a, None, ws.flow4_a, 0, ws.x_a, 252)
+        lib.flow_prep(ws.c1b, ws.flow_b, ws.flow2_b, 0, ws.x_b, 254)
+        # flo_rotate(flow_B, W2C = grid(R_B2A^T) == grid(R_A2B), C2W = grid(R_B2A))  (:179)
+        lib.flo_rotate(ws.flow_b, ws.g_a2b_8, ws.g_b2a_8, ws.flow_ba, ws.flow4_a, 2, ws.x_a, 254)
+        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.c1a, False, ws.conf_in, 0)
+        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.flow_ba, True, ws.conf_in, 4)
+        # DCCL lookups (K3+K4): A looks into B through grid(R_A2B^T)==grid(R_B2A), rotates back
+        # with grid(R_B2A) (:185); B the other way round (:186)
+        lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+        lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+        if need_b:
+            lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own, ws.raw)
+            lib.dccl_combine(ws.own, ws.raw, ws.g_a2b_8, ws.corr_b, B, H8, W8)
+
+    def update_blocks(self, ws: Workspace, P: Dict[str, object], cur: int, need_b: bool, mask_a: bool,
+                      mask_b: bool) -> int:
+        """ODDC (branch A) and update_block (branch B) (core/update.py:152-159, :129-136).
+        Inputs: corr_x, flow4_a / flow2_b, conf_in, x_x (inp + flow tail), net_x[cur].
+        Outputs: net_x[cur], delta_x, mask_x."""
+        lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
+        like = ws.x_a
+
+        def conv(descs):
+            lib.conv2d(descs, B, H8, W8, like)
+
+        def direct(dc: DirectConv, x, off_in, out, off_out, relu=True):
+            lib.conv2d_direct(x, off_in, dc.cin, dc.w, dc.b, out, off_out, dc.cout, dc.kh, dc.kw, relu,
+                              B, H8, W8)
+
+        # motion encoders (core/update.py:183-201, :91-99); A and B side by side where the
+        # GEMM geometry matches
+        d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
+        if need_b:
+            d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, ws.c1_b, 0, EPI_RELU))
+        conv(d)
+        d = [P["a.c2"].desc(ws.c1_a, 0, 256, ws.cat_a, 0, EPI_RELU)]
+        if need_b:
+            d.append(P["b.c2"].desc(ws.c1_b, 0, 256, ws.cat_b, 0, EPI_RELU))
+        conv(d)
+        direct(P["a.f1a"], ws.flow4_a, 0, ws.t_a, 0)
+        direct(P["a.f1b"], ws.flow4_a, 2, ws.t_ba, 0)
+        d = [P["a.f2a"].desc(ws.t_a, 0, 128, ws.cat_a, 128, EPI_RELU),
+             P["a.f2b"].desc(ws.t_ba, 0, 128, ws.cat_a, 192, EPI_RELU)]
+        if need_b:
+            direct(P["b.f1"], ws.flow2_b, 0, ws.t_b, 0)
+            d.append(P["b.f2"].desc(ws.t_b, 0, 128, ws.cat_b, 192, EPI_RELU))
+        conv(d)
+        direct(P["a.cf1"], ws.conf_in, 0, ws.conf_mid, 0)
+        direct(P["a.cf2"], ws.conf_mid, 0, ws.cat_a, 256)
+        conv([P["a.out"].desc(ws.cat_a, 0, 272, ws.x_a, 128, EPI_RELU)])
+        if need_b:
+            conv([P["b.out"].desc(ws.cat_b, 0, 256, ws.x_b, 128, EPI_RELU)])
+
+        # SepConvGRU (core/update.py:46-60): z|r fused GEMM with sigmoid + r*h epilogue, then q
+        # with the tanh + blend epilogue; horizontal (1x5) then vertical (5x1)
+        branches = [("a", ws.net_a, ws.x_a, ws.z_a, ws.rh_a)]
+        if need_b:
+            branches.append(("b", ws.net_b, ws.x_b, ws.z_b, ws.rh_b))
+        c = cur
+        for tag in ("1", "2"):
+            conv([P[f"{t}.zr{tag}"].desc(net[c], 0, 128, zb, 0, EPI_GRU_ZR, in1=x, off1=0, c1=256,
+                                          h=net[c], aux=rh) for t, net, x, zb, rh in branches])
+            conv([P[f"{t}.q{tag}"].desc(rh, 0, 128, net[c ^ 1], 0, EPI_GRU_Q, in1=x, off1=0, c1=256,
+                                         h=net[c], z=zb) for t, net, x, zb, rh in branches])
+            c ^= 1
+        assert c == cur
+
+        # heads (core/update.py:13-14, :124-136): the 3x3 128->256 stems share their input `net`
+        d = [P["a.fh1"].desc(ws.net_a[c], 0, 128, ws.fh_a, 0, EPI_RELU)]
+        if need_b:
+            d.append(P["b.fh1"].desc(ws.net_b[c], 0, 128, ws.fh_b, 0, EPI_RELU))
+        if mask_a:
+            d.append(P["a.m0"].desc(ws.net_a[c], 0, 128, ws.mh_a, 0, EPI_RELU))
+        if mask_b and need_b:
+            d.append(P["b.m0"].desc(ws.net_b[c], 0, 128, ws.mh_b, 0, EPI_RELU))
+        conv(d)
+        d = [P["a.fh2"].desc(ws.fh_a, 0, 256, ws.delta_a, 0, EPI_LINEAR)]
+        if need_b:
+            d.append(P["b.fh2"].desc(ws.fh_b, 0, 256, ws.delta_b, 0, EPI_LINEAR))
+        conv(d)
+        d = []
+        if mask_a:
+            d.append(P["a.m2"].desc(ws.mh_a, 0, 256, ws.mask_a, 0, EPI_LINEAR, scale=0.25))
+        if mask_b and need_b:
+            d.append(P["b.m2"].desc(ws.mh_b, 0, 256, ws.mask_b, 0, EPI_LINEAR, scale=0.25))
+        if d:
+            conv(d)
+
+        return c
+
+    def upsample(self, ws: Workspace, branch: str, out: torch.Tensor):
+        """upsample_flow (core/prior_raft.py:58-67) for branch 'a' or 'b' into out [B,2,H,W]."""
+        if branch == "a":
+            self.lib.upsample_flow(ws.c1a, ws.mask_a, out)
+        else:
+            self.lib.upsample_flow(ws.c1b, ws.mask_b, out)
+        return out

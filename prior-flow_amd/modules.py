@@ -41,6 +41,13 @@ class ResidualBlock(nn.Module):
             self.norm3 = _norm(kind, ch)
             self.downsample = nn.Sequential(_conv(cin, ch, 1, 0, stride), self.norm3)
 
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
 
 class BasicEncoder(nn.Module):
     def __init__(self, output_dim, norm_fn, dropout=0.0):
@@ -60,6 +67,16 @@ class BasicEncoder(nn.Module):
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        """x: one NCHW batch (callers concatenate the image list on dim 0 themselves).
+        SURVEY.md §8f rank 1: the encoders still run on PyTorch-ROCm convolutions."""
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        x = self.conv2(x)
+        if self.training and self.dropout is not None:
+            x = self.dropout(x)
+        return x
 
 
 # ---- update blocks (core/update.py) ----------------------------------------------------------

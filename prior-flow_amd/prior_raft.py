@@ -1,2 +1,179 @@
-"""placeholder — replaced below once the HIP host wrapper exists"""
-from .modules import state_dict_shapes  # noqa: F401
+"""Drop-in ``PriOr_RAFT`` for MI355X: same constructor, ``forward`` signature, return types
+and ``state_dict`` as the reference module (PriOr-RAFT/core/prior_raft.py:27-215), with the
+inner loop running in hand-written gfx950 kernels (``libpriorflow_hip.so``).
+
+    model = PriOr_RAFT(args).cuda().eval()
+    flow  = model(image1, image2, iters=12, test_mode=True)      # [B,2,H,W]
+
+Callers covered: demo.py:11-19, demo_image.py:30-39, evaluate.py:208,266,318,350,382 (all
+inference).  The training caller (train_flow.py:131) needs the backward kernels, which this
+round does not ship: a forward with autograd enabled in train() mode raises instead of
+silently returning non-differentiable tensors.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import Engine, Workspace, pack_update_blocks
+from .modules import BasicEncoder, build_tree, state_dict_shapes  # noqa: F401
+
+
+class PriOr_RAFT(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.hidden_dim = 128
+        self.context_dim = 128
+        args.corr_levels = 4          # the reference writes these back (core/prior_raft.py:34-35)
+        args.corr_radius = 4
+        dropout = float(getattr(args, "dropout", 0.0))
+        self.fnet, self.cnet, self.ODDC, self.update_block = build_tree(dropout)
+        # non-module state (not part of state_dict)
+        self._packed: Optional[Dict[str, object]] = None
+        self._packed_sig = None
+        self._ws: Dict[Tuple, Workspace] = {}
+        self._graphs: Dict[Tuple, object] = {}
+        self.use_graph = os.environ.get("PRIORFLOW_GRAPH", "1") != "0"
+
+    # ---- reference API surface ----------------------------------------------------------------
+    def freeze_bn(self):
+        """core/prior_raft.py:43-48."""
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.SyncBatchNorm)):
+                m.eval()
+
+    def load_things_ckpt(self, ckpt_path):
+        """RAFT-things import with the update_block.* -> ODDC.* remap (core/prior_raft.py:85-104)."""
+        raw = torch.load(ckpt_path, map_location=torch.device("cpu"))
+        ckpt = {k[7:]: v for k, v in raw.items() if k.startswith("module.")}
+        state = self.state_dict()
+        for key in state.keys():
+            if key in ckpt and state[key].shape == ckpt[key].shape:
+                state[key] = ckpt[key]
+                continue
+            alt = key.replace("ODDC", "update_block")
+            if ("ODDC" in key and any(s in key for s in (".gru.", ".flow_head.", ".mask."))
+                    and alt in ckpt and state[key].shape == ckpt[alt].shape):
+                state[key] = ckpt[alt]
+            else:
+                print(f"Skip loading parameter: {key}, not found in checkpoint")
+        self.load_state_dict(state, strict=True)
+
+    # ---- internals ----------------------------------------------------------------------------
+    def _lib(self) -> _lib.PfLib:
+        return _lib.load()       # raises loudly when the HIP library is missing
+
+    def _weights(self):
+        params = list(self.ODDC.parameters()) + list(self.update_block.parameters())
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is None or sig != self._packed_sig:
+            with torch.no_grad():
+                self._packed = pack_update_blocks(self.ODDC, self.update_block)
+            self._packed_sig = sig
+            self._graphs.clear()
+        return self._packed
+
+    def _workspace(self, B, H, W, device) -> Workspace:
+        key = (B, H, W, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = Workspace(self._lib(), B, H, W, device)
+            self._ws = {key: ws}          # keep one shape resident (288 GB HBM, but be polite)
+            self._graphs.clear()
+        return ws
+
+    def _encode(self, image1, image2, ws: Workspace, eng: Engine):
+        """Normalise, rotate to view B, run cnet / fnet (core/prior_raft.py:109-149).
+        SURVEY.md §8f rank 1: the encoders run on PyTorch-ROCm convolutions this round."""
+        B = ws.B
+        image1 = 2 * (image1 / 255.0) - 1.0
+        image2 = 2 * (image2 / 255.0) - 1.0
+        image1_b, image2_b = eng.rotate_images(ws, image1, image2)
+        amp = bool(getattr(self.args, "mixed_precision", False))
+        with torch.autocast("cuda", enabled=amp):
+            cnet = self.cnet(torch.cat([image1, image1_b], 0))
+            fmaps = self.fnet(torch.cat([image1, image2, image1_b, image2_b], 0))
+        return fmaps.float(), cnet.float()
+
+    def _run(self, ws: Workspace, image1, image2, iters, init_flow, test_mode, out_a, out_b):
+        eng = Engine(self._lib())
+        P = self._weights()
+        fmaps, cnet = self._encode(image1, image2, ws, eng)
+        eng.load_features(ws, fmaps, cnet)
+        eng.build_pyramids(ws)
+        eng.init_coords(ws, init_flow)
+        cur = 0
+        for it in range(iters):
+            last = it == iters - 1
+            if test_mode:
+                # dead-work elimination: only the last prediction of branch A is returned
+                # (core/prior_raft.py:212-213), so 23 of 24 upsamples, every B mask head and
+                # branch B's last update are never observable.
+                cur = eng.iteration(ws, P, cur, need_b=not last, mask_a=last, mask_b=False)
+                if last:
+                    eng.upsample(ws, "a", out_a[0])
+            else:
+                cur = eng.iteration(ws, P, cur, need_b=True, mask_a=True, mask_b=True)
+                eng.upsample(ws, "a", out_a[it])
+                eng.upsample(ws, "b", out_b[it])
+
+    def forward(self, image1, image2, iters=12, init_flow=None, test_mode=False, flow_init=None):
+        """Estimate optical flow between a pair of ERP frames (core/prior_raft.py:107).
+        ``flow_init`` is accepted as an alias of ``init_flow`` (BASELINE.json spells it so)."""
+        if init_flow is None:
+            init_flow = flow_init
+        if not image1.is_cuda:
+            raise _lib.PfError("PriOr_RAFT (MI355X build) needs inputs on a cuda/ROCm device; "
+                               "there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only)")
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "training forward/backward through the HIP kernels is not implemented in this round "
+                "(SURVEY.md §8f rank 3); run inference under torch.no_grad() / model.eval()")
+        B, _, H, W = image1.shape
+        device = image1.device
+        with torch.no_grad(), torch.cuda.device(device):
+            ws = self._workspace(B, H, W, device)
+            n_out = 1 if test_mode else iters
+            out_a = [torch.empty(B, 2, H, W, dtype=torch.float32, device=device) for _ in range(n_out)]
+            out_b = [] if test_mode else [torch.empty(B, 2, H, W, dtype=torch.float32, device=device)
+                                           for _ in range(n_out)]
+            image1 = image1.float().contiguous()
+            image2 = image2.float().contiguous()
+            if self.use_graph and test_mode and init_flow is None and not self.training:
+                return self._run_graph(ws, image1, image2, iters)
+            self._run(ws, image1, image2, iters, init_flow, test_mode, out_a, out_b)
+        if test_mode:
+            return out_a[0]
+        return out_a, out_b
+
+    # ---- HIP-graph replay of the whole test_mode forward --------------------------------------
+    def _run_graph(self, ws: Workspace, image1, image2, iters):
+        self._weights()
+        key = (ws.B, ws.H, ws.W, iters, str(image1.device))
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_i1 = image1.clone()
+            static_i2 = image2.clone()
+            static_out = [torch.empty(ws.B, 2, ws.H, ws.W, dtype=torch.float32, device=image1.device)]
+            # warm-up on a side stream (MIOpen picks its kernels, lazy inits happen here)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self._run(ws, static_i1, static_i2, iters, None, True, static_out, [])
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._run(ws, static_i1, static_i2, iters, None, True, static_out, [])
+            entry = (graph, static_i1, static_i2, static_out)
+            self._graphs[key] = entry
+        graph, static_i1, static_i2, static_out = entry
+        static_i1.copy_(image1)
+        static_i2.copy_(image2)
+        graph.replay()
+        return static_out[0].clone()

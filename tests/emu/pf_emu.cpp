@@ -1,0 +1,26 @@
+// Host emulation build of the per-element kernels -- TEST INFRASTRUCTURE ONLY.
+// Compiles prior-flow_amd/csrc/pf_elem.h + pf_api_elem.inc for the CPU so that the sampler /
+// geometry / lookup index logic can be checked against the oracle in the GPU-less build
+// container (tests/test_emu_kernels.py).  The product never loads this library; the MFMA
+// kernels (pf_conv2d, pf_corr_pyramid) have no emulation and are tested on the GPU only.
+#include "pf_elem.h"
+
+template <class Args, void (*F)(long, const Args&)>
+static int pf_loop(const Args& a, long total) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < total; ++i) F(i, a);
+    return PF_OK;
+}
+#define PF_LAUNCH(name, args, total, stream) pf_loop<decltype(args), pf_##name##_elem>(args, total)
+
+#include "pf_api_elem.inc"
+
+extern "C" int pf_warp_gcorr(const float* f1, const float* f2, const float* coords, int add_grid,
+                             float* dst, int dst_ld, int dst_off, int B, int H8, int W8, int C,
+                             void* stream) {
+    PfWarpGcorrArgs a;
+    const int rc = pf_warp_gcorr_fill(a, f1, f2, coords, add_grid, dst, dst_ld, dst_off, B, H8, W8, C);
+    if (rc != PF_OK) return rc;
+    return PF_LAUNCH(warp_gcorr, a, (long)B * H8 * W8 * 4, stream);
+}
+extern "C" const char* pf_version(void) { return "priorflow host emulation (tests only)"; }

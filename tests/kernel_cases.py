@@ -1,0 +1,252 @@
+"""Per-kernel parity cases: C-ABI library (through prior-flow_amd/_lib.py) vs the CPU oracle
+and the reference-generated golden vectors, on the same seeded inputs.
+
+The same cases run (a) on the GPU against libpriorflow_hip.so  -- tests/test_hip_kernels.py,
+the parity gate proper -- and (b) on the CPU against the host-emulation build of the
+per-element kernels -- tests/test_emu_kernels.py, which only checks index / wrap / padding
+logic in the GPU-less build container.
+"""
+import math
+
+import numpy as np
+import torch
+
+import golden_cases as gc
+import priorflow_oracle as po
+
+T = torch.from_numpy
+H8, W8 = gc.H8, gc.W8
+N = H8 * W8
+
+
+def maxerr(a, b):
+    return float((a.detach().cpu() - b.detach().cpu()).abs().max())
+
+
+def check(a, b, atol, what):
+    a = a.detach().cpu()
+    b = b.detach().cpu() if isinstance(b, torch.Tensor) else T(np.asarray(b))
+    assert a.shape == b.shape, (what, tuple(a.shape), tuple(b.shape))
+    assert torch.isfinite(a).all(), f"{what}: non-finite output"
+    err = float((a - b).abs().max())
+    assert err <= atol, f"{what}: max err {err:.3e} > {atol:.1e}"
+    return err
+
+
+def cl(x):
+    """NCHW -> channel-last rows [B*H*W, C]."""
+    B, C = x.shape[:2]
+    return x.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+
+
+def uncl(rows, B, H, W):
+    return rows.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def grids16(dev):
+    g = gc.load("grids")
+    return {k: T(g[k]).to(dev).contiguous() for k in g.files if k.endswith("16x32")}
+
+
+# ------------------------------------------------------------------------------------------
+def case_sample_grid(lib, dev):
+    g = gc.load("grids")
+    for tag, (h, w) in (("16x32", (16, 32)), ("64x128", (64, 128)), ("80x160", (80, 160))):
+        for name, theta in (("a2b", -math.pi / 2), ("b2a", math.pi / 2)):
+            R = po.rotation_x(theta)
+            out = torch.empty(2, h, w, device=dev)
+            lib.sample_grid(out, R)
+            # device libm vs torch-CPU libm: atan2 near the poles amplifies 1-ulp
+            # differences of sin/cos to ~1e-4 px (DESIGN.md "Sample grids")
+            check(out, g[f"{name}_{tag}"], 5e-4 * (w / 32) ** 0.5, f"grid {name} {tag}")
+            assert float((out.cpu() - T(g[f"{name}_{tag}"])).abs().mean()) < 2e-5
+    # identity rotation -> identity grid
+    out = torch.empty(2, 16, 32, device=dev)
+    lib.sample_grid(out, torch.eye(3))
+    check(out, po.coords_grid(1, 16, 32)[0], 3e-5, "identity grid")
+
+
+def case_img_rotate(lib, dev):
+    g = gc.load("grids")
+    im6 = gc.uni("img_rotate/img", (1, 6, 64, 128), -1, 1)
+    out = torch.empty_like(im6, device=dev)
+    lib.img_rotate(im6.to(dev), T(g["a2b_64x128"]).to(dev), out)
+    check(out, gc.load("img_rotate")["out"], 2e-6, "img_rotate vs reference")
+    # generic sampler semantics incl. seams: resample with "nasty" coordinates as the grid
+    img = gc.uni("sampler/img", (2, 3, H8, W8), -2, 2)
+    co = gc.nasty_coords("sampler", B=2)
+    ref = T(gc.load("sampler")["out"])
+    for b in range(2):
+        o = torch.empty(1, 3, H8, W8, device=dev)
+        lib.img_rotate(img[b:b + 1].to(dev).contiguous(), co[b].to(dev).contiguous(), o)
+        check(o, ref[b:b + 1], 2e-6, f"seam sampler b={b}")
+
+
+def case_flow_prep(lib, dev):
+    co = gc.nasty_coords("prep", B=2)
+    flow = torch.empty(2, 2, H8, W8, device=dev)
+    d0 = torch.zeros(2 * N, 6, device=dev)
+    d1 = torch.zeros(2 * N, 2, device=dev)
+    lib.flow_prep(co.to(dev), flow, d0, 3, d1, 0)
+    want = co - po.coords_grid(2, H8, W8)
+    check(flow, want, 0.0, "flow planar")
+    check(d0[:, 3:5], cl(want), 0.0, "flow dst0")
+    check(d1, cl(want), 0.0, "flow dst1")
+    assert float(d0[:, :3].abs().max()) == 0.0 and float(d0[:, 5].abs().max()) == 0.0
+
+
+def case_flo_rotate(lib, dev):
+    g = grids16(dev)
+    gold = gc.load("flo_rotate")
+    fl = gc.flows("flo_rotate", B=2)
+    for name, w2c, c2w in (("b2a", "b2aT_16x32", "b2a_16x32"), ("a2b", "a2bT_16x32", "a2b_16x32")):
+        out = torch.empty(2, 2, H8, W8, device=dev)
+        d0 = torch.zeros(2 * N, 4, device=dev)
+        lib.flo_rotate(fl.to(dev), g[w2c], g[c2w], out, d0, 2)
+        check(out, gold[name], 1e-5, f"flo_rotate {name} vs reference")
+        check(d0[:, 2:4], cl(out.cpu()), 0.0, "flo_rotate dst")
+    z = torch.zeros(1, 2, H8, W8, device=dev)
+    out = torch.empty_like(z)
+    lib.flo_rotate(z, g["b2aT_16x32"], g["b2a_16x32"], out)
+    assert float(out.abs().max()) == 0.0, "zero flow must rotate to exactly zero"
+
+
+def _pyr_rows(pyr):
+    return [p.reshape(p.shape[0], -1).contiguous() for p in pyr]
+
+
+def case_dccl(lib, dev):
+    g = grids16(dev)
+    gold = gc.load("dccl")
+    va, vb = gc.volumes("dccl")
+    pa, pb = _pyr_rows(po.build_pyramid(va)), _pyr_rows(po.build_pyramid(vb))
+    pa_d, pb_d = [p.to(dev) for p in pa], [p.to(dev) for p in pb]
+    co = gc.nasty_coords("dccl").to(dev)
+    LD = 324
+    own = torch.empty(N, LD, device=dev)
+    raw = torch.empty(N, LD, device=dev)
+    out = torch.empty(N, LD, device=dev)
+    lib.dccl_lookup(co, pa_d, pb_d, g["a2bT_16x32"], own, raw)
+    lib.dccl_combine(own, raw, g["b2a_16x32"], out, 1, H8, W8)
+    own_n = uncl(own.cpu(), 1, H8, W8)
+    corr_n = uncl(out.cpu(), 1, H8, W8)
+    check(own_n[:, :, :8], gold["own_a"], 2e-5, "own_a vs reference")
+    want = T(gold["own_a"]) + T(gold["cross_a"])
+    check(corr_n[:, :, :8], want, 1e-3, "corr_a vs reference")          # see test_oracle_golden
+    assert float((corr_n[:, :, :8] - want).abs().mean()) < 2e-5
+    # other direction (B looks into A)
+    lib.dccl_lookup(co, pb_d, pa_d, g["b2aT_16x32"], own, raw)
+    lib.dccl_combine(own, raw, g["a2b_16x32"], out, 1, H8, W8)
+    corr_n = uncl(out.cpu(), 1, H8, W8)
+    check(corr_n[:, :, :8], gold["corr_b"], 1e-3, "corr_b vs reference")
+    # and against the oracle on ALL pixels
+    o_own, o_cross = po.dccl_lookup(co.cpu(), po.build_pyramid(vb), po.build_pyramid(va),
+                                    g["b2aT_16x32"].cpu(), g["a2b_16x32"].cpu())
+    check(corr_n, o_own + o_cross, 1e-3, "corr_b vs oracle (all pixels)")
+    # padded row stride
+    own2 = torch.full((N, 336), 7.0, device=dev)
+    raw2 = torch.full((N, 336), 7.0, device=dev)
+    lib.dccl_lookup(co, pb_d, pa_d, g["b2aT_16x32"], own2, raw2)
+    check(own2[:, :324], own, 0.0, "ld=336 own")
+    assert float((own2[:, 324:] - 7.0).abs().max()) == 0.0, "padding columns must stay untouched"
+
+
+def case_warp_gcorr(lib, dev):
+    f1, f2 = gc.fmaps("gwc")
+    co = gc.nasty_coords("gwc")
+    dst = torch.zeros(N, 8, device=dev)
+    f1c, f2c = cl(f1).to(dev), cl(f2).to(dev)
+    lib.warp_gcorr(f1c, f2c, co.to(dev), False, dst, 0)
+    flow = (co - po.coords_grid(1, H8, W8)).contiguous()
+    lib.warp_gcorr(f1c, f2c, flow.to(dev), True, dst, 4)
+    want = T(gc.load("warp_gcorr")["flaw"])
+    check(uncl(dst[:, :4].cpu(), 1, H8, W8), want, 3e-6, "warp_gcorr vs reference")
+    # coords0 + (coords1 - coords0) differs from coords1 by an ulp of the coordinate
+    check(uncl(dst[:, 4:].cpu(), 1, H8, W8), want, 2e-4, "warp_gcorr add_grid")
+
+
+def case_upsample(lib, dev):
+    fl8 = gc.uni("up/flow", (1, 2, H8, W8), -6, 6)
+    mk = gc.uni("up/mask", (1, 576, H8, W8), -2, 2)
+    coords1 = (po.coords_grid(1, H8, W8) + fl8).contiguous()
+    out = torch.empty(1, 2, 8 * H8, 8 * W8, device=dev)
+    lib.upsample_flow(coords1.to(dev), cl(mk).to(dev), out)
+    # coords0 + flow - coords0 rounds at the coordinate's ulp (<= 32 * 2^-24 * 8)
+    check(out, gc.load("upsample")["out"], 3e-5, "upsample vs reference")
+
+
+def case_coords_add(lib, dev):
+    co = gc.nasty_coords("cadd", B=2)
+    delta = gc.uni("cadd/delta", (2 * N, 4), -1, 1)
+    c1 = co.clone().to(dev)
+    lib.coords_add(c1, delta.to(dev))
+    want = co + uncl(delta[:, :2], 2, H8, W8)
+    check(c1, want, 0.0, "coords_add")
+
+
+def case_direct_conv(lib, dev, params):
+    ui = gc.update_inputs("upd")
+    # 7x7 2->128 + relu  (ODDC.encoder.convf1_A)
+    w, b = params["ODDC.encoder.convf1_A.weight"], params["ODDC.encoder.convf1_A.bias"]
+    want = torch.relu(torch.nn.functional.conv2d(ui["flow_a"], w, b, padding=3))
+    wp = w.permute(2, 3, 1, 0).reshape(49, 2, 128).contiguous()
+    x = torch.zeros(N, 4, device=dev)
+    x[:, 1:3] = cl(ui["flow_a"]).to(dev)
+    out = torch.zeros(N, 130, device=dev)
+    lib.conv2d_direct(x, 1, 2, wp.to(dev), b.to(dev), out, 2, 128, 7, 7, True, 1, H8, W8)
+    check(uncl(out[:, 2:].cpu(), 1, H8, W8), want, 2e-5, "direct 7x7")
+    assert float(out[:, :2].abs().max()) == 0.0
+    # 3x3 8->32 relu -> 3x3 32->16 relu (confidence stem)
+    w1, b1 = params["ODDC.encoder.conv_conf1.weight"], params["ODDC.encoder.conv_conf1.bias"]
+    w2, b2 = params["ODDC.encoder.conv_conf2.weight"], params["ODDC.encoder.conv_conf2.bias"]
+    xin = torch.cat([ui["flaw_a"], ui["flaw_ba"]], 1)
+    want = torch.relu(torch.nn.functional.conv2d(
+        torch.relu(torch.nn.functional.conv2d(xin, w1, b1, padding=1)), w2, b2, padding=1))
+    mid = torch.empty(N, 32, device=dev)
+    out = torch.empty(N, 16, device=dev)
+    lib.conv2d_direct(cl(xin).to(dev), 0, 8, w1.permute(2, 3, 1, 0).reshape(9, 8, 32).contiguous().to(dev),
+                      b1.to(dev), mid, 0, 32, 3, 3, True, 1, H8, W8)
+    lib.conv2d_direct(mid, 0, 32, w2.permute(2, 3, 1, 0).reshape(9, 32, 16).contiguous().to(dev),
+                      b2.to(dev), out, 0, 16, 3, 3, True, 1, H8, W8)
+    check(uncl(out.cpu(), 1, H8, W8), want, 2e-5, "conf stem")
+
+
+def case_layout(lib, dev):
+    x = gc.uni("layout/x", (2, 12, H8, W8), -3, 3)
+    out = torch.zeros(2 * N, 10, device=dev)
+    lib.to_channel_last(x.to(dev), 4, 6, out, 3, 2)      # tanh of channels 4..9 -> cols 3..8
+    check(out[:, 3:9], cl(torch.tanh(x[:, 4:10])), 2e-6, "to_channel_last tanh")
+    lib.to_channel_last(x.to(dev), 0, 3, out, 0, 1)
+    check(out[:, :3], cl(torch.relu(x[:, :3])), 0.0, "to_channel_last relu")
+    assert float(out[:, 9].abs().max()) == 0.0
+    back = torch.empty(2, 6, H8, W8, device=dev)
+    lib.to_nchw(out, 3, 6, back)
+    check(back, torch.tanh(x[:, 4:10]), 2e-6, "to_nchw")
+
+
+def case_bad_args(lib, dev):
+    """Error behaviour: negative PF_ERR codes surface as PfError, nothing is written."""
+    from prior_flow_amd._lib import PfError
+    co = gc.nasty_coords("prep").to(dev)
+    bad = torch.zeros(N, 1, device=dev)
+    try:
+        lib.flow_prep(co, None, bad, 0)       # 2 channels do not fit in ld=1
+    except PfError:
+        pass
+    else:
+        raise AssertionError("expected PfError for a destination slice that does not fit")
+    tiny = torch.zeros(1, 2, 8, 8, device=dev)   # level 3 would be 1x1 -> division by zero
+    lv = [torch.zeros(64, (8 >> i) * (8 >> i), device=dev) for i in range(4)]
+    g = torch.zeros(2, 8, 8, device=dev)
+    o = torch.zeros(64, 324, device=dev)
+    r = torch.zeros(64, 324, device=dev)
+    try:
+        lib.dccl_lookup(tiny, lv, lv, g, o, r)
+    except PfError:
+        pass
+    else:
+        raise AssertionError("expected PfError for an image below the smallest legal size")
+
+
+ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
+                     case_warp_gcorr, case_upsample, case_coords_add, case_layout, case_bad_args]

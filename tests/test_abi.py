@@ -1,0 +1,108 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/priorflow_hip.h declares (no compute call without a GPU); the Python module has
+the reference's constructor / state_dict contract; the product path fails loudly off-GPU."""
+import argparse
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import __graft_entry__ as ge
+    return ge.build_hip()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "priorflow_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(built_lib):
+    syms = _declared_symbols()
+    assert len(syms) >= 15, syms
+    dll = ctypes.CDLL(built_lib)
+    missing = [s for s in syms if not hasattr(dll, s)]
+    assert not missing, missing
+    dll.pf_version.restype = ctypes.c_char_p
+    assert b"gfx950" in dll.pf_version()
+
+
+def test_binding_covers_header(built_lib):
+    from prior_flow_amd import _lib
+    assert sorted(_lib.EXPORTS) == _declared_symbols()
+    lib = _lib.PfLib(built_lib, require_cuda=True)
+    assert not lib.missing
+    # the ctypes mirror of pf_conv_desc must have the C compiler's layout
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc"):
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "sz.c")
+            open(src, "w").write(
+                '#include <stdio.h>\n#include <stddef.h>\n#include "priorflow_hip.h"\n'
+                'int main(){printf("%zu %zu %zu %zu %zu", sizeof(pf_conv_desc), offsetof(pf_conv_desc, weight),'
+                ' offsetof(pf_conv_desc, out), offsetof(pf_conv_desc, h), offsetof(pf_conv_desc, aux_out));return 0;}')
+            subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(td, "sz")])
+            got = [int(v) for v in subprocess.check_output([os.path.join(td, "sz")]).split()]
+        D = _lib.ConvDesc
+        assert got == [ctypes.sizeof(D), D.weight.offset, D.out.offset, D.h.offset, D.aux_out.offset]
+
+
+def test_null_and_shape_errors_are_reported_without_a_gpu(built_lib):
+    """Argument validation happens before any launch, so it can be exercised here."""
+    dll = ctypes.CDLL(built_lib)
+    assert dll.pf_sample_grid(None, 16, 32, None, None) == -1           # PF_ERR_BAD_ARG
+    assert dll.pf_conv2d(None, 1, 1, 16, 32, None) == -1
+    assert dll.pf_corr_pyramid(None, None, None, None, None, None, 1, 16, 32, 256, None) == -1
+
+
+def test_state_dict_contract():
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    args = argparse.Namespace(mixed_precision=False, dropout=0.0)
+    m = PriOr_RAFT(args)
+    assert args.corr_levels == 4 and args.corr_radius == 4       # core/prior_raft.py:34-35
+    sd = m.state_dict()
+    assert len(sd) == 217
+    assert sum(v.numel() for v in sd.values() if v.dtype.is_floating_point) == 8341422
+    assert {k.split(".")[0] for k in sd} == {"fnet", "cnet", "ODDC", "update_block"}
+    assert tuple(sd["ODDC.gru.convz1.weight"].shape) == (128, 384, 1, 5)
+    assert tuple(sd["update_block.mask.2.weight"].shape) == (576, 256, 1, 1)
+    # DataParallel-style checkpoints ("module." prefix) load through nn.DataParallel as in
+    # evaluate.py:410-411
+    wrapped = torch.nn.DataParallel(m)
+    wrapped.load_state_dict({"module." + k: v for k, v in sd.items()}, strict=True)
+    m.freeze_bn()
+    assert all(not mod.training for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d))
+
+
+def test_cpu_inputs_fail_loudly():
+    from prior_flow_amd._lib import PfError
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0)).eval()
+    x = torch.zeros(1, 3, 128, 256)
+    with pytest.raises(PfError):
+        m(x, x, iters=1, test_mode=True)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from prior_flow_amd._lib import PfError, PfLib
+    with pytest.raises(PfError):
+        PfLib(str(tmp_path / "nope.so"))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under prior-flow_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "prior-flow_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "priorflow_oracle" not in text and "import oracle" not in text, f

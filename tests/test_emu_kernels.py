@@ -1,0 +1,47 @@
+"""CPU logic check of the per-element kernels: the SAME csrc/pf_elem.h device functions,
+compiled for the host (tests/emu/pf_emu.cpp), run through the SAME ctypes wrappers and the
+SAME parity cases as the GPU tests.  This validates index / wrap / zero-padding logic in the
+GPU-less build container; it is not a product path and proves nothing about the HIP build
+(tests/test_hip_kernels.py does, on the GPU)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+import torch
+
+import golden_cases as gc
+import kernel_cases as kc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_SO = os.path.join(EMU_DIR, "libpf_emu.so")
+CSRC = os.path.join(ROOT, "prior-flow_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    srcs = [os.path.join(EMU_DIR, "pf_emu.cpp"), os.path.join(CSRC, "pf_elem.h"),
+            os.path.join(CSRC, "pf_api_elem.inc"), os.path.join(CSRC, "pf_common.h")]
+    if not os.path.exists(EMU_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
+                               "-I", CSRC, srcs[0], "-o", EMU_SO])
+    from prior_flow_amd._lib import PfLib
+    return PfLib(EMU_SO, require_cuda=False, optional=("pf_conv2d", "pf_conv2d_tile", "pf_corr_pyramid"))
+
+
+@pytest.fixture(scope="module")
+def params():
+    from prior_flow_amd.modules import state_dict_shapes
+    return gc.det_state_dict(state_dict_shapes())
+
+
+@pytest.mark.parametrize("case", kc.ELEMENTWISE_CASES, ids=lambda c: c.__name__)
+def test_emu_case(emu, case):
+    case(emu, torch.device("cpu"))
+
+
+def test_emu_direct_conv(emu, params):
+    kc.case_direct_conv(emu, torch.device("cpu"), params)

@@ -1,0 +1,211 @@
+"""GPU parity tests proper: every C-ABI entry point of libpriorflow_hip.so against the CPU
+oracle and the reference-generated golden vectors.  Run with ``-m gpu`` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import kernel_cases as kc
+import priorflow_oracle as po
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+H8, W8, N = gc.H8, gc.W8, gc.H8 * gc.W8
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from prior_flow_amd import _lib
+    return _lib.load()          # raises if the HIP library was not built: no fallback
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def params():
+    from prior_flow_amd.modules import state_dict_shapes
+    return gc.det_state_dict(state_dict_shapes())
+
+
+def test_native_library_is_loaded(lib):
+    assert "gfx950" in lib.version()
+    loaded = open("/proc/self/maps").read()
+    assert "libpriorflow_hip.so" in loaded
+
+
+@pytest.mark.parametrize("case", kc.ELEMENTWISE_CASES, ids=lambda c: c.__name__)
+def test_elementwise_case(lib, dev, case):
+    case(lib, dev)
+    torch.cuda.synchronize()
+
+
+def test_direct_conv(lib, dev, params):
+    kc.case_direct_conv(lib, dev, params)
+
+
+# ---- MFMA implicit-GEMM convolution --------------------------------------------------------
+def _conv_ref(x, w, b, pad):
+    return torch.nn.functional.conv2d(x, w, b, padding=pad)
+
+
+def _run_conv(lib, dev, x_nchw, w, b, epilogue, scale=1.0, off_out=0, extra_cols=0, B=None):
+    from prior_flow_amd.engine import Conv, pack_mfma
+    Bn, cin, h, wd = x_nchw.shape
+    cout = w.shape[0]
+    wp, bp = pack_mfma(w.to(dev), b.to(dev))
+    cv = Conv(wp, bp, w.shape[2], w.shape[3], cin, cout)
+    xin = kc.cl(x_nchw).to(dev)
+    out = torch.full((Bn * h * wd, cout + off_out + extra_cols), -777.0, device=dev)
+    d = cv.desc(xin, 0, cin, out, off_out, epilogue, scale=scale)
+    lib.conv2d([d], Bn, h, wd, out)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32), (2, 16, 32), (1, 24, 40), (1, 8, 8)],
+                         ids=lambda s: "B%dx%dx%d" % s)
+@pytest.mark.parametrize("conv", [
+    ("1x1_324_256", 324, 256, 1, 1), ("3x3_272_124", 272, 124, 3, 3), ("3x3_128_64", 128, 64, 3, 3),
+    ("3x3_256_2", 256, 2, 3, 3), ("1x5_384_128", 384, 128, 1, 5), ("5x1_384_256", 384, 256, 5, 1),
+    ("1x1_256_576", 256, 576, 1, 1), ("3x3_256_192", 256, 192, 3, 3)], ids=lambda c: c[0])
+def test_conv_mfma_vs_cpu_conv2d(lib, dev, shape, conv):
+    from prior_flow_amd._lib import EPI_LINEAR, EPI_RELU
+    B, h, w_ = shape
+    name, cin, cout, kh, kw = conv
+    x = gc.uni(f"conv/{name}/x{B}{h}{w_}", (B, cin, h, w_), -1, 1)
+    bound = (3.0 / (cin * kh * kw)) ** 0.5
+    w = gc.uni(f"conv/{name}/w", (cout, cin, kh, kw), -bound, bound)
+    b = gc.uni(f"conv/{name}/b", (cout,), -0.1, 0.1)
+    want = _conv_ref(x, w, b, (kh // 2, kw // 2))
+    out = _run_conv(lib, dev, x, w, b, EPI_RELU, off_out=4, extra_cols=3)
+    got = kc.uncl(out[:, 4:4 + cout].cpu(), B, h, w_)
+    kc.check(got, torch.relu(want), 2e-5, f"{name} relu")
+    assert float((out[:, :4] + 777.0).abs().max()) == 0.0, "columns left of the slice were touched"
+    assert float((out[:, 4 + cout:] + 777.0).abs().max()) == 0.0, "columns right of the slice were touched"
+    out = _run_conv(lib, dev, x, w, b, EPI_LINEAR, scale=0.25)
+    kc.check(kc.uncl(out.cpu(), B, h, w_), 0.25 * want, 2e-5, f"{name} linear*0.25")
+
+
+def test_conv_mfma_identity_asymmetric(lib, dev):
+    """A = delta kernel with an ASYMMETRIC weight map: catches row/col swaps in the MFMA
+    operand / accumulator layout (cdna_hip_programming.md §3)."""
+    from prior_flow_amd._lib import EPI_LINEAR
+    cin, cout = 64, 96
+    x = gc.uni("conv/id/x", (1, cin, 16, 32), -1, 1)
+    w = torch.zeros(cout, cin, 3, 3)
+    for o in range(cout):
+        w[o, (o * 7 + 3) % cin, 1, 1] = 1.0 + o      # out[o] = (1+o) * x[(7o+3) % 64]
+    b = torch.arange(cout, dtype=torch.float32) * 0.5
+    out = _run_conv(lib, dev, x, w, b, EPI_LINEAR)
+    want = torch.stack([(1.0 + o) * x[0, (o * 7 + 3) % cin] + 0.5 * o for o in range(cout)])[None]
+    kc.check(kc.uncl(out.cpu(), 1, 16, 32), want, 1e-5, "identity/asymmetric")
+
+
+def test_conv_mfma_groups_and_gru(lib, dev, params):
+    """Grouped launch (branch A | branch B) with two input segments and the fused SepConvGRU
+    epilogues, against the oracle's GRU (core/update.py:46-60) and the reference golden."""
+    from prior_flow_amd._lib import EPI_GRU_Q, EPI_GRU_ZR
+    from prior_flow_amd.engine import Conv
+    import argparse
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    model.load_state_dict(params)
+    model = model.to(dev)
+    ui = gc.update_inputs("upd")
+    mf = T(gc.load("update_A")["motion"])
+    x = torch.cat([ui["inp"], mf], 1)
+    h0 = ui["net"]
+    net = [kc.cl(h0).to(dev), torch.empty(N, 128, device=dev)]
+    net_b = [kc.cl(h0).to(dev), torch.empty(N, 128, device=dev)]
+    xr = kc.cl(x).to(dev)
+    z = [torch.empty(N, 128, device=dev) for _ in range(2)]
+    rh = [torch.empty(N, 128, device=dev) for _ in range(2)]
+    c = 0
+    for tag in ("1", "2"):
+        descs = []
+        for gi, (blk, nn_) in enumerate(((model.ODDC, net), (model.update_block, net_b))):
+            cv = Conv.fused(getattr(blk.gru, "convz" + tag), getattr(blk.gru, "convr" + tag))
+            descs.append(cv.desc(nn_[c], 0, 128, z[gi], 0, EPI_GRU_ZR, in1=xr, off1=0, c1=256, h=nn_[c], aux=rh[gi]))
+        lib.conv2d(descs, 1, H8, W8, xr)
+        descs = []
+        for gi, (blk, nn_) in enumerate(((model.ODDC, net), (model.update_block, net_b))):
+            cv = Conv.of(getattr(blk.gru, "convq" + tag))
+            descs.append(cv.desc(rh[gi], 0, 128, nn_[c ^ 1], 0, EPI_GRU_Q, in1=xr, off1=0, c1=256, h=nn_[c], z=z[gi]))
+        lib.conv2d(descs, 1, H8, W8, xr)
+        c ^= 1
+    torch.cuda.synchronize()
+    kc.check(kc.uncl(net[c].cpu(), 1, H8, W8), gc.load("gru")["out"], 3e-5, "ODDC.gru vs reference")
+    want_b = po.sepconv_gru(params, "update_block.gru.", h0, x)
+    kc.check(kc.uncl(net_b[c].cpu(), 1, H8, W8), want_b, 3e-5, "update_block.gru vs oracle")
+
+
+# ---- corr volume + pyramid -------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 16, 64), (1, 24, 40), (1, 16, 24)],
+                         ids=lambda s: "B%dx%dx%d" % s)
+def test_corr_pyramid(lib, dev, shape):
+    B, h, w = shape
+    f1 = gc.uni(f"corrk/f1/{h}x{w}", (B, 256, h, w), -1.7, 1.7)
+    f2 = gc.uni(f"corrk/f2/{h}x{w}", (B, 256, h, w), -1.7, 1.7)
+    n = h * w
+    lv = [torch.full((B * n, (h >> i) * (w >> i)), float("nan"), device=dev) for i in range(4)]
+    lib.corr_pyramid(kc.cl(f1).to(dev), kc.cl(f2).to(dev), lv, B, h, w)
+    torch.cuda.synchronize()
+    pyr = po.build_pyramid(po.corr_volume(f1, f2))
+    for i in range(4):
+        kc.check(lv[i].cpu(), pyr[i].reshape(B * n, -1), 3e-5, f"level {i}")
+
+
+def test_corr_pyramid_vs_reference_golden(lib, dev):
+    g = gc.load("corr_pyramid")
+    f1, f2 = gc.fmaps("corr", B=2)
+    lv = [torch.empty(2 * N, (H8 >> i) * (W8 >> i), device=dev) for i in range(4)]
+    lib.corr_pyramid(kc.cl(f1).to(dev), kc.cl(f2).to(dev), lv, 2, H8, W8)
+    torch.cuda.synchronize()
+    rows = g["rows"]
+    for i in range(4):
+        kc.check(lv[i].cpu()[rows], T(g[f"l{i}"]).reshape(len(rows), -1), 3e-5, f"level {i} vs reference")
+        assert float(lv[i].double().sum()) == pytest.approx(float(g["checksum"][i]), abs=2e-2 * (1 + i))
+    # known answers: diagonal of corr(f,f) = |f|^2 / 16
+    lib.corr_pyramid(kc.cl(f1).to(dev), kc.cl(f1).to(dev), lv, 2, H8, W8)
+    diag = torch.diagonal(lv[0][:N].cpu())
+    kc.check(diag, (f1[0].reshape(256, -1) ** 2).sum(0) / 16.0, 1e-4, "diag")
+
+
+# ---- update blocks through the engine -----------------------------------------------------------
+def test_update_blocks_vs_reference_golden(lib, dev, params):
+    import argparse
+    from prior_flow_amd.engine import Engine, Workspace, pack_update_blocks
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    model.load_state_dict(params)
+    model = model.to(dev)
+    P = pack_update_blocks(model.ODDC, model.update_block)
+    ws = Workspace(lib, 1, 128, 256, dev)
+    eng = Engine(lib)
+    ui = gc.update_inputs("upd")
+    up = lambda t: kc.cl(t).to(dev)
+    ws.net_a[0].copy_(up(ui["net"])); ws.net_b[0].copy_(up(ui["net"]))
+    ws.x_a[:, :128] = up(ui["inp"]); ws.x_b[:, :128] = up(ui["inp"])
+    ws.x_a[:, 252:254] = up(ui["flow_a"]); ws.x_a[:, 254:256] = up(ui["flow_ba"])
+    ws.x_b[:, 254:256] = up(ui["flow_a"])
+    ws.flow4_a[:, 0:2] = up(ui["flow_a"]); ws.flow4_a[:, 2:4] = up(ui["flow_ba"])
+    ws.flow2_b.copy_(up(ui["flow_a"]))
+    ws.corr_a.copy_(up(ui["corr"])); ws.corr_b.copy_(up(ui["corr"]))
+    ws.conf_in[:, :4] = up(ui["flaw_a"]); ws.conf_in[:, 4:] = up(ui["flaw_ba"])
+    cur = eng.update_blocks(ws, P, 0, need_b=True, mask_a=True, mask_b=True)
+    torch.cuda.synchronize()
+    ga, gb = gc.load("update_A"), gc.load("update_B")
+    back = lambda rows: kc.uncl(rows.cpu(), 1, H8, W8)
+    kc.check(back(ws.x_a[:, 128:]), ga["motion"], 3e-5, "motion features A")
+    kc.check(back(ws.x_b[:, 128:]), gb["motion"], 3e-5, "motion features B")
+    kc.check(back(ws.net_a[cur]), ga["net"], 3e-5, "net A")
+    kc.check(back(ws.net_b[cur]), gb["net"], 3e-5, "net B")
+    kc.check(back(ws.delta_a[:, :2]), ga["delta"], 3e-5, "delta A")
+    kc.check(back(ws.delta_b[:, :2]), gb["delta"], 3e-5, "delta B")
+    kc.check(back(ws.mask_a)[:, 3::8], ga["mask"], 3e-5, "mask A")
+    kc.check(back(ws.mask_b)[:, 3::8], gb["mask"], 3e-5, "mask B")
