@@ -40,6 +40,30 @@ TILE_NAMES = {0: "pf_conv_mfma_kernel<4,1,1> (128x32)", 1: "pf_conv_mfma_kernel<
               2: "pf_conv_mfma_kernel<2,2,2> (64x128)"}
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cpus() -> int:
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the host's cores even inside a quota-limited container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,10 +155,13 @@ def profile_kernels(model, i1, i2):
 
 def cpu_baseline(params, i1, i2, flow_gpu):
     import priorflow_oracle as po
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline: os.cpu_count()={os.cpu_count()} usable={cores} torch threads={torch.get_num_threads()}")
     t0 = time.time()
     ref = po.forward(params, i1, i2, iters=ITERS, test_mode=True)        # warm-up + parity
     first = time.time() - t0
+    log(f"cpu baseline: first oracle forward {first:.1f}s")
     times = []
     budget = 25.0 - first
     while len(times) < 2 and (not times or budget > times[-1]):
@@ -144,9 +171,9 @@ def cpu_baseline(params, i1, i2, flow_gpu):
         budget -= times[-1]
     best = min(times) if times else first
     epe = po.epe(flow_gpu.cpu(), ref)
-    cb = {"value": round(i1.shape[0] / best, 4), "unit": "frame-pairs/s", "cores": os.cpu_count(),
+    cb = {"value": round(i1.shape[0] / best, 4), "unit": "frame-pairs/s", "cores": cores,
           "kind": "port", "sample": f"{1 + len(times)} forwards of the same {i1.shape[0]}x{H}x{W} pair, "
-                                      f"iters={ITERS}, torch CPU threads={os.cpu_count()}, best of the timed ones",
+                                      f"iters={ITERS}, torch CPU threads={cores}, best of the timed ones",
           "seconds_per_pair": round(best / i1.shape[0], 3)}
     parity = {"epe_mean": float(epe.mean()), "epe_max": float(epe.max()), "bar": 1e-3,
               "flow_mean_abs": float(ref.abs().mean())}
@@ -168,6 +195,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}; building model")
     model, params = build_model(device)
     if args.no_graph:
         model.use_graph = False
@@ -184,14 +212,17 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
+        for w in range(max(args.warmup, 1)):
             flow = model(i1, i2, iters=ITERS, test_mode=True)
+            torch.cuda.synchronize()
+            log(f"warm-up {w} done")
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             flow = model(i1, i2, iters=ITERS, test_mode=True)
         barrier()
         elapsed = time.perf_counter() - t0
+    log(f"timed {args.steps} steps in {elapsed:.3f}s")
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,6 +247,7 @@ def main():
                        "encoders": "PyTorch-ROCm convs (SURVEY.md 8f rank 1); loop = libpriorflow_hip.so"},
         }
         try:
+            log("per-kernel HIP-event pass")
             result["roofline"], result["roofline_corr"] = profile_kernels(model, i1, i2)
         except Exception as exc:  # measured extras must not hide the headline number
             result["roofline"] = {"error": repr(exc)}
