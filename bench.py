@@ -35,6 +35,7 @@ import torch  # noqa: E402
 
 H, W, ITERS = 512, 1024, 12
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 TILE_NAMES = {0: "pf_conv_mfma_kernel<4,1,1> (128x32)", 1: "pf_conv_mfma_kernel<2,2,1> (64x64)",
               2: "pf_conv_mfma_kernel<2,2,2> (64x128)"}
@@ -72,6 +73,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step (configs[1] = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
+                    help="update-block conv arithmetic (default: PRIORFLOW_PRECISION or bf16x3)")
     return ap.parse_args()
 
 
@@ -137,8 +140,15 @@ def profile_kernels(model, i1, i2):
     all_fl = sum(v[0] for v in by_tile.values())
     all_ms = sum(v[1] for v in by_tile.values())
     achieved = fl / (ms * 1e-3) / 1e12
-    roofline = {"kernel": TILE_NAMES[dom], "bound": "mfma", "achieved": round(achieved, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+    from prior_flow_amd._lib import PREC_BF16X3
+    split = model._weights()["precision"] == PREC_BF16X3
+    peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    roofline = {"kernel": TILE_NAMES[dom] + (" bf16x3" if split else " fp32"), "bound": "mfma",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4),
+                # the 3-pass split issues 3 bf16 MFMA FLOPs per algorithmic FLOP: pipe utilisation
+                "mfma_issue_tflops": round(achieved * (3 if split else 1), 2),
+                "mfma_pipe_util": round(achieved * (3 if split else 1) / peak, 4),
                 "traffic": None, "launches_per_forward": n, "avg_launch_us": round(ms / n * 1e3, 1),
                 "gflop_per_forward": round(fl / 1e9, 1),
                 "all_conv_kernels": {"gflop": round(all_fl / 1e9, 1), "ms": round(all_ms, 3),
@@ -197,6 +207,9 @@ def main():
 
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}; building model")
     model, params = build_model(device)
+    if args.precision is not None:
+        from prior_flow_amd._lib import PREC_BF16X3, PREC_F32
+        model.precision = PREC_F32 if args.precision == "fp32" else PREC_BF16X3
     if args.no_graph:
         model.use_graph = False
     from prior_flow_amd import synthetic_pair
@@ -237,7 +250,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("bf16x3 split MFMA, f32 accumulate/storage" if model._weights()["precision"] == 1 else "f32"),
+            "data": "synthetic",
             "config": {"workload": f"PriOr-RAFT forward, {args.batch} synthetic 512x1024 ERP pair(s) per GPU per step, "
                                    "iters=12, test_mode (BASELINE.json configs[1])",
                        "pairs_per_gpu_per_step": args.batch, "height": H, "width": W, "iters": ITERS,

@@ -92,6 +92,11 @@ int pf_warp_gcorr(const float* f1, const float* f2, const float* coords, int add
 #define PF_EPI_GRU_ZR 2   /* cout [0,128): out = sigmoid(.) -> z; [128,256): aux_out = sigmoid(.)*h */
 #define PF_EPI_GRU_Q 3    /* q = tanh(.); out = (1-z)*h + z*q                              */
 
+/* Arithmetic of pf_conv2d (pf_conv_desc.precision); the weight buffer format follows it. */
+#define PF_PREC_F32 0     /* exact fp32 MFMA; weights fp32 [Cout_pad][KH*KW][Cin_pad]                 */
+#define PF_PREC_BF16X3 1  /* 3-pass bf16 split (hi*hi + hi*lo + lo*hi), fp32 accumulate; weights     *
+                           * pre-split: [Cout_pad][KH*KW][Cin_pad/32] x {bf16 hi[32], bf16 lo[32]}  */
+
 /* One stride-1 "same" convolution on channel-last activations as an implicit GEMM on the
  * matrix cores (nn.Conv2d forwards of core/update.py:6-14, 35-60, 81-99, 117-136, 139-201).
  * The input is the virtual concatenation of two channel-last segments (in1 may be NULL);
@@ -108,6 +113,7 @@ typedef struct pf_conv_desc {
     const float* h; int ld_h;        /* GRU_ZR / GRU_Q: hidden state [B*N][ld_h]            */
     const float* z; int ld_z;        /* GRU_Q: update gate                                  */
     float* aux_out; int ld_aux;      /* GRU_ZR: r*h                                         */
+    int precision;                   /* PF_PREC_*; identical in every group of a launch     */
 } pf_conv_desc;
 
 /* Launch `ngroups` (1..4) same-geometry convolutions in ONE kernel (grid.z = group):

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpriorflow_hip.so")
 
 EPI_LINEAR, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2, 3
+PREC_F32, PREC_BF16X3 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
 _fp = C.c_void_p
@@ -34,6 +35,7 @@ class ConvDesc(C.Structure):
         ("h", _fp), ("ld_h", _i),
         ("z", _fp), ("ld_z", _i),
         ("aux_out", _fp), ("ld_aux", _i),
+        ("precision", _i),
     ]
 
 

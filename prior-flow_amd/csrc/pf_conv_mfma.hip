@@ -15,8 +15,19 @@
 // Row stride 36 floats (144 B) makes those reads and the 16-byte staging writes bank-conflict
 // free (9*row mod 16 is a bijection over any 16 distinct rows).
 //
+// Precision modes (pf_conv_desc.precision):
+//   PF_PREC_F32    exact fp32: v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains (1/16 of the bf16 rate)
+//   PF_PREC_BF16X3 3-pass bf16 split: x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
+//                  a*b ~= hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+//                  (16 mantissa bits per operand; the dropped lo*lo term is 2^-16 relative).
+//                  3/16 of the exact-fp32 MFMA time.  Same tiling and LDS footprint: a 32-channel
+//                  LDS row is [hi bf16 x32 | lo bf16 x32] (128 B + 16 B pad).  Weights are split
+//                  offline into that row format (the B path stays a pure 16-byte copy);
+//                  activations stay fp32 in HBM and are split when staged into LDS.
+//
 // Software pipeline: global loads of K-step s+1 are issued before the MFMAs of step s and
 // written to the other LDS buffer at the top of the next iteration; one __syncthreads per K-step.
+#include <stdlib.h>
 #include "pf_common.h"
 #include "../../include/priorflow_hip.h"
 
@@ -24,6 +35,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain 16-byte loads, no struct memcpy
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KC = 32;        // channels per K-step
 constexpr int LDS_LD = 36;    // padded row stride (floats)
@@ -33,7 +46,28 @@ struct ConvGroups { pf_conv_desc d[MAX_GROUPS]; };
 
 struct ConvGeom { int M, H, W, N; int taps, nchunks, cin_pad, kh, kw; };
 
-template <int WM, int WN, int NT>
+// Fused epilogue of one output element (pixel row p, output channel j), v = acc + bias.
+__device__ __forceinline__ void conv_epilogue(const pf_conv_desc& d, long p, int j, float v) {
+    if (d.epilogue == PF_EPI_LINEAR) {
+        d.out[p * d.ld_out + d.off_out + j] = v * d.scale;
+    } else if (d.epilogue == PF_EPI_RELU) {
+        d.out[p * d.ld_out + d.off_out + j] = fmaxf(v, 0.f);
+    } else if (d.epilogue == PF_EPI_GRU_ZR) {
+        const float s = 1.f / (1.f + expf(-v));
+        if (j < 128) {
+            d.out[p * d.ld_out + d.off_out + j] = s;                                  // z
+        } else {
+            d.aux_out[p * d.ld_aux + (j - 128)] = s * d.h[p * d.ld_h + (j - 128)];    // r*h
+        }
+    } else {   // PF_EPI_GRU_Q
+        const float q = tanhf(v);
+        const float z = d.z[p * d.ld_z + j];
+        const float hh = d.h[p * d.ld_h + j];
+        d.out[p * d.ld_out + d.off_out + j] = (1.f - z) * hh + z * q;
+    }
+}
+
+template <int WM, int WN, int NT, bool SPLIT>
 __global__ void __launch_bounds__(256, 2)   // 2 waves/SIMD -> 256-register budget, no spills
 pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
     constexpr int BM = 32 * WM;
@@ -119,8 +153,18 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
 #pragma unroll
         for (int q = 0; q < A_V4; ++q) {
             const int r = (tid + 256 * q) >> 3;
-            *reinterpret_cast<f32x4*>(as + r * LDS_LD + c4) =
-                ((a_ok >> q) & 1u) ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = ((a_ok >> q) & 1u) ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) {
+                // hi = bf16(v) (RNE, v_cvt_pk_bf16_f32); lo = bf16(v - hi): the subtraction is exact
+                const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+                const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
+                const bf16x4 lo = __builtin_convertvector(rest, bf16x4);
+                char* row = reinterpret_cast<char*>(as + r * LDS_LD);
+                *reinterpret_cast<bf16x4*>(row + 2 * c4) = hi;
+                *reinterpret_cast<bf16x4*>(row + 64 + 2 * c4) = lo;
+            } else {
+                *reinterpret_cast<f32x4*>(as + r * LDS_LD + c4) = v;
+            }
         }
 #pragma unroll
         for (int q = 0; q < B_V4; ++q) {
@@ -155,21 +199,50 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
 
         const float* as = As + buf * BM * LDS_LD + a_off;
         const float* bs = Bs + buf * BN * LDS_LD + b_off;
-        f32x4 af[4];
+        if constexpr (SPLIT) {
+            // lane (row li, half lh) owns channels [16lh, 16lh+16): bytes [32lh, 32lh+32) of the hi
+            // part and the same of the lo part (+64 B); K-step ks uses the ks-th 16 bytes of each
+            const char* ap = reinterpret_cast<const char*>(as);     // a_off already holds 16*lh floats = 64lh B
+            ap -= 32 * lh;                                          // -> 32lh bytes into the row
+            bf16x8 ah[2], al[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(as + 4 * q);
+            for (int ks = 0; ks < 2; ++ks) {
+                ah[ks] = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
+                al[ks] = *reinterpret_cast<const bf16x8*>(ap + 64 + 16 * ks);
+            }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x4 bf[4];
+            for (int t = 0; t < NT; ++t) {
+                const char* bp = reinterpret_cast<const char*>(bs + t * 32 * LDS_LD) - 32 * lh;
+                bf16x8 bh[2], bl[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                bf[q] = *reinterpret_cast<const f32x4*>(bs + t * 32 * LDS_LD + 4 * q);
+                for (int ks = 0; ks < 2; ++ks) {
+                    bh[ks] = *reinterpret_cast<const bf16x8*>(bp + 16 * ks);
+                    bl[ks] = *reinterpret_cast<const bf16x8*>(bp + 64 + 16 * ks);
+                }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[q].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf[q].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf[q].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf[q].w, acc[t], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[ks], acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+            f32x4 af[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(as + 4 * q);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 bf[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bf[q] = *reinterpret_cast<const f32x4*>(bs + t * 32 * LDS_LD + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[q].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf[q].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf[q].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf[q].w, acc[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -183,41 +256,234 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long p = (long)m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (!jok || p >= g.M) continue;
-            float v = acc[t][r] + bias;
-            if (d.epilogue == PF_EPI_LINEAR) {
-                d.out[p * d.ld_out + d.off_out + j] = v * d.scale;
-            } else if (d.epilogue == PF_EPI_RELU) {
-                d.out[p * d.ld_out + d.off_out + j] = fmaxf(v, 0.f);
-            } else if (d.epilogue == PF_EPI_GRU_ZR) {
-                const float s = 1.f / (1.f + expf(-v));
-                if (j < 128) {
-                    d.out[p * d.ld_out + d.off_out + j] = s;                 // z
-                } else {
-                    d.aux_out[p * d.ld_aux + (j - 128)] = s * d.h[p * d.ld_h + (j - 128)];  // r*h
-                }
-            } else {   // PF_EPI_GRU_Q
-                const float q = tanhf(v);
-                const float z = d.z[p * d.ld_z + j];
-                const float hh = d.h[p * d.ld_h + j];
-                d.out[p * d.ld_out + d.off_out + j] = (1.f - z) * hh + z * q;
-            }
+            if (jok && p < g.M) conv_epilogue(d, p, j, acc[t][r] + bias);
         }
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Halo-tile kernel (PF_PREC_BF16X3, KH*KW >= 3, W8 % 32 == 0, H8 % 4 == 0).
+//
+// With 3-pass bf16 MFMAs a K-step carries 5x less matrix time than in exact fp32, so the generic
+// kernel above becomes bound by what surrounds the MFMAs: every tap re-loads and re-splits the
+// same activations, and one step of prefetch no longer covers the global-load latency.  Here a
+// workgroup (8 waves) owns a 4-row x 32-column pixel tile x BN output channels and, per
+// 32-channel chunk, stages the (4+KH-1) x (32+KW-1) input HALO once (fp32 -> bf16 hi|lo split done
+// once per chunk instead of once per tap; 1.6-2x fewer activation bytes than per-tap tiles).  The
+// KH*KW taps of the chunk then read SHIFTED rows of that LDS image as their A operand.  Weight
+// tiles (already split offline) stream through a 2-slot LDS ring fed by two register sets, i.e.
+// three K-steps in flight; the next chunk's halo is loaded at the chunk's first tap and
+// converted/written at its last tap.  One barrier per K-step.
+// Wave w: tile row w>>1 (32 pixels = one MFMA M-block), output channels (w&1)*32*NT + [0, 32*NT).
+// ----------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(512, 2)      // 8 waves = 2 per SIMD, 256-register budget
+pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
+    constexpr int TH = 4, TW = 32, BN = 64 * NT;
+    constexpr int A_MAX = 4;                  // halo float4 per thread (<= 256 rows x 8 / 512)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = TW + g.kw - 1, HH = TH + g.kh - 1;
+    const int halo_rows = HH * HW;
+    float* Ah = smem;                                   // [2][halo_rows][LDS_LD]
+    float* Bs = smem + 2 * halo_rows * LDS_LD;          // [2][BN][LDS_LD]
+
+    pf_conv_desc d = groups.d[0];
+    if (blockIdx.z == 1) d = groups.d[1];
+    else if (blockIdx.z == 2) d = groups.d[2];
+    else if (blockIdx.z == 3) d = groups.d[3];
+    const int n0 = blockIdx.y * BN;
+    if (n0 >= d.cout) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wy = wave >> 1, wn = wave & 1;
+    const int tiles_x = g.W / TW, tiles_y = g.H / TH;
+    const int tile = blockIdx.x;
+    const int x0 = (tile % tiles_x) * TW;
+    const int y0 = ((tile / tiles_x) % tiles_y) * TH;
+    const long pix0 = (long)(tile / (tiles_x * tiles_y)) * g.N;      // batch offset in pixels
+    const int ph = g.kh / 2, pw = g.kw / 2;
+
+    // ---- halo loader assignment ---------------------------------------------------------------
+    long a_pix[A_MAX];        // source pixel (global row) or -1 (outside the image / no row)
+    int a_row[A_MAX];         // halo row or -1
+#pragma unroll
+    for (int q = 0; q < A_MAX; ++q) {
+        const int r = (tid + 512 * q) >> 3;
+        a_row[q] = r < halo_rows ? r : -1;
+        const int yy = y0 + r / HW - ph, xx = x0 + r % HW - pw;
+        a_pix[q] = (r < halo_rows && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
+                       ? pix0 + (long)yy * g.W + xx : -1;
+    }
+    const int c4 = (tid & 7) * 4;
+    const int ctot = d.c0 + d.c1;
+    const long wrow = (long)g.taps * g.cin_pad;
+    f32x4 ra[A_MAX];
+    unsigned a_ok = 0;
+    auto load_A = [&](int chunk) __attribute__((always_inline)) {
+        const int c = chunk * KC + c4;
+        const float* src; int ld, cc;
+        if (c < d.c0) { src = d.in0 + d.off0; ld = d.ld0; cc = c; }
+        else          { src = d.in1 + d.off1; ld = d.ld1; cc = c - d.c0; }
+        const bool cok = c < ctot;
+        unsigned okbits = 0;
+#pragma unroll
+        for (int q = 0; q < A_MAX; ++q) {
+            const bool ok = cok && a_pix[q] >= 0;
+            const float* ptr = ok ? src + a_pix[q] * ld + cc : d.in0 + d.off0;
+            ra[q] = *reinterpret_cast<const f32x4*>(ptr);
+            okbits |= ok ? (1u << q) : 0u;
+        }
+        a_ok = okbits;
+    };
+    auto store_A = [&](int buf) __attribute__((always_inline)) {
+        float* ah = Ah + buf * halo_rows * LDS_LD;
+#pragma unroll
+        for (int q = 0; q < A_MAX; ++q) {
+            if (a_row[q] < 0) continue;
+            const f32x4 v = ((a_ok >> q) & 1u) ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+            const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
+            const bf16x4 lo = __builtin_convertvector(rest, bf16x4);
+            char* row = reinterpret_cast<char*>(ah + a_row[q] * LDS_LD);
+            *reinterpret_cast<bf16x4*>(row + 2 * c4) = hi;
+            *reinterpret_cast<bf16x4*>(row + 64 + 2 * c4) = lo;
+        }
+    };
+
+    // ---- weight ring: 2 LDS slots, 2 register sets (steps s+1 and s+2 in flight) ----------------
+    f32x4 rb0[NT], rb1[NT];
+    auto load_B = [&](int step, f32x4 (&rb)[NT]) __attribute__((always_inline)) {
+        if (step >= g.nchunks * g.taps) step = g.nchunks * g.taps - 1;      // harmless re-read at the tail
+        const int chunk = step / g.taps, tap = step - chunk * g.taps;
+        const float* wp = d.weight + (long)tap * g.cin_pad + chunk * KC + c4;
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+            rb[q] = *reinterpret_cast<const f32x4*>(wp + (long)(n0 + ((tid + 512 * q) >> 3)) * wrow);
+    };
+    auto store_B = [&](int slot, const f32x4 (&rb)[NT]) __attribute__((always_inline)) {
+        float* bs = Bs + slot * BN * LDS_LD;
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+            *reinterpret_cast<f32x4*>(bs + ((tid + 512 * q) >> 3) * LDS_LD + c4) = rb[q];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto compute = [&](int chunk, int tap, int slot) __attribute__((always_inline)) {
+        const int ky = tap / g.kw, kx = tap - ky * g.kw;
+        const char* ap = reinterpret_cast<const char*>(Ah + (chunk & 1) * halo_rows * LDS_LD +
+                                                       ((wy + ky) * HW + li + kx) * LDS_LD) + 32 * lh;
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            ah[ks] = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
+            al[ks] = *reinterpret_cast<const bf16x8*>(ap + 64 + 16 * ks);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const char* bp = reinterpret_cast<const char*>(Bs + slot * BN * LDS_LD +
+                                                           (32 * NT * wn + 32 * t + li) * LDS_LD) + 32 * lh;
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bh[ks] = *reinterpret_cast<const bf16x8*>(bp + 16 * ks);
+                bl[ks] = *reinterpret_cast<const bf16x8*>(bp + 64 + 16 * ks);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[ks], acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nsteps = g.nchunks * g.taps;
+    // prologue: chunk 0's halo and weight step 0 synchronously; steps 1, 2 in flight
+    load_A(0);
+    load_B(0, rb0);
+    store_A(0);
+    store_B(0, rb0);
+    load_B(1, rb1);
+    load_B(2, rb0);
+    asm volatile("" ::: "memory");
+
+    int chunk = 0, tap = 0;
+    // one K-step; WSET (compile-time) is the register set that holds step s+1 at its top
+    auto step_body = [&](int s, f32x4 (&rb)[NT]) __attribute__((always_inline)) {
+        __syncthreads();                       // slot s&1 and halo chunk&1 are complete; the other
+                                               // slot / halo buffer are no longer being read
+        store_B((s + 1) & 1, rb);              // step s+1 (issued two steps ago)
+        if (tap == g.taps - 1 && chunk + 1 < g.nchunks) store_A((chunk + 1) & 1);
+        load_B(s + 3, rb);                     // refill the freed set
+        if (tap == 0 && chunk + 1 < g.nchunks) load_A(chunk + 1);
+        asm volatile("" ::: "memory");         // keep the loads above the MFMA block
+        compute(chunk, tap, s & 1);
+        if (++tap == g.taps) { tap = 0; ++chunk; }
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        step_body(s, rb1);
+        if (s + 1 < nsteps) step_body(s + 1, rb0);
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = n0 + 32 * NT * wn + 32 * t + li;
+        const bool jok = j < d.cout;
+        const float bias = jok ? d.bias[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tx = (r & 3) + 8 * (r >> 2) + 4 * lh;          // column inside the tile row
+            const long p = pix0 + (long)(y0 + wy) * g.W + x0 + tx;
+            if (jok) conv_epilogue(d, p, j, acc[t][r] + bias);
+        }
+    }
+}
+
+template <int NT>
+int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
+    constexpr int BN = 64 * NT;
+    const int halo_rows = (4 + g.kh - 1) * (32 + g.kw - 1);
+    const size_t lds = (size_t)(2 * halo_rows + 2 * BN) * LDS_LD * sizeof(float);
+    const int B = g.M / g.N;
+    dim3 grid((unsigned)(B * (g.H / 4) * (g.W / 32)), (unsigned)((max_cout + BN - 1) / BN), (unsigned)ngroups);
+    // up to 110 KB of dynamic LDS (5x1 taps): above the 64 KB default limit
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL((pf_conv_halo_kernel<NT>), grid, dim3(512), lds, stream, grp, g);
+    return (int)hipGetLastError();
+}
+
 template <int WM, int WN, int NT>
-int launch_conv(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
+int launch_conv(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, bool split,
+                hipStream_t stream) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((max_cout + BN - 1) / BN), (unsigned)ngroups);
-    hipLaunchKernelGGL((pf_conv_mfma_kernel<WM, WN, NT>), grid, dim3(256), lds, stream, grp, g);
+    if (split)
+        hipLaunchKernelGGL((pf_conv_mfma_kernel<WM, WN, NT, true>), grid, dim3(256), lds, stream, grp, g);
+    else
+        hipLaunchKernelGGL((pf_conv_mfma_kernel<WM, WN, NT, false>), grid, dim3(256), lds, stream, grp, g);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
 // validation + geometry shared by pf_conv2d and pf_conv2d_tile
+// PRIORFLOW_CONV_GENERIC=1 forces the generic kernel (A/B comparisons, debugging)
+static bool pf_conv_force_generic() {
+    static const bool v = [] { const char* e = getenv("PRIORFLOW_CONV_GENERIC"); return e && e[0] == '1'; }();
+    return v;
+}
+
 static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8,
                         ConvGroups& grp, ConvGeom& g, int& max_cout) {
     if (!descs || ngroups < 1 || ngroups > MAX_GROUPS) return PF_ERR_BAD_ARG;
@@ -237,6 +503,8 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
         if (d.off0 < 0 || d.off0 + d.c0 > d.ld0 || (d.c1 > 0 && (d.off1 < 0 || d.off1 + d.c1 > d.ld1)))
             return PF_ERR_BAD_ARG;
         if (d.epilogue < PF_EPI_LINEAR || d.epilogue > PF_EPI_GRU_Q) return PF_ERR_BAD_ARG;
+        if (d.precision != f.precision || (d.precision != PF_PREC_F32 && d.precision != PF_PREC_BF16X3))
+            return PF_ERR_BAD_ARG;
         if (d.off_out < 0 || d.off_out + (d.epilogue == PF_EPI_GRU_ZR ? 128 : d.cout) > d.ld_out)
             return PF_ERR_BAD_ARG;
         if (d.epilogue == PF_EPI_GRU_ZR && (d.cout != 256 || !d.h || !d.aux_out || d.ld_aux < 128 || d.ld_h < 128))
@@ -258,7 +526,13 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // BN in {32,64,128} is legal.  Small problems (one 512x1024 pair = 8192 pixels per branch) need
 // the smaller tile to put >= 1 workgroup on each of the 256 CUs.
 // 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
-static int conv_tile(const ConvGeom& g, int ngroups, int max_cout) {
+// 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3, >= 3 taps, W8 % 32 == 0, H8 % 4 == 0)
+static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
+    if (precision == PF_PREC_BF16X3 && g.taps >= 3 && g.W % 32 == 0 && g.H % 4 == 0 && max_cout > 32 &&
+        (4 + g.kh - 1) * (32 + g.kw - 1) <= 256 && !pf_conv_force_generic()) {
+        const long wgs128 = ((long)g.M / 128) * ngroups * ((max_cout + 127) / 128);
+        return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
+    }
     const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;
     if (max_cout <= 32) return 0;
     if (max_cout <= 64 || m_tiles64 * ((max_cout + 127) / 128) < 512) return 1;
@@ -268,7 +542,7 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout) {
 extern "C" int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
     ConvGroups grp; ConvGeom g; int max_cout;
     const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
-    return rc != PF_OK ? rc : conv_tile(g, ngroups, max_cout);
+    return rc != PF_OK ? rc : conv_tile(g, ngroups, max_cout, descs[0].precision);
 }
 
 extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream) {
@@ -276,9 +550,12 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
     const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
     if (rc != PF_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    switch (conv_tile(g, ngroups, max_cout)) {
-        case 0: return launch_conv<4, 1, 1>(grp, ngroups, g, max_cout, s);
-        case 1: return launch_conv<2, 2, 1>(grp, ngroups, g, max_cout, s);
-        default: return launch_conv<2, 2, 2>(grp, ngroups, g, max_cout, s);
+    const bool split = descs[0].precision == PF_PREC_BF16X3;
+    switch (conv_tile(g, ngroups, max_cout, descs[0].precision)) {
+        case 0: return launch_conv<4, 1, 1>(grp, ngroups, g, max_cout, split, s);
+        case 1: return launch_conv<2, 2, 1>(grp, ngroups, g, max_cout, split, s);
+        case 2: return launch_conv<2, 2, 2>(grp, ngroups, g, max_cout, split, s);
+        case 3: return launch_conv_halo<1>(grp, ngroups, g, max_cout, s);
+        default: return launch_conv_halo<2>(grp, ngroups, g, max_cout, s);
     }
 }

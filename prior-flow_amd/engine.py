@@ -22,8 +22,10 @@ from typing import Dict, List, Optional
 
 import torch
 
-from ._lib import (ACT_RELU, ACT_TANH, EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_RELU, ConvDesc,
-                   PfError, PfLib)
+import os
+
+from ._lib import (ACT_RELU, ACT_TANH, EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_RELU, PREC_BF16X3, PREC_F32,
+                   ConvDesc, PfError, PfLib)
 
 CORR_CH = 324
 
@@ -51,6 +53,22 @@ def pack_mfma(w: torch.Tensor, b: torch.Tensor):
     return wp.contiguous(), bp.contiguous()
 
 
+def split_bf16(wp: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., Cin_pad] -> bf16 [..., Cin_pad/32, 2, 32]: per 32-channel chunk the hi halves
+    (bf16(w), round-to-nearest-even) followed by the lo halves (bf16(w - hi)): exactly the 128-byte
+    LDS row of the PF_PREC_BF16X3 kernels, so staging the weight tile is a plain copy."""
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.float()).to(torch.bfloat16)
+    shp = wp.shape[:-1] + (wp.shape[-1] // 32, 1, 32)
+    return torch.cat([hi.reshape(shp), lo.reshape(shp)], dim=-2).contiguous()
+
+
+def default_precision() -> int:
+    """PRIORFLOW_PRECISION=fp32 selects the exact-fp32 MFMA path; default is the 3-pass bf16
+    split (same parity class: SURVEY.md §7 measured 2e-5 EPE for split-x3 update blocks)."""
+    return PREC_F32 if os.environ.get("PRIORFLOW_PRECISION", "bf16x3").lower() in ("fp32", "f32") else PREC_BF16X3
+
+
 def pack_direct(w: torch.Tensor, b: torch.Tensor):
     """[Cout,Cin,KH,KW] -> [KH*KW][Cin][Cout]."""
     cout, cin, kh, kw = w.shape
@@ -61,21 +79,25 @@ def pack_direct(w: torch.Tensor, b: torch.Tensor):
 class Conv:
     """One packed convolution (MFMA implicit-GEMM path)."""
 
-    def __init__(self, w, b, kh, kw, cin, cout):
+    def __init__(self, w, b, kh, kw, cin, cout, precision=PREC_F32):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
+        self.precision = precision
+        if precision == PREC_BF16X3:
+            self.w = split_bf16(w)
 
     @staticmethod
-    def of(mod) -> "Conv":
+    def of(mod, precision=PREC_F32) -> "Conv":
         w, b = pack_mfma(mod.weight, mod.bias)
-        return Conv(w, b, mod.weight.shape[2], mod.weight.shape[3], mod.weight.shape[1], mod.weight.shape[0])
+        return Conv(w, b, mod.weight.shape[2], mod.weight.shape[3], mod.weight.shape[1], mod.weight.shape[0],
+                    precision)
 
     @staticmethod
-    def fused(mod_z, mod_r) -> "Conv":
+    def fused(mod_z, mod_r, precision=PREC_F32) -> "Conv":
         """convz|convr share their input (core/update.py:48-49): one 384->256 GEMM."""
         w = torch.cat([mod_z.weight, mod_r.weight], 0)
         b = torch.cat([mod_z.bias, mod_r.bias], 0)
         wp, bp = pack_mfma(w, b)
-        return Conv(wp, bp, w.shape[2], w.shape[3], w.shape[1], w.shape[0])
+        return Conv(wp, bp, w.shape[2], w.shape[3], w.shape[1], w.shape[0], precision)
 
     def desc(self, in0, off0, c0, out, off_out, epilogue, in1=None, off1=0, c1=0, scale=1.0,
              h=None, z=None, aux=None) -> ConvDesc:
@@ -93,6 +115,7 @@ class Conv:
         d.ld_z = z.shape[-1] if z is not None else 0
         d.aux_out = aux.data_ptr() if aux is not None else None
         d.ld_aux = aux.shape[-1] if aux is not None else 0
+        d.precision = self.precision
         return d
 
 
@@ -102,27 +125,30 @@ class DirectConv:
         self.cout, self.cin, self.kh, self.kw = mod.weight.shape
 
 
-def pack_update_blocks(oddc, upd) -> Dict[str, object]:
+def pack_update_blocks(oddc, upd, precision: Optional[int] = None) -> Dict[str, object]:
+    pr = default_precision() if precision is None else precision
+    C = lambda m: Conv.of(m, pr)                      # noqa: E731
     ea, eb = oddc.encoder, upd.encoder
     P: Dict[str, object] = {
-        "a.c1": Conv.of(ea.convc1_A), "a.c2": Conv.of(ea.convc2_A),
-        "a.f1a": DirectConv(ea.convf1_A), "a.f2a": Conv.of(ea.convf2_A),
-        "a.f1b": DirectConv(ea.convf1_B), "a.f2b": Conv.of(ea.convf2_B),
+        "precision": pr,
+        "a.c1": C(ea.convc1_A), "a.c2": C(ea.convc2_A),
+        "a.f1a": DirectConv(ea.convf1_A), "a.f2a": C(ea.convf2_A),
+        "a.f1b": DirectConv(ea.convf1_B), "a.f2b": C(ea.convf2_B),
         "a.cf1": DirectConv(ea.conv_conf1), "a.cf2": DirectConv(ea.conv_conf2),
-        "a.out": Conv.of(ea.conv_A),
-        "b.c1": Conv.of(eb.convc1), "b.c2": Conv.of(eb.convc2),
-        "b.f1": DirectConv(eb.convf1), "b.f2": Conv.of(eb.convf2), "b.out": Conv.of(eb.conv),
+        "a.out": C(ea.conv_A),
+        "b.c1": C(eb.convc1), "b.c2": C(eb.convc2),
+        "b.f1": DirectConv(eb.convf1), "b.f2": C(eb.convf2), "b.out": C(eb.conv),
     }
     for tag, blk in (("a", oddc), ("b", upd)):
         g = blk.gru
-        P[f"{tag}.zr1"] = Conv.fused(g.convz1, g.convr1)
-        P[f"{tag}.q1"] = Conv.of(g.convq1)
-        P[f"{tag}.zr2"] = Conv.fused(g.convz2, g.convr2)
-        P[f"{tag}.q2"] = Conv.of(g.convq2)
-        P[f"{tag}.fh1"] = Conv.of(blk.flow_head.conv1)
-        P[f"{tag}.fh2"] = Conv.of(blk.flow_head.conv2)
-        P[f"{tag}.m0"] = Conv.of(blk.mask[0])
-        P[f"{tag}.m2"] = Conv.of(blk.mask[2])
+        P[f"{tag}.zr1"] = Conv.fused(g.convz1, g.convr1, pr)
+        P[f"{tag}.q1"] = C(g.convq1)
+        P[f"{tag}.zr2"] = Conv.fused(g.convz2, g.convr2, pr)
+        P[f"{tag}.q2"] = C(g.convq2)
+        P[f"{tag}.fh1"] = C(blk.flow_head.conv1)
+        P[f"{tag}.fh2"] = C(blk.flow_head.conv2)
+        P[f"{tag}.m0"] = C(blk.mask[0])
+        P[f"{tag}.m2"] = C(blk.mask[2])
     return P
 
 

@@ -39,6 +39,7 @@ class PriOr_RAFT(nn.Module):
         self._ws: Dict[Tuple, Workspace] = {}
         self._graphs: Dict[Tuple, object] = {}
         self.use_graph = os.environ.get("PRIORFLOW_GRAPH", "1") != "0"
+        self.precision: Optional[int] = None      # None -> PRIORFLOW_PRECISION env (default bf16x3)
 
     # ---- reference API surface ----------------------------------------------------------------
     def freeze_bn(self):
@@ -70,10 +71,10 @@ class PriOr_RAFT(nn.Module):
 
     def _weights(self):
         params = list(self.ODDC.parameters()) + list(self.update_block.parameters())
-        sig = tuple((p.data_ptr(), p._version) for p in params)
+        sig = tuple((p.data_ptr(), p._version) for p in params) + (self.precision,)
         if self._packed is None or sig != self._packed_sig:
             with torch.no_grad():
-                self._packed = pack_update_blocks(self.ODDC, self.update_block)
+                self._packed = pack_update_blocks(self.ODDC, self.update_block, self.precision)
             self._packed_sig = sig
             self._graphs.clear()
         return self._packed

@@ -52,6 +52,22 @@ def test_forward_128x256_all_predictions(model):
         assert mean < EPE_BAR, (key, mean, mx)
 
 
+def test_forward_exact_fp32_mode(params):
+    """PRIORFLOW_PRECISION=fp32 / model.precision: exact-fp32 MFMA path."""
+    from prior_flow_amd._lib import PREC_F32
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().eval()
+    m.precision = PREC_F32
+    i1, i2 = gc.synthetic_pair(1, 128, 256)
+    with torch.no_grad():
+        out = m(i1.cuda(), i2.cuda(), iters=12, test_mode=True)
+    mean, mx = epe(out, gc.load("forward_128x256_it12")["a11"])
+    print(f"exact fp32: a11 vs reference mean EPE {mean:.3e} max {mx:.3e}")
+    assert mean < 2e-5, (mean, mx)
+
+
 def test_forward_test_mode_eager_and_graph(model):
     i1, i2 = gc.synthetic_pair(1, 128, 256)
     g = gc.load("forward_128x256_it12")

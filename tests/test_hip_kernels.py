@@ -53,12 +53,23 @@ def _conv_ref(x, w, b, pad):
     return torch.nn.functional.conv2d(x, w, b, padding=pad)
 
 
-def _run_conv(lib, dev, x_nchw, w, b, epilogue, scale=1.0, off_out=0, extra_cols=0, B=None):
+PRECISIONS = ["fp32", "bf16x3"]
+# exact-fp32 MFMA reproduces CPU conv2d to accumulation-order noise; the 3-pass bf16 split keeps
+# 16 mantissa bits per operand (2^-17 relative per product)
+TOL = {"fp32": 2e-5, "bf16x3": 1.5e-4}
+
+
+def _prec(name):
+    from prior_flow_amd._lib import PREC_BF16X3, PREC_F32
+    return {"fp32": PREC_F32, "bf16x3": PREC_BF16X3}[name]
+
+
+def _run_conv(lib, dev, x_nchw, w, b, epilogue, scale=1.0, off_out=0, extra_cols=0, prec="fp32"):
     from prior_flow_amd.engine import Conv, pack_mfma
     Bn, cin, h, wd = x_nchw.shape
     cout = w.shape[0]
     wp, bp = pack_mfma(w.to(dev), b.to(dev))
-    cv = Conv(wp, bp, w.shape[2], w.shape[3], cin, cout)
+    cv = Conv(wp, bp, w.shape[2], w.shape[3], cin, cout, _prec(prec))
     xin = kc.cl(x_nchw).to(dev)
     out = torch.full((Bn * h * wd, cout + off_out + extra_cols), -777.0, device=dev)
     d = cv.desc(xin, 0, cin, out, off_out, epilogue, scale=scale)
@@ -73,7 +84,8 @@ def _run_conv(lib, dev, x_nchw, w, b, epilogue, scale=1.0, off_out=0, extra_cols
     ("1x1_324_256", 324, 256, 1, 1), ("3x3_272_124", 272, 124, 3, 3), ("3x3_128_64", 128, 64, 3, 3),
     ("3x3_256_2", 256, 2, 3, 3), ("1x5_384_128", 384, 128, 1, 5), ("5x1_384_256", 384, 256, 5, 1),
     ("1x1_256_576", 256, 576, 1, 1), ("3x3_256_192", 256, 192, 3, 3)], ids=lambda c: c[0])
-def test_conv_mfma_vs_cpu_conv2d(lib, dev, shape, conv):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_conv_mfma_vs_cpu_conv2d(lib, dev, shape, conv, prec):
     from prior_flow_amd._lib import EPI_LINEAR, EPI_RELU
     B, h, w_ = shape
     name, cin, cout, kh, kw = conv
@@ -82,16 +94,17 @@ def test_conv_mfma_vs_cpu_conv2d(lib, dev, shape, conv):
     w = gc.uni(f"conv/{name}/w", (cout, cin, kh, kw), -bound, bound)
     b = gc.uni(f"conv/{name}/b", (cout,), -0.1, 0.1)
     want = _conv_ref(x, w, b, (kh // 2, kw // 2))
-    out = _run_conv(lib, dev, x, w, b, EPI_RELU, off_out=4, extra_cols=3)
+    out = _run_conv(lib, dev, x, w, b, EPI_RELU, off_out=4, extra_cols=3, prec=prec)
     got = kc.uncl(out[:, 4:4 + cout].cpu(), B, h, w_)
-    kc.check(got, torch.relu(want), 2e-5, f"{name} relu")
+    kc.check(got, torch.relu(want), TOL[prec], f"{name} relu")
     assert float((out[:, :4] + 777.0).abs().max()) == 0.0, "columns left of the slice were touched"
     assert float((out[:, 4 + cout:] + 777.0).abs().max()) == 0.0, "columns right of the slice were touched"
-    out = _run_conv(lib, dev, x, w, b, EPI_LINEAR, scale=0.25)
-    kc.check(kc.uncl(out.cpu(), B, h, w_), 0.25 * want, 2e-5, f"{name} linear*0.25")
+    out = _run_conv(lib, dev, x, w, b, EPI_LINEAR, scale=0.25, prec=prec)
+    kc.check(kc.uncl(out.cpu(), B, h, w_), 0.25 * want, TOL[prec], f"{name} linear*0.25")
 
 
-def test_conv_mfma_identity_asymmetric(lib, dev):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_conv_mfma_identity_asymmetric(lib, dev, prec):
     """A = delta kernel with an ASYMMETRIC weight map: catches row/col swaps in the MFMA
     operand / accumulator layout (cdna_hip_programming.md §3)."""
     from prior_flow_amd._lib import EPI_LINEAR
@@ -101,12 +114,14 @@ def test_conv_mfma_identity_asymmetric(lib, dev):
     for o in range(cout):
         w[o, (o * 7 + 3) % cin, 1, 1] = 1.0 + o      # out[o] = (1+o) * x[(7o+3) % 64]
     b = torch.arange(cout, dtype=torch.float32) * 0.5
-    out = _run_conv(lib, dev, x, w, b, EPI_LINEAR)
+    out = _run_conv(lib, dev, x, w, b, EPI_LINEAR, prec=prec)
     want = torch.stack([(1.0 + o) * x[0, (o * 7 + 3) % cin] + 0.5 * o for o in range(cout)])[None]
-    kc.check(kc.uncl(out.cpu(), 1, 16, 32), want, 1e-5, "identity/asymmetric")
+    # bf16x3: integer weights <= 96 are exact in bf16; x keeps 16 bits -> 2^-17 * 97
+    kc.check(kc.uncl(out.cpu(), 1, 16, 32), want, 1e-5 if prec == "fp32" else 1e-3, "identity/asymmetric")
 
 
-def test_conv_mfma_groups_and_gru(lib, dev, params):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_conv_mfma_groups_and_gru(lib, dev, params, prec):
     """Grouped launch (branch A | branch B) with two input segments and the fused SepConvGRU
     epilogues, against the oracle's GRU (core/update.py:46-60) and the reference golden."""
     from prior_flow_amd._lib import EPI_GRU_Q, EPI_GRU_ZR
@@ -129,19 +144,19 @@ def test_conv_mfma_groups_and_gru(lib, dev, params):
     for tag in ("1", "2"):
         descs = []
         for gi, (blk, nn_) in enumerate(((model.ODDC, net), (model.update_block, net_b))):
-            cv = Conv.fused(getattr(blk.gru, "convz" + tag), getattr(blk.gru, "convr" + tag))
+            cv = Conv.fused(getattr(blk.gru, "convz" + tag), getattr(blk.gru, "convr" + tag), _prec(prec))
             descs.append(cv.desc(nn_[c], 0, 128, z[gi], 0, EPI_GRU_ZR, in1=xr, off1=0, c1=256, h=nn_[c], aux=rh[gi]))
         lib.conv2d(descs, 1, H8, W8, xr)
         descs = []
         for gi, (blk, nn_) in enumerate(((model.ODDC, net), (model.update_block, net_b))):
-            cv = Conv.of(getattr(blk.gru, "convq" + tag))
+            cv = Conv.of(getattr(blk.gru, "convq" + tag), _prec(prec))
             descs.append(cv.desc(rh[gi], 0, 128, nn_[c ^ 1], 0, EPI_GRU_Q, in1=xr, off1=0, c1=256, h=nn_[c], z=z[gi]))
         lib.conv2d(descs, 1, H8, W8, xr)
         c ^= 1
     torch.cuda.synchronize()
-    kc.check(kc.uncl(net[c].cpu(), 1, H8, W8), gc.load("gru")["out"], 3e-5, "ODDC.gru vs reference")
+    kc.check(kc.uncl(net[c].cpu(), 1, H8, W8), gc.load("gru")["out"], TOL[prec], "ODDC.gru vs reference")
     want_b = po.sepconv_gru(params, "update_block.gru.", h0, x)
-    kc.check(kc.uncl(net_b[c].cpu(), 1, H8, W8), want_b, 3e-5, "update_block.gru vs oracle")
+    kc.check(kc.uncl(net_b[c].cpu(), 1, H8, W8), want_b, TOL[prec], "update_block.gru vs oracle")
 
 
 # ---- corr volume + pyramid -------------------------------------------------------------------
@@ -177,14 +192,15 @@ def test_corr_pyramid_vs_reference_golden(lib, dev):
 
 
 # ---- update blocks through the engine -----------------------------------------------------------
-def test_update_blocks_vs_reference_golden(lib, dev, params):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_update_blocks_vs_reference_golden(lib, dev, params, prec):
     import argparse
     from prior_flow_amd.engine import Engine, Workspace, pack_update_blocks
     from prior_flow_amd.prior_raft import PriOr_RAFT
     model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
     model.load_state_dict(params)
     model = model.to(dev)
-    P = pack_update_blocks(model.ODDC, model.update_block)
+    P = pack_update_blocks(model.ODDC, model.update_block, _prec(prec))
     ws = Workspace(lib, 1, 128, 256, dev)
     eng = Engine(lib)
     ui = gc.update_inputs("upd")
@@ -201,11 +217,12 @@ def test_update_blocks_vs_reference_golden(lib, dev, params):
     torch.cuda.synchronize()
     ga, gb = gc.load("update_A"), gc.load("update_B")
     back = lambda rows: kc.uncl(rows.cpu(), 1, H8, W8)
-    kc.check(back(ws.x_a[:, 128:]), ga["motion"], 3e-5, "motion features A")
-    kc.check(back(ws.x_b[:, 128:]), gb["motion"], 3e-5, "motion features B")
-    kc.check(back(ws.net_a[cur]), ga["net"], 3e-5, "net A")
-    kc.check(back(ws.net_b[cur]), gb["net"], 3e-5, "net B")
-    kc.check(back(ws.delta_a[:, :2]), ga["delta"], 3e-5, "delta A")
-    kc.check(back(ws.delta_b[:, :2]), gb["delta"], 3e-5, "delta B")
-    kc.check(back(ws.mask_a)[:, 3::8], ga["mask"], 3e-5, "mask A")
-    kc.check(back(ws.mask_b)[:, 3::8], gb["mask"], 3e-5, "mask B")
+    tol = 3e-5 if prec == "fp32" else 2e-4
+    kc.check(back(ws.x_a[:, 128:]), ga["motion"], tol, "motion features A")
+    kc.check(back(ws.x_b[:, 128:]), gb["motion"], tol, "motion features B")
+    kc.check(back(ws.net_a[cur]), ga["net"], tol, "net A")
+    kc.check(back(ws.net_b[cur]), gb["net"], tol, "net B")
+    kc.check(back(ws.delta_a[:, :2]), ga["delta"], tol, "delta A")
+    kc.check(back(ws.delta_b[:, :2]), gb["delta"], tol, "delta B")
+    kc.check(back(ws.mask_a)[:, 3::8], ga["mask"], tol, "mask A")
+    kc.check(back(ws.mask_b)[:, 3::8], gb["mask"], tol, "mask B")
