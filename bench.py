@@ -38,7 +38,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 TILE_NAMES = {0: "pf_conv_mfma_kernel<4,1,1> (128x32)", 1: "pf_conv_mfma_kernel<2,2,1> (64x64)",
-              2: "pf_conv_mfma_kernel<2,2,2> (64x128)"}
+              2: "pf_conv_mfma_kernel<2,2,2> (64x128)", 3: "pf_conv_halo_kernel<1> (128x64)",
+              4: "pf_conv_halo_kernel<2> (128x128)"}
 
 
 def log(msg):

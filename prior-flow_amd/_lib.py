@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpriorflow_hip.so")
+LIB_PATH = os.environ.get("PRIORFLOW_LIB") or os.path.join(_HERE, "lib", "libpriorflow_hip.so")
 
 EPI_LINEAR, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1

@@ -28,6 +28,7 @@
 // Software pipeline: global loads of K-step s+1 are issued before the MFMAs of step s and
 // written to the other LDS buffer at the top of the next iteration; one __syncthreads per K-step.
 #include <stdlib.h>
+#include <type_traits>
 #include "pf_common.h"
 #include "../../include/priorflow_hip.h"
 
@@ -271,21 +272,33 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
 // 32-channel chunk, stages the (4+KH-1) x (32+KW-1) input HALO once (fp32 -> bf16 hi|lo split done
 // once per chunk instead of once per tap; 1.6-2x fewer activation bytes than per-tap tiles).  The
 // KH*KW taps of the chunk then read SHIFTED rows of that LDS image as their A operand.  Weight
-// tiles (already split offline) stream through a 2-slot LDS ring fed by two register sets, i.e.
-// three K-steps in flight; the next chunk's halo is loaded at the chunk's first tap and
-// converted/written at its last tap.  One barrier per K-step.
+// tiles (already split offline) stream through a 3-slot LDS ring fed by two register sets (global
+// loads issued 4 K-steps ahead); the next chunk's halo is loaded at the chunk's first tap and
+// converted/written at its last-but-one tap.  MFMA operand fragments are double buffered in
+// registers: the ds_reads of step s+1 are issued before the MFMAs of step s, so the LDS round
+// trip is off the critical path (measured: without this the loop ran at ~40 % of the MFMA rate
+// even with barriers, LDS writes and global loads removed).  One barrier per K-step.
 // Wave w: tile row w>>1 (32 pixels = one MFMA M-block), output channels (w&1)*32*NT + [0, 32*NT).
 // ----------------------------------------------------------------------------------------------
-template <int NT>
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NT, int KH, int KW>
 __global__ void __launch_bounds__(512, 2)      // 8 waves = 2 per SIMD, 256-register budget
 pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
-    constexpr int TH = 4, TW = 32, BN = 64 * NT;
-    constexpr int A_MAX = 4;                  // halo float4 per thread (<= 256 rows x 8 / 512)
+    constexpr int TH = 4, TW = 32, BN = 64 * NT, TAPS = KH * KW;
+    constexpr int HW = TW + KW - 1, HH = TH + KH - 1;
+    constexpr int HALO_ROWS = 256;            // >= HH*HW for every supported tap shape; the loader
+    static_assert(HH * HW <= HALO_ROWS, "");  // fills all 256 rows (rows past the halo get zeros)
+    constexpr int A_V4 = HALO_ROWS * 8 / 512; // 4 halo float4 per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int HW = TW + g.kw - 1, HH = TH + g.kh - 1;
-    const int halo_rows = HH * HW;
-    float* Ah = smem;                                   // [2][halo_rows][LDS_LD]
-    float* Bs = smem + 2 * halo_rows * LDS_LD;          // [2][BN][LDS_LD]
+    float* Ah = smem;                                   // [2][HALO_ROWS][LDS_LD]
+    float* Bs = smem + 2 * HALO_ROWS * LDS_LD;          // [3][BN][LDS_LD]  (3-slot ring)
 
     pf_conv_desc d = groups.d[0];
     if (blockIdx.z == 1) d = groups.d[1];
@@ -303,25 +316,26 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     const int x0 = (tile % tiles_x) * TW;
     const int y0 = ((tile / tiles_x) % tiles_y) * TH;
     const long pix0 = (long)(tile / (tiles_x * tiles_y)) * g.N;      // batch offset in pixels
-    const int ph = g.kh / 2, pw = g.kw / 2;
+    constexpr int ph = KH / 2, pw = KW / 2;
 
-    // ---- halo loader assignment ---------------------------------------------------------------
-    long a_pix[A_MAX];        // source pixel (global row) or -1 (outside the image / no row)
-    int a_row[A_MAX];         // halo row or -1
+    // ---- halo loader assignment: thread -> 4 (row, 16-byte column) slots ------------------------
+    long a_pix[A_V4];         // source pixel (global row) or -1 (outside the image / past the halo)
 #pragma unroll
-    for (int q = 0; q < A_MAX; ++q) {
+    for (int q = 0; q < A_V4; ++q) {
         const int r = (tid + 512 * q) >> 3;
-        a_row[q] = r < halo_rows ? r : -1;
         const int yy = y0 + r / HW - ph, xx = x0 + r % HW - pw;
-        a_pix[q] = (r < halo_rows && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
+        a_pix[q] = (r < HH * HW && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
                        ? pix0 + (long)yy * g.W + xx : -1;
     }
     const int c4 = (tid & 7) * 4;
     const int ctot = d.c0 + d.c1;
-    const long wrow = (long)g.taps * g.cin_pad;
-    f32x4 ra[A_MAX];
+    const long wrow = (long)TAPS * g.cin_pad;
+    const int nchunks = g.nchunks;
+    const int nsteps = nchunks * TAPS;
+    f32x4 ra[A_V4];
     unsigned a_ok = 0;
     auto load_A = [&](int chunk) __attribute__((always_inline)) {
+        if (chunk >= nchunks) chunk = nchunks - 1;       // tail: harmless re-read, stored to the idle buffer
         const int c = chunk * KC + c4;
         const float* src; int ld, cc;
         if (c < d.c0) { src = d.in0 + d.off0; ld = d.ld0; cc = c; }
@@ -329,7 +343,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         const bool cok = c < ctot;
         unsigned okbits = 0;
 #pragma unroll
-        for (int q = 0; q < A_MAX; ++q) {
+        for (int q = 0; q < A_V4; ++q) {
             const bool ok = cok && a_pix[q] >= 0;
             const float* ptr = ok ? src + a_pix[q] * ld + cc : d.in0 + d.off0;
             ra[q] = *reinterpret_cast<const f32x4*>(ptr);
@@ -338,25 +352,25 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         a_ok = okbits;
     };
     auto store_A = [&](int buf) __attribute__((always_inline)) {
-        float* ah = Ah + buf * halo_rows * LDS_LD;
+        float* ah = Ah + buf * HALO_ROWS * LDS_LD;
 #pragma unroll
-        for (int q = 0; q < A_MAX; ++q) {
-            if (a_row[q] < 0) continue;
+        for (int q = 0; q < A_V4; ++q) {
             const f32x4 v = ((a_ok >> q) & 1u) ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            // hi = bf16(v) (RNE); lo = bf16(v - hi): the subtraction is exact in fp32
             const bf16x4 hi = __builtin_convertvector(v, bf16x4);
             const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
             const bf16x4 lo = __builtin_convertvector(rest, bf16x4);
-            char* row = reinterpret_cast<char*>(ah + a_row[q] * LDS_LD);
+            char* row = reinterpret_cast<char*>(ah + ((tid + 512 * q) >> 3) * LDS_LD);
             *reinterpret_cast<bf16x4*>(row + 2 * c4) = hi;
             *reinterpret_cast<bf16x4*>(row + 64 + 2 * c4) = lo;
         }
     };
 
-    // ---- weight ring: 2 LDS slots, 2 register sets (steps s+1 and s+2 in flight) ----------------
+    // ---- weight ring: 3 LDS slots, 2 register sets (steps s+2, s+3 staged; s+4 issued) -----------
     f32x4 rb0[NT], rb1[NT];
     auto load_B = [&](int step, f32x4 (&rb)[NT]) __attribute__((always_inline)) {
-        if (step >= g.nchunks * g.taps) step = g.nchunks * g.taps - 1;      // harmless re-read at the tail
-        const int chunk = step / g.taps, tap = step - chunk * g.taps;
+        if (step >= nsteps) step = nsteps - 1;           // tail: harmless re-read
+        const int chunk = step / TAPS, tap = step - chunk * TAPS;
         const float* wp = d.weight + (long)tap * g.cin_pad + chunk * KC + c4;
 #pragma unroll
         for (int q = 0; q < NT; ++q)
@@ -375,62 +389,90 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    auto compute = [&](int chunk, int tap, int slot) __attribute__((always_inline)) {
-        const int ky = tap / g.kw, kx = tap - ky * g.kw;
-        const char* ap = reinterpret_cast<const char*>(Ah + (chunk & 1) * halo_rows * LDS_LD +
-                                                       ((wy + ky) * HW + li + kx) * LDS_LD) + 32 * lh;
-        bf16x8 ah[2], al[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            ah[ks] = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
-            al[ks] = *reinterpret_cast<const bf16x8*>(ap + 64 + 16 * ks);
-        }
+    const char* a_lane = reinterpret_cast<const char*>(Ah + (wy * HW + li) * LDS_LD) + 32 * lh;
+    const char* b_lane = reinterpret_cast<const char*>(Bs + (32 * NT * wn + li) * LDS_LD) + 32 * lh;
+
+    // MFMA operand fragments, double buffered in registers: set (s&1) feeds step s while set
+    // ((s+1)&1) is being filled from LDS for step s+1, so the LDS round trip hides behind MFMAs.
+    // [0],[1] = hi K-halves, [2],[3] = lo K-halves.
+    bf16x8 fa[2][4], fb[2][NT][4];
+    auto fetch = [&](auto SET, int halo_buf, int ky, int kx, int slot) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value;
+        const char* ap = a_lane + (halo_buf * HALO_ROWS + ky * HW + kx) * (LDS_LD * 4);
+        fa[set][0] = *reinterpret_cast<const bf16x8*>(ap);
+        fa[set][1] = *reinterpret_cast<const bf16x8*>(ap + 16);
+        fa[set][2] = *reinterpret_cast<const bf16x8*>(ap + 64);
+        fa[set][3] = *reinterpret_cast<const bf16x8*>(ap + 80);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const char* bp = reinterpret_cast<const char*>(Bs + slot * BN * LDS_LD +
-                                                           (32 * NT * wn + 32 * t + li) * LDS_LD) + 32 * lh;
-            bf16x8 bh[2], bl[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bh[ks] = *reinterpret_cast<const bf16x8*>(bp + 16 * ks);
-                bl[ks] = *reinterpret_cast<const bf16x8*>(bp + 64 + 16 * ks);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[ks], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[ks], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[ks], acc[t], 0, 0, 0);
-            }
+            const char* bp = b_lane + (slot * BN + 32 * t) * (LDS_LD * 4);
+            fb[set][t][0] = *reinterpret_cast<const bf16x8*>(bp);
+            fb[set][t][1] = *reinterpret_cast<const bf16x8*>(bp + 16);
+            fb[set][t][2] = *reinterpret_cast<const bf16x8*>(bp + 64);
+            fb[set][t][3] = *reinterpret_cast<const bf16x8*>(bp + 80);
         }
     };
 
-    const int nsteps = g.nchunks * g.taps;
-    // prologue: chunk 0's halo and weight step 0 synchronously; steps 1, 2 in flight
+    // ---- prologue: halo 0, weight steps 0 and 1 synchronously; steps 2, 3 in flight; frags(0) ------
     load_A(0);
     load_B(0, rb0);
+    load_B(1, rb1);
     store_A(0);
     store_B(0, rb0);
-    load_B(1, rb1);
+    store_B(1, rb1);
     load_B(2, rb0);
+    load_B(3, rb1);
     asm volatile("" ::: "memory");
+    __syncthreads();
+    fetch(std::integral_constant<int, 0>{}, 0, 0, 0, 0);
 
-    int chunk = 0, tap = 0;
-    // one K-step; WSET (compile-time) is the register set that holds step s+1 at its top
-    auto step_body = [&](int s, f32x4 (&rb)[NT]) __attribute__((always_inline)) {
-        __syncthreads();                       // slot s&1 and halo chunk&1 are complete; the other
-                                               // slot / halo buffer are no longer being read
-        store_B((s + 1) & 1, rb);              // step s+1 (issued two steps ago)
-        if (tap == g.taps - 1 && chunk + 1 < g.nchunks) store_A((chunk + 1) & 1);
-        load_B(s + 3, rb);                     // refill the freed set
-        if (tap == 0 && chunk + 1 < g.nchunks) load_A(chunk + 1);
-        asm volatile("" ::: "memory");         // keep the loads above the MFMA block
-        compute(chunk, tap, s & 1);
-        if (++tap == g.taps) { tap = 0; ++chunk; }
+    // One K-step.  U = position inside a PAIR of chunks (0 .. 2*TAPS-1): tap, register-set parity,
+    // ring slot arithmetic (the pair loop carries s mod 3 in `slot3`) and the halo load/store
+    // points are compile-time, so the instruction stream of a pair is straight-line and hipcc
+    // uses exact counted vmcnt waits (a conditional load inside the loop forces vmcnt(0) at the
+    // loop header and drains the whole prefetch queue).
+    //   step s:  barrier | B(s+2) regs -> slot (s+2)%3 | halo(c+1) -> LDS at tap TAPS-2 |
+    //            issue B(s+4) (and halo(c+1) loads at tap 0) | fetch frags(s+1) | MFMAs on frags(s)
+    int slot3 = 0;            // s % 3
+    auto step = [&](auto U, int chunk) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        constexpr int tap = u % TAPS;
+        constexpr int cur = u & 1;                     // parity of s == parity of u (pairs start even)
+        const int s = chunk * TAPS + tap;
+        constexpr int ntap = (tap + 1) % TAPS;         // tap of step s+1
+        constexpr int nky = ntap / KW, nkx = ntap % KW;
+        const int nchunk = (tap == TAPS - 1) ? chunk + 1 : chunk;
+        const int s1 = slot3 == 2 ? 0 : slot3 + 1;     // (s+1) % 3
+        const int s2 = s1 == 2 ? 0 : s1 + 1;           // (s+2) % 3
+#ifndef PF_ABLATE_NO_BARRIER
+        __syncthreads();      // slot (s+1)%3 and the halo of step s+1 are complete; slot (s+2)%3 is idle
+#endif
+#ifndef PF_ABLATE_NO_LDS_WRITE
+        if constexpr (cur == 0) store_B(s2, rb0); else store_B(s2, rb1);
+        if constexpr (tap == TAPS - 2) store_A((chunk + 1) & 1);
+#endif
+#ifndef PF_ABLATE_NO_GLOBAL
+        if constexpr (cur == 0) load_B(s + 4, rb0); else load_B(s + 4, rb1);
+        if constexpr (tap == 0) load_A(chunk + 1);
+#endif
+        asm volatile("" ::: "memory");                 // keep the loads above the MFMA block
+        fetch(std::integral_constant<int, cur ^ 1>{}, nchunk & 1, nky, nkx, s1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][2 + ks], fb[cur][t][ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][ks], fb[cur][t][2 + ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][ks], fb[cur][t][ks], acc[t], 0, 0, 0);
+            }
+        }
+        slot3 = s1;
     };
-    for (int s = 0; s < nsteps; s += 2) {
-        step_body(s, rb1);
-        if (s + 1 < nsteps) step_body(s + 1, rb0);
-    }
+    int c2 = 0;
+    for (; c2 + 1 < nchunks; c2 += 2)
+        static_for<0, 2 * TAPS>([&](auto U) { step(U, c2 + decltype(U)::value / TAPS); });
+    if (nchunks & 1)
+        static_for<0, TAPS>([&](auto U) { step(U, nchunks - 1); });
 
     // ---- epilogue -----------------------------------------------------------------------------
 #pragma unroll
@@ -447,19 +489,26 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     }
 }
 
-template <int NT>
-int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
+template <int NT, int KH, int KW>
+int launch_conv_halo_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
     constexpr int BN = 64 * NT;
-    const int halo_rows = (4 + g.kh - 1) * (32 + g.kw - 1);
-    const size_t lds = (size_t)(2 * halo_rows + 2 * BN) * LDS_LD * sizeof(float);
+    const size_t lds = (size_t)(2 * 256 + 3 * BN) * LDS_LD * sizeof(float);
     const int B = g.M / g.N;
     dim3 grid((unsigned)(B * (g.H / 4) * (g.W / 32)), (unsigned)((max_cout + BN - 1) / BN), (unsigned)ngroups);
-    // up to 110 KB of dynamic LDS (5x1 taps): above the 64 KB default limit
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT>),
+    // 92-110 KB of dynamic LDS: above the 64 KB default limit
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT, KH, KW>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL((pf_conv_halo_kernel<NT>), grid, dim3(512), lds, stream, grp, g);
+    hipLaunchKernelGGL((pf_conv_halo_kernel<NT, KH, KW>), grid, dim3(512), lds, stream, grp, g);
     return (int)hipGetLastError();
+}
+
+template <int NT>
+int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
+    if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3>(grp, ngroups, g, max_cout, stream);
+    if (g.kh == 1 && g.kw == 5) return launch_conv_halo_t<NT, 1, 5>(grp, ngroups, g, max_cout, stream);
+    if (g.kh == 5 && g.kw == 1) return launch_conv_halo_t<NT, 5, 1>(grp, ngroups, g, max_cout, stream);
+    return PF_ERR_BAD_SHAPE;
 }
 
 template <int WM, int WN, int NT>
@@ -528,8 +577,8 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
 // 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3, >= 3 taps, W8 % 32 == 0, H8 % 4 == 0)
 static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
-    if (precision == PF_PREC_BF16X3 && g.taps >= 3 && g.W % 32 == 0 && g.H % 4 == 0 && max_cout > 32 &&
-        (4 + g.kh - 1) * (32 + g.kw - 1) <= 256 && !pf_conv_force_generic()) {
+    const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1);
+    if (precision == PF_PREC_BF16X3 && halo_shape && g.W % 32 == 0 && g.H % 4 == 0 && !pf_conv_force_generic()) {
         const long wgs128 = ((long)g.M / 128) * ngroups * ((max_cout + 127) / 128);
         return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
     }

@@ -59,70 +59,152 @@ __global__ void __launch_bounds__(kBlock) pf_warp_gcorr_wave(const PfWarpGcorrAr
     }
 }
 
-// Tiled direct convolution for the tiny-Cin layers (7x7 2->128, 3x3 8->32, 3x3 32->16).
-// One workgroup = 32 consecutive pixels of one image row x all Cout.  The (KH) x (32+KW-1) x Cin
-// input patch is staged once in LDS (zero padded); a thread owns ONE output channel and
-// 32*Cout/256 pixels, so the weight stream is coalesced over lanes (packed [tap][cin][cout])
-// and every LDS read is a broadcast (all lanes of a pixel group read the same address).
-// Same arithmetic order as pf_direct_conv_elem (taps outer, channels inner).
-template <int COUT>
-__global__ void __launch_bounds__(256) pf_direct_conv_tile(const PfDirectConvArgs a) {
-    constexpr int TP = 32;                       // pixels per tile
-    constexpr int GROUPS = 256 / COUT;           // pixel groups
-    constexpr int PPT = TP / GROUPS;             // pixels per thread
-    static_assert(256 % COUT == 0 && TP % GROUPS == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) float patch[];   // [KH][TP+KW-1][Cin]
-    const int tiles_x = a.W / TP;
-    const int tile = blockIdx.x;
-    const int tx = tile % tiles_x;
-    const int y = (tile / tiles_x) % a.H;
-    const long b = tile / ((long)tiles_x * a.H);
-    const int x0 = tx * TP;
+// Small-Cin convolution on the exact-fp32 matrix cores (7x7 2->128, 3x3 8->32, 3x3 32->16 of the
+// motion encoders, core/update.py:171-178,87; and the encoders' 7x7/2 3->64 stem).
+//
+// GEMM view per 32-pixel row segment: M = 32 output pixels, N = Cout, K = KH*KW*Cin (tap-major,
+// channel-minor: exactly the [KH*KW][Cin][Cout] packing of pf_conv2d_direct).  K is too small
+// and too ragged for the 32-channel-chunk kernels, so the A operand is GATHERED: the input patch
+// (KH x ((32-1)*stride+KW) pixels x Cin, zero padded) is staged in LDS once per segment and lane
+// (pixel i, half h) of v_mfma_f32_32x32x2_f32 step s reads element k = 2s+h of its pixel's
+// im2col row through a small k -> patch-offset table.  Pixel stride inside the patch is made odd
+// (Cin|1) so the 32 lanes of a read spread over the banks.
+struct PfSmallConvArgs {
+    const float* in; int ld_in, c_in_off, Cin; int nchw;      // channel-last rows, or NCHW planes
+    const float* w; const float* bias;                        // [KH*KW*Cin][Cout]
+    float* out; int ld_out, c_out_off, Cout;                  // channel-last
+    int B, H, W;                                              // INPUT spatial size
+    int KH, KW, stride, relu;
+    int Ho, Wo;                                               // output size (H/stride, W/stride)
+};
+
+// One workgroup = one (32-pixel segment, 32-output-channel group) work item; its 4 waves split
+// the K dimension (each <= MAXS MFMA steps) and reduce their 32x32 partial accumulators through
+// LDS.  These layers are LATENCY chains with little parallelism at B=1 (a 64x128 map has 256
+// segments), so the kernel is built to have one global round trip per phase: the patch is staged
+// by all 256 threads with 4 loads in flight each, and every wave prefetches ALL its weights
+// (one per lane per step, 128-byte coalesced rows) into registers before the first MFMA.
+template <int MAXS>
+__global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvArgs a) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int K = a.KH * a.KW * a.Cin;
+    const int KS = (K + 1) >> 1;                    // MFMA steps
+    const int CinP = a.Cin | 1;                     // odd pixel stride (bank spread)
+    const int PW = 31 * a.stride + a.KW;            // patch width in pixels
+    const int patch_elems = a.KH * PW * CinP;
+    float* patch = sm;                              // [KH*PW*CinP]
+    float* red = sm + ((patch_elems + 3) & ~3);     // [3][16][64] partial accumulators of waves 1..3
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ngrp = (a.Cout + 31) / 32;
     const int ph = a.KH / 2, pw = a.KW / 2;
-    const int PW = TP + a.KW - 1;
-    const long N = (long)a.H * a.W;
+    const int segs_x = a.Wo / 32;
+    const long nitems = (long)a.B * a.Ho * segs_x * ngrp;
+    const long Nin = (long)a.H * a.W, Nout = (long)a.Ho * a.Wo;
+    const int a_lane = li * a.stride * CinP;
     const int total = a.KH * PW * a.Cin;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int c = i % a.Cin;
-        const int px = (i / a.Cin) % PW;
-        const int ky = i / (a.Cin * PW);
-        const int yy = y + ky - ph, xx = x0 + px - pw;
-        float v = 0.f;
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-            v = a.in[(b * N + (long)yy * a.W + xx) * a.ld_in + a.c_in_off + c];
-        patch[i] = v;
-    }
-    __syncthreads();
-    const int co = threadIdx.x % COUT;
-    const int grp = threadIdx.x / COUT;
-    float acc[PPT];
+    const int spw = (KS + 3) >> 2;                  // steps per wave
+    const int s_begin = wave * spw;
+    const int s_end = (s_begin + spw < KS) ? s_begin + spw : KS;
+
+    for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int grp = (int)(item % ngrp);
+        const long seg = item / ngrp;
+        const int sx = (int)(seg % segs_x);
+        const int yo = (int)((seg / segs_x) % a.Ho);
+        const long b = seg / ((long)segs_x * a.Ho);
+        const int xi0 = sx * 32 * a.stride - pw, yi0 = yo * a.stride - ph;
+        const int j = 32 * grp + li;                // this lane's output channel
+        const bool jok = j < a.Cout;
+
+        // ---- weights of this wave's K range: one round trip -------------------------------------
+        float bv[MAXS];
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) acc[i] = 0.f;
-    const float* wp = a.w + co;
-    for (int ky = 0; ky < a.KH; ++ky)
-        for (int kx = 0; kx < a.KW; ++kx) {
-            const float* prow = patch + (ky * PW + grp * PPT + kx) * a.Cin;
-            for (int c = 0; c < a.Cin; ++c) {
-                const float w = wp[((long)(ky * a.KW + kx) * a.Cin + c) * COUT];
+        for (int q = 0; q < MAXS; ++q) {
+            const int k = 2 * (s_begin + q) + lh;
+            bv[q] = (jok && s_begin + q < s_end && k < K) ? a.w[(long)k * a.Cout + j] : 0.f;
+        }
+        // ---- input patch: 4 loads in flight per thread ----------------------------------------------
+        __syncthreads();                            // previous item's LDS reads are done
+        for (int e0 = tid; e0 < total; e0 += 4 * 256) {
+            float v[4];
+            int dst[4];
 #pragma unroll
-                for (int i = 0; i < PPT; ++i) acc[i] = acc[i] + prow[i * a.Cin + c] * w;
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u;
+                const int c = e % a.Cin;
+                const int px = (e / a.Cin) % PW;
+                const int ky = e / (a.Cin * PW);
+                const int yy = yi0 + ky, xx = xi0 + px;
+                const bool ok = e < total && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                const long src = a.nchw ? (b * a.Cin + c) * Nin + (long)yy * a.W + xx
+                                        : (b * Nin + (long)yy * a.W + xx) * a.ld_in + a.c_in_off + c;
+                v[u] = ok ? a.in[src] : 0.f;
+                dst[u] = e < total ? (ky * PW + px) * CinP + c : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) patch[dst[u]] = v[u];
+        }
+        __syncthreads();
+
+        // ---- this wave's MFMA steps; im2col offset advanced incrementally (k = 2s + lh) -------------
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        int k0 = 2 * s_begin + lh;
+        if (k0 >= K) k0 = 0;                        // padded K: weight is 0, any valid offset
+        int c = k0 % a.Cin, tap = k0 / a.Cin;
+        int kx = tap % a.KW, ky = tap / a.KW;
+#pragma unroll
+        for (int q = 0; q < MAXS; ++q) {
+            if (s_begin + q < s_end) {              // wave-uniform
+                const float av = patch[(ky * PW + kx) * CinP + c + a_lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[q], acc, 0, 0, 0);
+                c += 2;
+                while (c >= a.Cin) { c -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
+                if (ky >= a.KH) { ky = 0; kx = 0; c = 0; }   // ran past K (odd K tail): stay in range
             }
         }
-    const float bias = a.bias[co];
+        // ---- reduce the 4 partial accumulators ----------------------------------------------------
+        if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        float v = acc[i] + bias;
-        if (a.relu) v = fmaxf(v, 0.f);
-        const long row = b * N + (long)y * a.W + x0 + grp * PPT + i;
-        a.out[row * a.ld_out + a.c_out_off + co] = v;
+            for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave == 0 && jok) {
+            const float bias = a.bias[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[r] + red[r * 64 + lane];
+                v = v + red[(16 + r) * 64 + lane];
+                v = v + red[(32 + r) * 64 + lane];
+                v = v + bias;
+                if (a.relu) v = fmaxf(v, 0.f);
+                const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                a.out[(b * Nout + (long)yo * a.Wo + sx * 32 + px) * a.ld_out + a.c_out_off + j] = v;
+            }
+        }
     }
 }
 
-template <int COUT>
-int launch_direct_tile(const PfDirectConvArgs& a, void* stream) {
-    const size_t lds = (size_t)a.KH * (32 + a.KW - 1) * a.Cin * sizeof(float);
-    const long tiles = (long)a.B * a.H * (a.W / 32);
-    hipLaunchKernelGGL(pf_direct_conv_tile<COUT>, dim3((unsigned)tiles), dim3(256), lds, (hipStream_t)stream, a);
+int launch_small_conv(const PfSmallConvArgs& a, void* stream) {
+    const int K = a.KH * a.KW * a.Cin, KS = (K + 1) / 2;
+    const int PW = 31 * a.stride + a.KW;
+    const int patch_elems = a.KH * PW * (a.Cin | 1);
+    const size_t lds = ((size_t)((patch_elems + 3) & ~3) + 3 * 16 * 64) * 4;
+    const long nitems = (long)a.B * a.Ho * (a.Wo / 32) * ((a.Cout + 31) / 32);
+    const long cap = 256L * 8;                      // 8 workgroups per CU, grid-stride beyond
+    const long blocks = nitems < cap ? nitems : cap;
+    const int spw = ((KS + 3) / 4);
+    if (spw <= 16)
+        hipLaunchKernelGGL(pf_small_conv_mfma<16>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+    else if (spw <= 40)
+        hipLaunchKernelGGL(pf_small_conv_mfma<40>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+    else
+        return PF_ERR_BAD_SHAPE;
     return (int)hipGetLastError();
 }
 
@@ -131,14 +213,21 @@ int launch_direct_tile(const PfDirectConvArgs& a, void* stream) {
 #define PF_LAUNCH(name, args, total, stream) \
     pf_launch_elem<decltype(args), pf_##name##_elem>(args, total, stream)
 
-// device build: route pf_conv2d_direct to the tiled kernel when the shape allows
-#define PF_DIRECT_CONV_LAUNCH(a, total, stream)                                                  \
-    (((a).W % 32 == 0 && (size_t)(a).KH * (32 + (a).KW - 1) * (a).Cin * 4 <= 48 * 1024)          \
-         ? ((a).Cout == 128 ? launch_direct_tile<128>(a, stream)                                 \
-            : (a).Cout == 32 ? launch_direct_tile<32>(a, stream)                                 \
-            : (a).Cout == 16 ? launch_direct_tile<16>(a, stream)                                 \
-                             : pf_launch_elem<PfDirectConvArgs, pf_direct_conv_elem>(a, total, stream)) \
-         : pf_launch_elem<PfDirectConvArgs, pf_direct_conv_elem>(a, total, stream))
+// device build: route pf_conv2d_direct to the MFMA small-Cin kernel when the shape allows
+static int pf_direct_conv_dispatch(const PfDirectConvArgs& d, long total, void* stream) {
+    const int K = d.KH * d.KW * d.Cin;
+    const size_t lds = ((size_t)d.KH * (31 + d.KW) * (d.Cin | 1) + 4 + 3 * 16 * 64) * 4;
+    if (d.W % 32 == 0 && lds <= 60 * 1024 && (K + 1) / 2 <= 160) {
+        PfSmallConvArgs a;
+        a.in = d.in; a.ld_in = d.ld_in; a.c_in_off = d.c_in_off; a.Cin = d.Cin; a.nchw = 0;
+        a.w = d.w; a.bias = d.bias; a.out = d.out; a.ld_out = d.ld_out; a.c_out_off = d.c_out_off; a.Cout = d.Cout;
+        a.B = d.B; a.H = d.H; a.W = d.W; a.KH = d.KH; a.KW = d.KW; a.stride = 1; a.relu = d.relu;
+        a.Ho = d.H; a.Wo = d.W;
+        return launch_small_conv(a, stream);
+    }
+    return pf_launch_elem<PfDirectConvArgs, pf_direct_conv_elem>(d, total, stream);
+}
+#define PF_DIRECT_CONV_LAUNCH(a, total, stream) pf_direct_conv_dispatch(a, total, stream)
 
 #include "pf_api_elem.inc"
 

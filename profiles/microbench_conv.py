@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single pf_conv2d launches at the 512x1024 problem size (B=1, 64x128 map):
+   python profiles/microbench_conv.py [reps] [which]
+which: zr (grouped 1x5 384->256 GRU gates), q (1x5 384->128), c2 (3x3 256->128|192), fh1 (3x3 128->256 x3)
+Prints HIP-event time per launch and algorithmic TFLOP/s; used under rocprofv3 --pmc."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from prior_flow_amd import _lib
+from prior_flow_amd._lib import EPI_GRU_Q, EPI_GRU_ZR, EPI_RELU, PREC_BF16X3, PREC_F32
+from prior_flow_amd.engine import Conv, pack_mfma
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+which = sys.argv[2] if len(sys.argv) > 2 else "zr"
+prec = PREC_F32 if os.environ.get("PRIORFLOW_PRECISION", "bf16x3") == "fp32" else PREC_BF16X3
+lib = _lib.load()
+dev = torch.device("cuda:0")
+H8, W8 = 64, 128
+N = H8 * W8
+g = torch.Generator(device="cpu").manual_seed(0)
+
+
+def rnd(*shape, s=1.0):
+    return (torch.rand(*shape, generator=g) * 2 - 1).mul_(s).to(dev)
+
+
+def conv(cin, cout, kh, kw):
+    w = rnd(cout, cin, kh, kw, s=(1.0 / (cin * kh * kw)) ** 0.5)
+    b = rnd(cout, s=0.1)
+    wp, bp = pack_mfma(w, b)
+    return Conv(wp, bp, kh, kw, cin, cout, prec)
+
+
+net = [rnd(N, 128) for _ in range(2)]
+x = [rnd(N, 256) for _ in range(2)]
+z = [torch.empty(N, 128, device=dev) for _ in range(2)]
+rh = [torch.empty(N, 128, device=dev) for _ in range(2)]
+out = [torch.empty(N, 256, device=dev) for _ in range(3)]
+if which == "zr":
+    cv = [conv(384, 256, 1, 5) for _ in range(2)]
+    descs = [cv[i].desc(net[i], 0, 128, z[i], 0, EPI_GRU_ZR, in1=x[i], off1=0, c1=256, h=net[i], aux=rh[i]) for i in range(2)]
+    flops = 2 * 2.0 * N * 256 * 5 * 384
+elif which == "q":
+    cv = [conv(384, 128, 1, 5) for _ in range(2)]
+    descs = [cv[i].desc(rh[i], 0, 128, out[i], 0, EPI_GRU_Q, in1=x[i], off1=0, c1=256, h=net[i], z=z[i]) for i in range(2)]
+    flops = 2 * 2.0 * N * 128 * 5 * 384
+elif which == "c2":
+    cv = [conv(256, 128, 3, 3), conv(256, 192, 3, 3)]
+    descs = [cv[i].desc(x[i], 0, 256, out[i], 0, EPI_RELU) for i in range(2)]
+    flops = 2.0 * N * (128 + 192) * 9 * 256
+else:
+    cv = [conv(128, 256, 3, 3) for _ in range(3)]
+    descs = [cv[i].desc(net[i % 2], 0, 128, out[i], 0, EPI_RELU) for i in range(3)]
+    flops = 3 * 2.0 * N * 256 * 9 * 128
+for _ in range(3):
+    lib.conv2d(descs, 1, H8, W8, x[0])
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(reps):
+    lib.conv2d(descs, 1, H8, W8, x[0])
+e.record()
+torch.cuda.synchronize()
+us = s.elapsed_time(e) * 1e3 / reps
+print(f"{which}: tile {lib.conv2d_tile(descs, 1, H8, W8)}  {us:.1f} us/launch  {flops / us / 1e6:.1f} TFLOP/s algorithmic "
+      f"({'fp32' if prec == PREC_F32 else 'bf16x3'})")

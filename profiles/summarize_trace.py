@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Per-forward kernel breakdown from a rocprofv3 --kernel-trace CSV of `bench.py`.
+usage: summarize_trace.py <kernel_trace.csv> [forward_index]
+The window runs from one pf_corr_kernel launch pair to the next (one steady-state forward)."""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "pf_corr_kernel" in r["Kernel_Name"]]
+starts = idx[0::2]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else max(0, len(starts) - 4)
+seg = rows[starts[k]:starts[k + 1]]
+agg = collections.OrderedDict()
+for r in seg:
+    key = r["Kernel_Name"][:100]
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    agg.setdefault(key, [0, 0.0])
+    agg[key][0] += 1
+    agg[key][1] += d
+tot = sum(v[1] for v in agg.values())
+span = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e3
+print(f"# forward {k}: kernels {len(seg)}, span {span:.1f} us, busy {tot:.1f} us")
+for name, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%-102s n=%4d  %9.1f us  avg %8.1f us  %5.1f%%" % (name, v[0], v[1], v[1] / v[0], 100 * v[1] / tot))
