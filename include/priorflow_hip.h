@@ -91,6 +91,8 @@ int pf_warp_gcorr(const float* f1, const float* f2, const float* coords, int add
 #define PF_EPI_RELU 1     /* out = relu(acc + bias)                                       */
 #define PF_EPI_GRU_ZR 2   /* cout [0,128): out = sigmoid(.) -> z; [128,256): aux_out = sigmoid(.)*h */
 #define PF_EPI_GRU_Q 3    /* q = tanh(.); out = (1-z)*h + z*q                              */
+#define PF_EPI_TANH_RELU 4 /* cout [0,128): out = tanh(.); [128,256): aux_out = relu(.)
+                            * (net / inp split of the context features, core/prior_raft.py:136-142) */
 
 /* Arithmetic of pf_conv2d (pf_conv_desc.precision); the weight buffer format follows it. */
 #define PF_PREC_F32 0     /* exact fp32 MFMA; weights fp32 [Cout_pad][KH*KW][Cin_pad]                 */
@@ -114,10 +116,15 @@ typedef struct pf_conv_desc {
     const float* z; int ld_z;        /* GRU_Q: update gate                                  */
     float* aux_out; int ld_aux;      /* GRU_ZR: r*h                                         */
     int precision;                   /* PF_PREC_*; identical in every group of a launch     */
+    int stride;                      /* 1 or 2; input map = stride x the output map         */
+    /* optional per-(image, input-channel) affine + ReLU applied to the INPUT as it is loaded
+     * (the previous layer's Instance/BatchNorm folded into this conv): x' = relu?(x*s + t).
+     * [B][c0+c1] floats each; NULL = none.  Halo-kernel convolutions only (3x3/1x5/5x1, bf16x3). */
+    const float* in_scale; const float* in_shift; int in_relu;
 } pf_conv_desc;
 
 /* Launch `ngroups` (1..4) same-geometry convolutions in ONE kernel (grid.z = group):
- * branch A and branch B of an iteration run side by side. */
+ * branch A and branch B of an iteration run side by side.  H8, W8 = OUTPUT map size. */
 int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream);
 
 /* Host-only introspection: which workgroup tile pf_conv2d would use for this launch
@@ -131,6 +138,26 @@ int pf_conv2d_direct(const float* in, int ld_in, int off_in, int cin,
                      const float* weight, const float* bias,
                      float* out, int ld_out, int off_out, int cout,
                      int kh, int kw, int relu, int B, int H8, int W8, void* stream);
+
+/* Small-Cin convolution with stride 1|2 from channel-last or NCHW input (the encoders' 7x7/2 3->64
+ * stem, core/extractor.py:112,144; same kernel family as pf_conv2d_direct).  Hout/Wout = OUTPUT map;
+ * input map = stride x output.  nchw != 0: `in` is [B,cin,Hin,Win] planes (ld_in/off_in ignored). */
+int pf_conv2d_small(const float* in, int nchw, int ld_in, int off_in, int cin,
+                    const float* weight, const float* bias, float* out, int ld_out, int off_out, int cout,
+                    int kh, int kw, int stride, int relu, int B, int Hout, int Wout, void* stream);
+
+/* ---- encoder glue (core/extractor.py) ---------------------------------------------------------- */
+
+/* Per-(image, channel) InstanceNorm statistics of a channel-last map y [B*Np][C] (C <= 256):
+ * scale[b][c] = 1/sqrt(var+eps), shift[b][c] = -mean*scale (biased variance).  Deterministic
+ * two-stage fp64 reduction; partials: workspace of B*nblk*C*2 doubles. */
+int pf_channel_stats(const float* y, int B, int Np, int C, float eps, float* scale, float* shift,
+                     double* partials, int nblk, void* stream);
+
+/* out = relu( res' + relu(y*s + t) ), res' = res | res*rs + rt | absent (ResidualBlock tail,
+ * core/extractor.py:41-47).  y,res,out channel-last [B*Np][C]; s,t,rs,rt [B][C]. */
+int pf_norm_act(const float* y, const float* s, const float* t, const float* res,
+                const float* rs, const float* rt, float* out, int B, int Np, int C, void* stream);
 
 /* coords1 += delta (core/prior_raft.py:193,196).  delta: channel-last, 2 channels at column 0. */
 int pf_coords_add(float* coords1, const float* delta, int ld, int B, int H8, int W8, void* stream);

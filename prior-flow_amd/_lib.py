@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRIORFLOW_LIB") or os.path.join(_HERE, "lib", "libpriorflow_hip.so")
 
-EPI_LINEAR, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2, 3
+EPI_LINEAR, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_TANH_RELU = 0, 1, 2, 3, 4
 PREC_F32, PREC_BF16X3 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -35,7 +35,8 @@ class ConvDesc(C.Structure):
         ("h", _fp), ("ld_h", _i),
         ("z", _fp), ("ld_z", _i),
         ("aux_out", _fp), ("ld_aux", _i),
-        ("precision", _i),
+        ("precision", _i), ("stride", _i),
+        ("in_scale", _fp), ("in_shift", _fp), ("in_relu", _i),
     ]
 
 
@@ -51,6 +52,9 @@ _SIGNATURES = {
     "pf_conv2d": [C.POINTER(ConvDesc), _i, _i, _i, _i, _fp],
     "pf_conv2d_tile": [C.POINTER(ConvDesc), _i, _i, _i, _i],
     "pf_conv2d_direct": [_fp, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
+    "pf_conv2d_small": [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
+    "pf_channel_stats": [_fp, _i, _i, _i, C.c_float, _fp, _fp, _fp, _i, _fp],
+    "pf_norm_act": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pf_coords_add": [_fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
@@ -200,6 +204,27 @@ class PfLib:
         self._rc(self._dll.pf_conv2d_direct(_ptr(x), x.shape[-1], off_in, cin, _ptr(weight), _ptr(bias),
                                             _ptr(out), out.shape[-1], off_out, cout, kh, kw, int(relu),
                                             B, H8, W8, self._stream(x)), "pf_conv2d_direct")
+
+    def conv2d_small(self, x, nchw, off_in, cin, weight, bias, out, off_out, cout, kh, kw, stride, relu,
+                     B, Hout, Wout):
+        self._chk(x, weight, bias, out)
+        self._rc(self._dll.pf_conv2d_small(_ptr(x), int(nchw), 0 if nchw else x.shape[-1], off_in, cin,
+                                           _ptr(weight), _ptr(bias), _ptr(out), out.shape[-1], off_out, cout,
+                                           kh, kw, stride, int(relu), B, Hout, Wout, self._stream(x)),
+                 "pf_conv2d_small")
+
+    def channel_stats(self, y, B, Np, Cch, scale, shift, partials, nblk, eps=1e-5):
+        self._chk(y, scale, shift)
+        if partials.dtype != torch.float64 or partials.numel() < B * nblk * Cch * 2:
+            raise PfError("channel_stats: partials must be float64 with >= B*nblk*C*2 elements")
+        self._rc(self._dll.pf_channel_stats(_ptr(y), B, Np, Cch, eps, _ptr(scale), _ptr(shift),
+                                            C.c_void_p(partials.data_ptr()), nblk, self._stream(y)),
+                 "pf_channel_stats")
+
+    def norm_act(self, y, s, t, out, B, Np, Cc, res=None, rs=None, rt=None):
+        self._chk(y, s, t, out, res, rs, rt)
+        self._rc(self._dll.pf_norm_act(_ptr(y), _ptr(s), _ptr(t), _ptr(res), _ptr(rs), _ptr(rt), _ptr(out),
+                                       B, Np, Cc, self._stream(y)), "pf_norm_act")
 
     def coords_add(self, coords1, delta):
         self._chk(coords1, delta)

@@ -45,7 +45,7 @@ constexpr int MAX_GROUPS = 4;
 
 struct ConvGroups { pf_conv_desc d[MAX_GROUPS]; };
 
-struct ConvGeom { int M, H, W, N; int taps, nchunks, cin_pad, kh, kw; };
+struct ConvGeom { int M, H, W, N; int taps, nchunks, cin_pad, kh, kw; int stride, Hin, Win, Nin; };
 
 // Fused epilogue of one output element (pixel row p, output channel j), v = acc + bias.
 __device__ __forceinline__ void conv_epilogue(const pf_conv_desc& d, long p, int j, float v) {
@@ -60,6 +60,9 @@ __device__ __forceinline__ void conv_epilogue(const pf_conv_desc& d, long p, int
         } else {
             d.aux_out[p * d.ld_aux + (j - 128)] = s * d.h[p * d.ld_h + (j - 128)];    // r*h
         }
+    } else if (d.epilogue == PF_EPI_TANH_RELU) {
+        if (j < 128) d.out[p * d.ld_out + d.off_out + j] = tanhf(v);             // net
+        else d.aux_out[p * d.ld_aux + (j - 128)] = fmaxf(v, 0.f);                // inp
     } else {   // PF_EPI_GRU_Q
         const float q = tanhf(v);
         const float z = d.z[p * d.ld_z + j];
@@ -96,8 +99,8 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
     if (n0 >= d.cout) return;                          // groups may have different Cout
 
     // ---- loader assignment: A rows -----------------------------------------------------------
-    int a_y[A_V4], a_x[A_V4];
-    long a_pix[A_V4];                                  // global pixel index or -1
+    int a_y[A_V4], a_x[A_V4];                          // INPUT-space position of the tap centre
+    long a_pix[A_V4];                                  // its global input pixel index, or -1
 #pragma unroll
     for (int q = 0; q < A_V4; ++q) {
         const int idx = tid + 256 * q;
@@ -105,7 +108,8 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
         const long p = (long)m0 + r;
         if (p < g.M) {
             const int n = (int)(p % g.N);
-            a_y[q] = n / g.W; a_x[q] = n % g.W; a_pix[q] = p;
+            a_y[q] = (n / g.W) * g.stride; a_x[q] = (n % g.W) * g.stride;
+            a_pix[q] = (p / g.N) * g.Nin + (long)a_y[q] * g.Win + a_x[q];
         } else {
             a_y[q] = 0; a_x[q] = 0; a_pix[q] = -1;
         }
@@ -131,10 +135,10 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
 #pragma unroll
         for (int q = 0; q < A_V4; ++q) {
             const int yy = a_y[q] + dy, xx = a_x[q] + dx;
-            const bool ok = cok && a_pix[q] >= 0 && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+            const bool ok = cok && a_pix[q] >= 0 && yy >= 0 && yy < g.Hin && xx >= 0 && xx < g.Win;
             // branch-free: masked lanes read a valid dummy address (row 0 of segment 0) and
             // are zeroed afterwards, so the whole K-step stays in one basic block
-            const long sp = a_pix[q] + (long)dy * g.W + dx;
+            const long sp = a_pix[q] + (long)dy * g.Win + dx;
             const float* ptr = ok ? src + sp * ld + cc : d.in0 + d.off0;
             ra[q] = *reinterpret_cast<const f32x4*>(ptr);
             okbits |= ok ? (1u << q) : 0u;
@@ -288,7 +292,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int NT, int KH, int KW>
+template <int NT, int KH, int KW, bool AFFINE>
 __global__ void __launch_bounds__(512, 2)      // 8 waves = 2 per SIMD, 256-register budget
 pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     constexpr int TH = 4, TW = 32, BN = 64 * NT, TAPS = KH * KW;
@@ -333,10 +337,17 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     const int nchunks = g.nchunks;
     const int nsteps = nchunks * TAPS;
     f32x4 ra[A_V4];
+    f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};   // input affine of this thread's 4 channels
+    const long aff_row = (long)(tile / (tiles_x * tiles_y)) * ctot;     // [image][channel]
     unsigned a_ok = 0;
     auto load_A = [&](int chunk) __attribute__((always_inline)) {
         if (chunk >= nchunks) chunk = nchunks - 1;       // tail: harmless re-read, stored to the idle buffer
         const int c = chunk * KC + c4;
+        if constexpr (AFFINE) {     // compile-time: a runtime-conditional load would break the counted waits
+            const int ca = c < ctot ? c : 0;
+            a_sc = *reinterpret_cast<const f32x4*>(d.in_scale + aff_row + ca);
+            a_sh = *reinterpret_cast<const f32x4*>(d.in_shift + aff_row + ca);
+        }
         const float* src; int ld, cc;
         if (c < d.c0) { src = d.in0 + d.off0; ld = d.ld0; cc = c; }
         else          { src = d.in1 + d.off1; ld = d.ld1; cc = c - d.c0; }
@@ -355,7 +366,15 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         float* ah = Ah + buf * HALO_ROWS * LDS_LD;
 #pragma unroll
         for (int q = 0; q < A_V4; ++q) {
-            const f32x4 v = ((a_ok >> q) & 1u) ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            // previous layer's norm (+ReLU) folded into this load; zero padding applies AFTER it
+            f32x4 x = ra[q];
+            if constexpr (AFFINE) {
+                x = x * a_sc + a_sh;
+                if (d.in_relu) {
+                    x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+                }
+            }
+            const f32x4 v = ((a_ok >> q) & 1u) ? x : f32x4{0.f, 0.f, 0.f, 0.f};
             // hi = bf16(v) (RNE); lo = bf16(v - hi): the subtraction is exact in fp32
             const bf16x4 hi = __builtin_convertvector(v, bf16x4);
             const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
@@ -489,25 +508,34 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     }
 }
 
-template <int NT, int KH, int KW>
+template <int NT, int KH, int KW, bool AFFINE>
 int launch_conv_halo_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
     constexpr int BN = 64 * NT;
     const size_t lds = (size_t)(2 * 256 + 3 * BN) * LDS_LD * sizeof(float);
     const int B = g.M / g.N;
     dim3 grid((unsigned)(B * (g.H / 4) * (g.W / 32)), (unsigned)((max_cout + BN - 1) / BN), (unsigned)ngroups);
     // 92-110 KB of dynamic LDS: above the 64 KB default limit
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT, KH, KW>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT, KH, KW, AFFINE>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL((pf_conv_halo_kernel<NT, KH, KW>), grid, dim3(512), lds, stream, grp, g);
+    hipLaunchKernelGGL((pf_conv_halo_kernel<NT, KH, KW, AFFINE>), grid, dim3(512), lds, stream, grp, g);
     return (int)hipGetLastError();
 }
 
 template <int NT>
 int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
-    if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3>(grp, ngroups, g, max_cout, stream);
-    if (g.kh == 1 && g.kw == 5) return launch_conv_halo_t<NT, 1, 5>(grp, ngroups, g, max_cout, stream);
-    if (g.kh == 5 && g.kw == 1) return launch_conv_halo_t<NT, 5, 1>(grp, ngroups, g, max_cout, stream);
+    // every group of a launch must agree on having an input affine (one instantiation per launch)
+    bool affine = grp.d[0].in_scale != nullptr;
+    for (int i = 1; i < ngroups; ++i)
+        if ((grp.d[i].in_scale != nullptr) != affine) return PF_ERR_BAD_ARG;
+    if (affine) {                           // only the encoders' 3x3 convs use it
+        if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, true>(grp, ngroups, g, max_cout, stream);
+        return PF_ERR_BAD_SHAPE;
+    }
+    if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, false>(grp, ngroups, g, max_cout, stream);
+    if (g.kh == 1 && g.kw == 5) return launch_conv_halo_t<NT, 1, 5, false>(grp, ngroups, g, max_cout, stream);
+    if (g.kh == 5 && g.kw == 1) return launch_conv_halo_t<NT, 5, 1, false>(grp, ngroups, g, max_cout, stream);
     return PF_ERR_BAD_SHAPE;
 }
 
@@ -534,7 +562,7 @@ static bool pf_conv_force_generic() {
 }
 
 static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8,
-                        ConvGroups& grp, ConvGeom& g, int& max_cout) {
+                        ConvGroups& grp, ConvGeom& g, int& max_cout) {   // H8, W8: OUTPUT map size
     if (!descs || ngroups < 1 || ngroups > MAX_GROUPS) return PF_ERR_BAD_ARG;
     if (B <= 0 || H8 <= 0 || W8 <= 0) return PF_ERR_BAD_SHAPE;
     max_cout = 0;
@@ -551,10 +579,14 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
         if (d.c1 > 0 && (((d.ld1 | d.off1) & 3) || (d.c0 % KC) != 0)) return PF_ERR_BAD_SHAPE;
         if (d.off0 < 0 || d.off0 + d.c0 > d.ld0 || (d.c1 > 0 && (d.off1 < 0 || d.off1 + d.c1 > d.ld1)))
             return PF_ERR_BAD_ARG;
-        if (d.epilogue < PF_EPI_LINEAR || d.epilogue > PF_EPI_GRU_Q) return PF_ERR_BAD_ARG;
+        if (d.epilogue < PF_EPI_LINEAR || d.epilogue > PF_EPI_TANH_RELU) return PF_ERR_BAD_ARG;
+        if (d.stride != f.stride || (d.stride != 1 && d.stride != 2)) return PF_ERR_BAD_SHAPE;
+        if ((d.in_scale == nullptr) != (d.in_shift == nullptr)) return PF_ERR_BAD_ARG;
+        if (d.epilogue == PF_EPI_TANH_RELU && (d.cout != 256 || !d.aux_out || d.ld_aux < 128)) return PF_ERR_BAD_ARG;
         if (d.precision != f.precision || (d.precision != PF_PREC_F32 && d.precision != PF_PREC_BF16X3))
             return PF_ERR_BAD_ARG;
-        if (d.off_out < 0 || d.off_out + (d.epilogue == PF_EPI_GRU_ZR ? 128 : d.cout) > d.ld_out)
+        if (d.off_out < 0 ||
+            d.off_out + ((d.epilogue == PF_EPI_GRU_ZR || d.epilogue == PF_EPI_TANH_RELU) ? 128 : d.cout) > d.ld_out)
             return PF_ERR_BAD_ARG;
         if (d.epilogue == PF_EPI_GRU_ZR && (d.cout != 256 || !d.h || !d.aux_out || d.ld_aux < 128 || d.ld_h < 128))
             return PF_ERR_BAD_ARG;
@@ -568,6 +600,7 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
     g.kh = f.kh; g.kw = f.kw; g.taps = f.kh * f.kw;
     g.cin_pad = (f.c0 + f.c1 + KC - 1) / KC * KC;
     g.nchunks = g.cin_pad / KC;
+    g.stride = f.stride; g.Hin = H8 * f.stride; g.Win = W8 * f.stride; g.Nin = g.Hin * g.Win;
     return PF_OK;
 }
 
@@ -578,7 +611,8 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3, >= 3 taps, W8 % 32 == 0, H8 % 4 == 0)
 static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
     const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1);
-    if (precision == PF_PREC_BF16X3 && halo_shape && g.W % 32 == 0 && g.H % 4 == 0 && !pf_conv_force_generic()) {
+    if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1 && g.W % 32 == 0 && g.H % 4 == 0 &&
+        !pf_conv_force_generic()) {
         const long wgs128 = ((long)g.M / 128) * ngroups * ((max_cout + 127) / 128);
         return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
     }
@@ -600,7 +634,10 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
     if (rc != PF_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const bool split = descs[0].precision == PF_PREC_BF16X3;
-    switch (conv_tile(g, ngroups, max_cout, descs[0].precision)) {
+    const int tile_id = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    for (int i = 0; i < ngroups; ++i)       // the input affine is implemented by the halo kernel only
+        if (descs[i].in_scale && tile_id < 3) return PF_ERR_BAD_SHAPE;
+    switch (tile_id) {
         case 0: return launch_conv<4, 1, 1>(grp, ngroups, g, max_cout, split, s);
         case 1: return launch_conv<2, 2, 1>(grp, ngroups, g, max_cout, split, s);
         case 2: return launch_conv<2, 2, 2>(grp, ngroups, g, max_cout, split, s);

@@ -340,30 +340,61 @@ struct PfDirectConvArgs {
     const float* in; int ld_in, c_in_off, Cin;
     const float* w; const float* bias;
     float* out; int ld_out, c_out_off, Cout;
-    int B, H, W, KH, KW, relu;
+    int B, H, W, KH, KW, relu;      // H, W: OUTPUT map
+    int stride, nchw, Hin, Win;     // input map = stride x output; nchw: input is [B,Cin,Hin,Win] planes
 };
 PF_HD void pf_direct_conv_elem(long idx, const PfDirectConvArgs& a) {  // idx over B*N*Cout
-    const long N = (long)a.H * a.W;
+    const long N = (long)a.H * a.W, Nin = (long)a.Hin * a.Win;
     const int co = (int)(idx % a.Cout);
     const long row = idx / a.Cout;
     const long b = row / N, n = row % N;
-    const int y = (int)(n / a.W), x = (int)(n % a.W);
+    const int y = (int)(n / a.W) * a.stride, x = (int)(n % a.W) * a.stride;
     const int ph = a.KH / 2, pw = a.KW / 2;
     float acc = 0.f;
     for (int kh = 0; kh < a.KH; ++kh) {
         const int yy = y + kh - ph;
-        if (yy < 0 || yy >= a.H) continue;
+        if (yy < 0 || yy >= a.Hin) continue;
         for (int kw = 0; kw < a.KW; ++kw) {
             const int xx = x + kw - pw;
-            if (xx < 0 || xx >= a.W) continue;
-            const float* ip = a.in + (b * N + (long)yy * a.W + xx) * a.ld_in + a.c_in_off;
+            if (xx < 0 || xx >= a.Win) continue;
             const float* wp = a.w + ((long)(kh * a.KW + kw) * a.Cin) * a.Cout + co;
-            for (int c = 0; c < a.Cin; ++c) acc = acc + ip[c] * wp[(long)c * a.Cout];
+            for (int c = 0; c < a.Cin; ++c) {
+                const float v = a.nchw ? a.in[(b * a.Cin + c) * Nin + (long)yy * a.Win + xx]
+                                       : a.in[(b * Nin + (long)yy * a.Win + xx) * a.ld_in + a.c_in_off + c];
+                acc = acc + v * wp[(long)c * a.Cout];
+            }
         }
     }
     acc = acc + a.bias[co];
     if (a.relu) acc = fmaxf(acc, 0.f);
     a.out[row * a.ld_out + a.c_out_off + co] = acc;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Encoder glue (core/extractor.py:41-47, :144-150): out = relu( res' + relu(y*s + t) ) with
+// res' = res (identity shortcut) | res*rs + rt (normalised 1x1/2 shortcut) | absent.
+// y, res, out: channel-last [B*Np][C]; s,t,rs,rt: [B][C].  One call = 4 consecutive channels.
+// ----------------------------------------------------------------------------------------------
+struct PfNormActArgs {
+    const float* y; const float* s; const float* t;
+    const float* res; const float* rs; const float* rt;
+    float* out; int B, Np, C;
+};
+PF_HD void pf_norm_act_elem(long idx, const PfNormActArgs& a) {   // idx over B*Np*C/4
+    const int c4n = a.C / 4;
+    const int c = (int)(idx % c4n) * 4;
+    const long row = idx / c4n;
+    const long b = row / a.Np;
+    for (int i = 0; i < 4; ++i) {
+        const long e = row * a.C + c + i, pc = b * a.C + c + i;
+        float v = fmaxf(a.y[e] * a.s[pc] + a.t[pc], 0.f);
+        if (a.res) {
+            float r = a.res[e];
+            if (a.rs) r = r * a.rs[pc] + a.rt[pc];
+            v = fmaxf(r + v, 0.f);
+        }
+        a.out[e] = v;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -208,20 +208,70 @@ int launch_small_conv(const PfSmallConvArgs& a, void* stream) {
     return (int)hipGetLastError();
 }
 
+// Per-(image, channel) statistics of a channel-last map -> the affine of Instance/BatchNorm-style
+// normalisation: scale = 1/sqrt(var+eps), shift = -mean*scale (biased variance, eps 1e-5:
+// nn.InstanceNorm2d, core/extractor.py:112-113).  Two deterministic stages with fp64 accumulation:
+// nblk partial sums per image, then a fixed-order final reduction.
+__global__ void __launch_bounds__(256) pf_stats_partial(const float* __restrict__ y, double* __restrict__ part,
+                                                         int Np, int C, int nblk) {
+    __shared__ double sh[2][256];
+    const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const int g = 256 / C;
+    const int c = tid % C, grp = tid / C;
+    const int chunk = (Np + nblk - 1) / nblk;
+    const int p0 = blk * chunk, p1 = (p0 + chunk < Np) ? p0 + chunk : Np;
+    double s = 0.0, ss = 0.0;
+    if (grp < g)
+        for (int p = p0 + grp; p < p1; p += g) {
+            const double v = (double)y[((long)b * Np + p) * C + c];
+            s += v; ss += v * v;
+        }
+    sh[0][tid] = s; sh[1][tid] = ss;
+    __syncthreads();
+    if (tid < C) {
+        for (int k = 1; k < g; ++k) { s += sh[0][tid + k * C]; ss += sh[1][tid + k * C]; }
+        double* o = part + (((long)b * nblk + blk) * C + c) * 2;
+        o[0] = s; o[1] = ss;
+    }
+}
+__global__ void pf_stats_final(const double* __restrict__ part, float* __restrict__ scale,
+                               float* __restrict__ shift, int C, int nblk, int Np, float eps) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        const double* o = part + (((long)b * nblk + k) * C + c) * 2;
+        s += o[0]; ss += o[1];
+    }
+    const double mean = s / Np;
+    double var = ss / Np - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    scale[(long)b * C + c] = (float)rstd;
+    shift[(long)b * C + c] = (float)(-mean * rstd);
+}
+int launch_stats(const float* y, int B, int Np, int C, float eps, float* scale, float* shift, double* part,
+                 int nblk, void* stream) {
+    hipLaunchKernelGGL(pf_stats_partial, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, y, part, Np, C, nblk);
+    hipLaunchKernelGGL(pf_stats_final, dim3(B), dim3(256), 0, (hipStream_t)stream, part, scale, shift, C, nblk, Np, eps);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
+#define PF_STATS_LAUNCH launch_stats
 #define PF_LAUNCH(name, args, total, stream) \
     pf_launch_elem<decltype(args), pf_##name##_elem>(args, total, stream)
 
 // device build: route pf_conv2d_direct to the MFMA small-Cin kernel when the shape allows
 static int pf_direct_conv_dispatch(const PfDirectConvArgs& d, long total, void* stream) {
     const int K = d.KH * d.KW * d.Cin;
-    const size_t lds = ((size_t)d.KH * (31 + d.KW) * (d.Cin | 1) + 4 + 3 * 16 * 64) * 4;
+    const size_t lds = ((size_t)d.KH * (31 * d.stride + d.KW) * (d.Cin | 1) + 4 + 3 * 16 * 64) * 4;
     if (d.W % 32 == 0 && lds <= 60 * 1024 && (K + 1) / 2 <= 160) {
         PfSmallConvArgs a;
-        a.in = d.in; a.ld_in = d.ld_in; a.c_in_off = d.c_in_off; a.Cin = d.Cin; a.nchw = 0;
+        a.in = d.in; a.ld_in = d.ld_in; a.c_in_off = d.c_in_off; a.Cin = d.Cin; a.nchw = d.nchw;
         a.w = d.w; a.bias = d.bias; a.out = d.out; a.ld_out = d.ld_out; a.c_out_off = d.c_out_off; a.Cout = d.Cout;
-        a.B = d.B; a.H = d.H; a.W = d.W; a.KH = d.KH; a.KW = d.KW; a.stride = 1; a.relu = d.relu;
+        a.B = d.B; a.H = d.Hin; a.W = d.Win; a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.relu = d.relu;
         a.Ho = d.H; a.Wo = d.W;
         return launch_small_conv(a, stream);
     }

@@ -100,7 +100,7 @@ class Conv:
         return Conv(wp, bp, w.shape[2], w.shape[3], w.shape[1], w.shape[0], precision)
 
     def desc(self, in0, off0, c0, out, off_out, epilogue, in1=None, off1=0, c1=0, scale=1.0,
-             h=None, z=None, aux=None) -> ConvDesc:
+             h=None, z=None, aux=None, stride=1, in_scale=None, in_shift=None, in_relu=False) -> ConvDesc:
         assert c0 + c1 == self.cin, (c0, c1, self.cin)
         d = ConvDesc()
         d.in0, d.ld0, d.off0, d.c0 = in0.data_ptr(), in0.shape[-1], off0, c0
@@ -116,6 +116,10 @@ class Conv:
         d.aux_out = aux.data_ptr() if aux is not None else None
         d.ld_aux = aux.shape[-1] if aux is not None else 0
         d.precision = self.precision
+        d.stride = stride
+        d.in_scale = in_scale.data_ptr() if in_scale is not None else None
+        d.in_shift = in_shift.data_ptr() if in_shift is not None else None
+        d.in_relu = int(in_relu)
         return d
 
 
@@ -179,7 +183,11 @@ class Workspace:
         # ---- encoders' side
         self.img_stack = z(B, 6, H, W)
         self.img_rot = z(B, 6, H, W)
-        self.f = {k: z(rows, 256) for k in ("f1a", "f2a", "f1b", "f2b")}
+        # fnet output of the 4 images (f1A, f2A, f1B, f2B), one row block each
+        self.f_all = z(4 * rows, 256)
+        self.f = {k: self.f_all[i * rows:(i + 1) * rows] for i, k in enumerate(("f1a", "f2a", "f1b", "f2b"))}
+        self.img_c = z(2 * B, 3, H, W)         # cnet input  [image1_A | image1_B]
+        self.img_f = z(4 * B, 3, H, W)         # fnet input  [image1_A | image2_A | image1_B | image2_B]
         # ---- pyramids: level i rows [B*N, (H8>>i)*(W8>>i)]
         self.pyr_a = [z(rows, (H8 >> i) * (W8 >> i)) for i in range(4)]
         self.pyr_b = [z(rows, (H8 >> i) * (W8 >> i)) for i in range(4)]
@@ -189,10 +197,13 @@ class Workspace:
         self.flow_b = z(B, 2, H8, W8)
         self.flow_ba = z(B, 2, H8, W8)
         self.flow_tmp = z(B, 2, H8, W8)
-        self.net_a = [z(rows, 128), z(rows, 128)]
-        self.net_b = [z(rows, 128), z(rows, 128)]
-        self.x_a = z(rows, 256)
-        self.x_b = z(rows, 256)
+        # cnet output lands here directly (view A rows first, then view B)
+        self.net0_ab = z(2 * rows, 128)
+        self.x_ab = z(2 * rows, 256)
+        self.net_a = [self.net0_ab[:rows], z(rows, 128)]
+        self.net_b = [self.net0_ab[rows:], z(rows, 128)]
+        self.x_a = self.x_ab[:rows]
+        self.x_b = self.x_ab[rows:]
         self.z_a, self.z_b = z(rows, 128), z(rows, 128)
         self.rh_a, self.rh_b = z(rows, 128), z(rows, 128)
         self.own, self.raw = z(rows, CORR_CH), z(rows, CORR_CH)
@@ -376,3 +387,117 @@ class Engine:
         else:
             self.lib.upsample_flow(ws.c1b, ws.mask_b, out)
         return out
+
+
+# ------------------------------------------------------------------------------------------
+# Encoders (BasicEncoder, core/extractor.py:98-158) on the HIP kernels
+# ------------------------------------------------------------------------------------------
+class EncoderPlan:
+    """fnet (InstanceNorm) or cnet (BatchNorm, eval) as a launch plan.
+
+    conv1 7x7/2 (3->64) runs on the small-Cin exact-fp32 MFMA kernel straight from the NCHW
+    image; every 3x3 stride-1 conv runs on the bf16x3 halo kernel; the stride-2 3x3 / 1x1 convs
+    and the final 1x1 on the generic bf16x3 kernel.  A conv writes its RAW output (+bias); the
+    following norm is never applied as a pass of its own: it is folded, together with the ReLU,
+    into the next conv's input load (`in_scale/in_shift`) or into the residual-tail kernel
+    (`pf_norm_act`) that materialises a block's output.  InstanceNorm statistics come from
+    `pf_channel_stats`; BatchNorm (always eval, core/prior_raft.py:43-48) is a constant affine.
+    """
+
+    def __init__(self, lib: PfLib, enc, precision: int):
+        self.lib = lib
+        self.kind = enc.norm_fn
+        self.precision = precision
+        dev = enc.conv1.weight.device
+        self.dev = dev
+        self.stem = DirectConv(enc.conv1)                      # [49][3][64]
+        self.blocks = []
+        for layer, stride in ((enc.layer1, 1), (enc.layer2, 2), (enc.layer3, 2)):
+            for i, blk in enumerate(layer):
+                st = stride if i == 0 else 1
+                item = {"stride": st, "c1": Conv.of(blk.conv1, precision), "c2": Conv.of(blk.conv2, precision),
+                        "cin": blk.conv1.weight.shape[1], "cout": blk.conv1.weight.shape[0],
+                        "n1": blk.norm1, "n2": blk.norm2}
+                if st != 1:
+                    item["ds"] = Conv.of(blk.downsample[0], precision)
+                    item["n3"] = blk.norm3
+                self.blocks.append(item)
+        self.norm1 = enc.norm1
+        self.final = Conv.of(enc.conv2, precision)             # 1x1 128 -> 256
+        self._bn_cache: Dict[int, tuple] = {}
+        self._bufs = None
+
+    # BatchNorm(eval) -> constant per-channel affine, replicated per image
+    def _bn_affine(self, bn, Bn):
+        key = (id(bn), Bn)
+        if key not in self._bn_cache:
+            with torch.no_grad():
+                sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float()
+                sh = (bn.bias - bn.running_mean * sc).float()
+                self._bn_cache[key] = (sc[None].repeat(Bn, 1).contiguous(), sh[None].repeat(Bn, 1).contiguous())
+        return self._bn_cache[key]
+
+    def _affine(self, norm, y, Bn, Np, C, slot):
+        """(scale, shift) [Bn][C] that normalises the raw conv output y."""
+        if self.kind == "batch":
+            return self._bn_affine(norm, Bn)
+        sc, sh = self._bufs["sc"][slot][: Bn * C].view(Bn, C), self._bufs["sh"][slot][: Bn * C].view(Bn, C)
+        self.lib.channel_stats(y, Bn, Np, C, sc, sh, self._bufs["part"], 128)
+        return sc, sh
+
+    def _alloc(self, Bn, H, W):
+        key = (Bn, H, W)
+        if self._bufs is not None and self._bufs["key"] == key:
+            return
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.dev)  # noqa: E731
+        b = {"key": key}
+        # three rotating activation buffers per resolution (x / y1 / y2 / out rotate through them)
+        for lvl, (h, w, c) in enumerate(((H // 2, W // 2, 64), (H // 4, W // 4, 96), (H // 8, W // 8, 128))):
+            b[f"act{lvl}"] = [z(Bn * h * w, c) for _ in range(4)]
+        b["sc"] = [z(Bn * 128) for _ in range(3)]
+        b["sh"] = [z(Bn * 128) for _ in range(3)]
+        b["part"] = z(Bn * 128 * 128 * 2, dt=torch.float64)
+        self._bufs = b
+
+    def run(self, images: torch.Tensor, out: torch.Tensor, epilogue: int, aux: Optional[torch.Tensor] = None):
+        """images: NCHW [Bn,3,H,W] in [-1,1]; out: channel-last [Bn*N, ld] (fnet: 256 features;
+        cnet with EPI_TANH_RELU: out = net [.,128], aux = x buffer [.,256] whose first 128 columns get inp)."""
+        lib = self.lib
+        Bn, _, H, W = images.shape
+        self._alloc(Bn, H, W)
+        bufs = self._bufs
+        h, w = H // 2, W // 2
+        a0 = bufs["act0"]
+        # stem: raw conv -> a0[0]; x0 = relu(norm1(.)) materialised -> a0[1]
+        lib.conv2d_small(images, True, 0, 3, self.stem.w, self.stem.b, a0[0], 0, 64, 7, 7, 2, False, Bn, h, w)
+        sc, sh = self._affine(self.norm1, a0[0], Bn, h * w, 64, 0)
+        lib.norm_act(a0[0], sc, sh, a0[1], Bn, h * w, 64)
+        x = a0[1]
+        lvl = 0
+        for blk in self.blocks:
+            cin, cout, st = blk["cin"], blk["cout"], blk["stride"]
+            if st != 1:
+                lvl += 1
+                h, w = h // 2, w // 2
+            acts = bufs[f"act{lvl}"]
+            free = [t for t in acts if t.data_ptr() != x.data_ptr()]
+            y1, y2, o = free[0], free[1], free[2]
+            Np = h * w
+            # conv1 (input x is a materialised activation: no affine)
+            lib.conv2d([blk["c1"].desc(x, 0, cin, y1, 0, EPI_LINEAR, stride=st)], Bn, h, w, x)
+            s1, t1 = self._affine(blk["n1"], y1, Bn, Np, cout, 0)
+            # conv2 consumes relu(norm1(y1)) folded into its load
+            lib.conv2d([blk["c2"].desc(y1, 0, cout, y2, 0, EPI_LINEAR, in_scale=s1, in_shift=t1, in_relu=True)],
+                       Bn, h, w, x)
+            s2, t2 = self._affine(blk["n2"], y2, Bn, Np, cout, 1)
+            if st != 1:
+                # shortcut: norm3(conv1x1/2(x)); reuse y1 (conv2 has consumed it) for the raw shortcut
+                lib.conv2d([blk["ds"].desc(x, 0, cin, y1, 0, EPI_LINEAR, stride=st)], Bn, h, w, x)
+                s3, t3 = self._affine(blk["n3"], y1, Bn, Np, cout, 2)
+                lib.norm_act(y2, s2, t2, o, Bn, Np, cout, res=y1, rs=s3, rt=t3)
+            else:
+                lib.norm_act(y2, s2, t2, o, Bn, Np, cout, res=x)
+            x = o
+        # final 1x1 conv 128 -> 256 (core/extractor.py:151)
+        d = self.final.desc(x, 0, 128, out, 0, epilogue, aux=aux)
+        lib.conv2d([d], Bn, h, w, x)

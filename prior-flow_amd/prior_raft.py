@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import Engine, Workspace, pack_update_blocks
+from .engine import EncoderPlan, Engine, Workspace, default_precision, pack_update_blocks
 from .modules import BasicEncoder, build_tree, state_dict_shapes  # noqa: F401
 
 
@@ -38,6 +38,8 @@ class PriOr_RAFT(nn.Module):
         self._packed_sig = None
         self._ws: Dict[Tuple, Workspace] = {}
         self._graphs: Dict[Tuple, object] = {}
+        self._enc_plans = None
+        self._enc_sig = None
         self.use_graph = os.environ.get("PRIORFLOW_GRAPH", "1") != "0"
         self.precision: Optional[int] = None      # None -> PRIORFLOW_PRECISION env (default bf16x3)
 
@@ -88,24 +90,48 @@ class PriOr_RAFT(nn.Module):
             self._graphs.clear()
         return ws
 
+    def _encoder_plans(self):
+        """HIP launch plans of cnet / fnet (bf16x3 mode), rebuilt when their weights change."""
+        params = list(self.fnet.parameters()) + list(self.cnet.parameters()) + list(self.cnet.buffers())
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        if self._enc_plans is None or sig != self._enc_sig:
+            from ._lib import PREC_BF16X3
+            with torch.no_grad():
+                self._enc_plans = (EncoderPlan(self._lib(), self.cnet, PREC_BF16X3),
+                                   EncoderPlan(self._lib(), self.fnet, PREC_BF16X3))
+            self._enc_sig = sig
+            self._graphs.clear()
+        return self._enc_plans
+
     def _encode(self, image1, image2, ws: Workspace, eng: Engine):
-        """Normalise, rotate to view B, run cnet / fnet (core/prior_raft.py:109-149).
-        SURVEY.md §8f rank 1: the encoders run on PyTorch-ROCm convolutions this round."""
+        """Normalise, rotate to view B, run cnet / fnet (core/prior_raft.py:109-149) and leave the
+        features in the workspace (channel-last): f1A,f2A,f1B,f2B; net = tanh(cnet[:128]),
+        inp = relu(cnet[128:]) for both views."""
+        from ._lib import EPI_LINEAR, EPI_TANH_RELU, PREC_BF16X3
         B = ws.B
         image1 = 2 * (image1 / 255.0) - 1.0
         image2 = 2 * (image2 / 255.0) - 1.0
         image1_b, image2_b = eng.rotate_images(ws, image1, image2)
+        precision = default_precision() if self.precision is None else self.precision
+        if precision == PREC_BF16X3 and not self.training:
+            cplan, fplan = self._encoder_plans()
+            ws.img_c[:B].copy_(image1); ws.img_c[B:].copy_(image1_b)
+            ws.img_f[:B].copy_(image1); ws.img_f[B:2 * B].copy_(image2)
+            ws.img_f[2 * B:3 * B].copy_(image1_b); ws.img_f[3 * B:].copy_(image2_b)
+            cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+            fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
+            return
+        # exact-fp32 mode: the encoders stay on PyTorch-ROCm convolutions
         amp = bool(getattr(self.args, "mixed_precision", False))
         with torch.autocast("cuda", enabled=amp):
             cnet = self.cnet(torch.cat([image1, image1_b], 0))
             fmaps = self.fnet(torch.cat([image1, image2, image1_b, image2_b], 0))
-        return fmaps.float(), cnet.float()
+        eng.load_features(ws, fmaps.float(), cnet.float())
 
     def _run(self, ws: Workspace, image1, image2, iters, init_flow, test_mode, out_a, out_b):
         eng = Engine(self._lib())
         P = self._weights()
-        fmaps, cnet = self._encode(image1, image2, ws, eng)
-        eng.load_features(ws, fmaps, cnet)
+        self._encode(image1, image2, ws, eng)
         eng.build_pyramids(ws)
         eng.init_coords(ws, init_flow)
         cur = 0

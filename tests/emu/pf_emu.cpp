@@ -12,6 +12,35 @@ static int pf_loop(const Args& a, long total) {
     return PF_OK;
 }
 #define PF_LAUNCH(name, args, total, stream) pf_loop<decltype(args), pf_##name##_elem>(args, total)
+#define PF_DIRECT_CONV_LAUNCH(a, total, stream) pf_loop<PfDirectConvArgs, pf_direct_conv_elem>(a, total)
+
+// host statement of pf_channel_stats (same fp64 two-stage sums as the device kernels)
+static int emu_stats(const float* y, int B, int Np, int C, float eps, float* scale, float* shift, double* part,
+                     int nblk, void*) {
+    const int chunk = (Np + nblk - 1) / nblk;
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            double s = 0, ss = 0;
+            for (int k = 0; k < nblk; ++k) {
+                double ps = 0, pss = 0;
+                for (int p = k * chunk; p < (k + 1) * chunk && p < Np; ++p) {
+                    const double v = y[((long)b * Np + p) * C + c];
+                    ps += v; pss += v * v;
+                }
+                part[(((long)b * nblk + k) * C + c) * 2] = ps;
+                part[(((long)b * nblk + k) * C + c) * 2 + 1] = pss;
+                s += ps; ss += pss;
+            }
+            const double mean = s / Np;
+            double var = ss / Np - mean * mean;
+            if (var < 0) var = 0;
+            const double rstd = 1.0 / sqrt(var + (double)eps);
+            scale[(long)b * C + c] = (float)rstd;
+            shift[(long)b * C + c] = (float)(-mean * rstd);
+        }
+    return PF_OK;
+}
+#define PF_STATS_LAUNCH emu_stats
 
 #include "pf_api_elem.inc"
 

@@ -224,6 +224,57 @@ def case_layout(lib, dev):
     check(back, torch.tanh(x[:, 4:10]), 2e-6, "to_nchw")
 
 
+def case_channel_stats_and_norm_act(lib, dev):
+    """InstanceNorm statistics + the residual tail relu(res' + relu(norm(y))) (core/extractor.py:41-47)."""
+    B, C, h, w = 2, 96, 12, 20
+    Np = h * w
+    y = gc.uni("enc/y", (B, C, h, w), -3, 5)
+    res = gc.uni("enc/res", (B, C, h, w), -1, 2)
+    d = gc.uni("enc/ds", (B, C, h, w), -4, 4)
+    sc = torch.empty(B, C, device=dev)
+    sh = torch.empty(B, C, device=dev)
+    part = torch.zeros(B * 16 * C * 2, dtype=torch.float64, device=dev)
+    lib.channel_stats(cl(y).to(dev), B, Np, C, sc, sh, part, 16)
+    mean = y.mean(dim=(2, 3))
+    var = y.var(dim=(2, 3), unbiased=False)
+    check(sc, 1.0 / torch.sqrt(var + 1e-5), 2e-6, "scale = rstd")
+    check(sh, -mean / torch.sqrt(var + 1e-5), 2e-6, "shift = -mean*rstd")
+    inorm = torch.nn.functional.instance_norm
+    out = torch.empty(B * Np, C, device=dev)
+    lib.norm_act(cl(y).to(dev), sc, sh, out, B, Np, C)
+    check(uncl(out.cpu(), B, h, w), torch.relu(inorm(y)), 3e-6, "relu(norm(y))")
+    lib.norm_act(cl(y).to(dev), sc, sh, out, B, Np, C, res=cl(res).to(dev))
+    check(uncl(out.cpu(), B, h, w), torch.relu(res + torch.relu(inorm(y))), 3e-6, "identity shortcut")
+    sc3 = torch.empty(B, C, device=dev)
+    sh3 = torch.empty(B, C, device=dev)
+    lib.channel_stats(cl(d).to(dev), B, Np, C, sc3, sh3, part, 16)
+    lib.norm_act(cl(y).to(dev), sc, sh, out, B, Np, C, res=cl(d).to(dev), rs=sc3, rt=sh3)
+    check(uncl(out.cpu(), B, h, w), torch.relu(inorm(d) + torch.relu(inorm(y))), 5e-6, "normalised shortcut")
+
+
+def case_small_conv_stem(lib, dev):
+    """7x7 stride-2 3->64 from NCHW (the encoders' stem, core/extractor.py:112,144)."""
+    B, H, W = 2, 32, 128
+    x = gc.uni("stem/x", (B, 3, H, W), -1, 1)
+    w = gc.uni("stem/w", (64, 3, 7, 7), -0.2, 0.2)
+    b = gc.uni("stem/b", (64,), -0.1, 0.1)
+    want = torch.nn.functional.conv2d(x, w, b, stride=2, padding=3)
+    wp = w.permute(2, 3, 1, 0).reshape(49, 3, 64).contiguous()
+    out = torch.full((B * (H // 2) * (W // 2), 66), -5.0, device=dev)
+    lib.conv2d_small(x.to(dev), True, 0, 3, wp.to(dev), b.to(dev), out, 1, 64, 7, 7, 2, False, B, H // 2, W // 2)
+    check(uncl(out[:, 1:65].cpu(), B, H // 2, W // 2), want, 3e-5, "stem 7x7/2")
+    assert float((out[:, 0] + 5).abs().max()) == 0.0 and float((out[:, 65] + 5).abs().max()) == 0.0
+    # channel-last input, stride 2, ReLU, odd channel count
+    x2 = gc.uni("stem/x2", (1, 5, 16, 64), -1, 1)
+    w2 = gc.uni("stem/w2", (32, 5, 3, 3), -0.3, 0.3)
+    b2 = gc.uni("stem/b2", (32,), -0.1, 0.1)
+    want = torch.relu(torch.nn.functional.conv2d(x2, w2, b2, stride=2, padding=1))
+    out = torch.empty(8 * 32, 32, device=dev)
+    lib.conv2d_small(cl(x2).to(dev), False, 0, 5, w2.permute(2, 3, 1, 0).reshape(9, 5, 32).contiguous().to(dev),
+                     b2.to(dev), out, 0, 32, 3, 3, 2, True, 1, 8, 32)
+    check(uncl(out.cpu(), 1, 8, 32), want, 3e-5, "3x3/2 channel-last")
+
+
 def case_bad_args(lib, dev):
     """Error behaviour: negative PF_ERR codes surface as PfError, nothing is written."""
     from prior_flow_amd._lib import PfError
@@ -249,4 +300,5 @@ def case_bad_args(lib, dev):
 
 
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
-                     case_warp_gcorr, case_upsample, case_coords_add, case_layout, case_bad_args]
+                     case_warp_gcorr, case_upsample, case_coords_add, case_layout,
+                     case_channel_stats_and_norm_act, case_small_conv_stem, case_bad_args]

@@ -226,3 +226,58 @@ def test_update_blocks_vs_reference_golden(lib, dev, params, prec):
     kc.check(back(ws.delta_b[:, :2]), gb["delta"], tol, "delta B")
     kc.check(back(ws.mask_a)[:, 3::8], ga["mask"], tol, "mask A")
     kc.check(back(ws.mask_b)[:, 3::8], gb["mask"], tol, "mask B")
+
+
+# ---- encoders on the HIP kernels ----------------------------------------------------------------
+def test_conv_stride2_and_input_affine(lib, dev):
+    """Generic kernel with stride 2 (3x3/2, 1x1/2) and the halo kernel's folded input norm+ReLU."""
+    from prior_flow_amd._lib import EPI_LINEAR, PREC_BF16X3
+    from prior_flow_amd.engine import Conv, pack_mfma
+    x = gc.uni("s2/x", (2, 64, 16, 64), -1, 1)
+    for name, cout, k in (("3x3s2", 96, 3), ("1x1s2", 96, 1)):
+        w = gc.uni(f"s2/{name}/w", (cout, 64, k, k), -0.1, 0.1)
+        b = gc.uni(f"s2/{name}/b", (cout,), -0.1, 0.1)
+        want = torch.nn.functional.conv2d(x, w, b, stride=2, padding=k // 2)
+        wp, bp = pack_mfma(w.to(dev), b.to(dev))
+        cv = Conv(wp, bp, k, k, 64, cout, PREC_BF16X3)
+        out = torch.empty(2 * 8 * 32, cout, device=dev)
+        xin = kc.cl(x).to(dev)
+        lib.conv2d([cv.desc(xin, 0, 64, out, 0, EPI_LINEAR, stride=2)], 2, 8, 32, xin)
+        kc.check(kc.uncl(out.cpu(), 2, 8, 32), want, 1.5e-4, name)
+    # input affine + relu folded into the halo load (per image, per channel)
+    w = gc.uni("aff/w", (64, 64, 3, 3), -0.1, 0.1)
+    b = gc.uni("aff/b", (64,), -0.1, 0.1)
+    sc = gc.uni("aff/sc", (2, 64), 0.5, 1.5)
+    sh = gc.uni("aff/sh", (2, 64), -0.5, 0.5)
+    xn = torch.relu(x * sc[:, :, None, None] + sh[:, :, None, None])
+    want = torch.nn.functional.conv2d(xn, w, b, padding=1)
+    wp, bp = pack_mfma(w.to(dev), b.to(dev))
+    cv = Conv(wp, bp, 3, 3, 64, 64, PREC_BF16X3)
+    out = torch.empty(2 * 16 * 64, 64, device=dev)
+    xin = kc.cl(x).to(dev)
+    lib.conv2d([cv.desc(xin, 0, 64, out, 0, EPI_LINEAR, in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True)],
+               2, 16, 64, xin)
+    kc.check(kc.uncl(out.cpu(), 2, 16, 64), want, 1.5e-4, "halo conv with folded norm+relu")
+
+
+@pytest.mark.parametrize("which", ["fnet", "cnet"])
+def test_encoder_plan_vs_reference_golden(lib, dev, params, which):
+    """BasicEncoder (core/extractor.py:98-158) through EncoderPlan vs the reference's own output."""
+    import argparse
+    from prior_flow_amd._lib import EPI_LINEAR, PREC_BF16X3
+    from prior_flow_amd.engine import EncoderPlan
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    model.load_state_dict(params)
+    model = model.to(dev).eval()
+    im = gc.uni("enc/img", (2, 3, 128, 256), -1, 1)
+    plan = EncoderPlan(lib, getattr(model, which), PREC_BF16X3)
+    out = torch.empty(2 * 16 * 32, 256, device=dev)
+    plan.run(im.to(dev).contiguous(), out, EPI_LINEAR)
+    torch.cuda.synchronize()
+    got = kc.uncl(out.cpu(), 2, 16, 32)
+    g = gc.load("encoders")
+    sel = slice(0, None, 4) if which == "fnet" else slice(1, None, 4)
+    kc.check(got[:, sel], g[which], 3e-4, f"{which} vs reference")
+    want = po.encoder(params, which + ".", im, "instance" if which == "fnet" else "batch")
+    kc.check(got, want, 3e-4, f"{which} vs oracle (all channels)")
