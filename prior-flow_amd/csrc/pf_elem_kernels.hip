@@ -84,7 +84,7 @@ struct PfSmallConvArgs {
 // segments), so the kernel is built to have one global round trip per phase: the patch is staged
 // by all 256 threads with 4 loads in flight each, and every wave prefetches ALL its weights
 // (one per lane per step, 128-byte coalesced rows) into registers before the first MFMA.
-template <int MAXS>
+template <int MAXS, int PMAX>
 __global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvArgs a) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -108,45 +108,59 @@ __global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvArgs 
     const int spw = (KS + 3) >> 2;                  // steps per wave
     const int s_begin = wave * spw;
     const int s_end = (s_begin + spw < KS) ? s_begin + spw : KS;
+    // patch elements owned by this thread: e = tid + 256*u (same for every item)
+    int pe[PMAX], pd[PMAX];
+#pragma unroll
+    for (int u = 0; u < PMAX; ++u) {
+        const int e = tid + 256 * u;
+        if (e < total) {
+            const int c = e % a.Cin, px = (e / a.Cin) % PW, ky = e / (a.Cin * PW);
+            pe[u] = (ky << 20) | (px << 8) | c;
+            pd[u] = (ky * PW + px) * CinP + c;
+        } else {
+            pe[u] = -1; pd[u] = 0;
+        }
+    }
+
+    // the launcher makes gridDim.x a multiple of ngrp, so a block's channel group never changes:
+    // its weights are fetched ONCE (one global round trip) and stay in registers for every item
+    const int grp = (int)(blockIdx.x % ngrp);
+    const int j = 32 * grp + li;                    // this lane's output channel
+    const bool jok = j < a.Cout;
+    float bv[MAXS];
+#pragma unroll
+    for (int q = 0; q < MAXS; ++q) {
+        const int k = 2 * (s_begin + q) + lh;
+        bv[q] = (jok && s_begin + q < s_end && k < K) ? a.w[(long)k * a.Cout + j] : 0.f;
+    }
+    const float bias = jok ? a.bias[j] : 0.f;
 
     for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int grp = (int)(item % ngrp);
         const long seg = item / ngrp;
         const int sx = (int)(seg % segs_x);
         const int yo = (int)((seg / segs_x) % a.Ho);
         const long b = seg / ((long)segs_x * a.Ho);
         const int xi0 = sx * 32 * a.stride - pw, yi0 = yo * a.stride - ph;
-        const int j = 32 * grp + li;                // this lane's output channel
-        const bool jok = j < a.Cout;
 
-        // ---- weights of this wave's K range: one round trip -------------------------------------
-        float bv[MAXS];
-#pragma unroll
-        for (int q = 0; q < MAXS; ++q) {
-            const int k = 2 * (s_begin + q) + lh;
-            bv[q] = (jok && s_begin + q < s_end && k < K) ? a.w[(long)k * a.Cout + j] : 0.f;
-        }
-        // ---- input patch: 4 loads in flight per thread ----------------------------------------------
+        // ---- input patch: up to PMAX loads in flight per thread; the element -> (ky,px,c)
+        // decomposition is item-independent and was hoisted out of the item loop -----------------
         __syncthreads();                            // previous item's LDS reads are done
-        for (int e0 = tid; e0 < total; e0 += 4 * 256) {
+#pragma unroll
+        for (int u0 = 0; u0 < PMAX; u0 += 4) {
             float v[4];
-            int dst[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = e0 + 256 * u;
-                const int c = e % a.Cin;
-                const int px = (e / a.Cin) % PW;
-                const int ky = e / (a.Cin * PW);
+                const int pk = pe[u0 + u];          // packed (ky << 20 | px << 8 | c), or -1
+                const int c = pk & 255, px = (pk >> 8) & 4095, ky = pk >> 20;
                 const int yy = yi0 + ky, xx = xi0 + px;
-                const bool ok = e < total && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                const bool ok = pk >= 0 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
                 const long src = a.nchw ? (b * a.Cin + c) * Nin + (long)yy * a.W + xx
                                         : (b * Nin + (long)yy * a.W + xx) * a.ld_in + a.c_in_off + c;
-                v[u] = ok ? a.in[src] : 0.f;
-                dst[u] = e < total ? (ky * PW + px) * CinP + c : -1;
+                v[u] = ok ? a.in[ok ? src : 0] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (dst[u] >= 0) patch[dst[u]] = v[u];
+                if (pe[u0 + u] >= 0) patch[pd[u0 + u]] = v[u];
         }
         __syncthreads();
 
@@ -175,7 +189,6 @@ __global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvArgs 
         }
         __syncthreads();
         if (wave == 0 && jok) {
-            const float bias = a.bias[j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[r] + red[r * 64 + lane];
@@ -196,13 +209,21 @@ int launch_small_conv(const PfSmallConvArgs& a, void* stream) {
     const int patch_elems = a.KH * PW * (a.Cin | 1);
     const size_t lds = ((size_t)((patch_elems + 3) & ~3) + 3 * 16 * 64) * 4;
     const long nitems = (long)a.B * a.Ho * (a.Wo / 32) * ((a.Cout + 31) / 32);
-    const long cap = 256L * 8;                      // 8 workgroups per CU, grid-stride beyond
+    const int ngrp = (a.Cout + 31) / 32;
+    const long cap = (256L * 8 / ngrp) * ngrp;      // ~8 workgroups per CU, a multiple of ngrp (see kernel)
     const long blocks = nitems < cap ? nitems : cap;
     const int spw = ((KS + 3) / 4);
-    if (spw <= 16)
-        hipLaunchKernelGGL(pf_small_conv_mfma<16>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
-    else if (spw <= 40)
-        hipLaunchKernelGGL(pf_small_conv_mfma<40>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+    const int pmax = (a.KH * PW * a.Cin + 255) / 256;     // patch elements per thread
+    dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (spw <= 16 && pmax <= 4)
+        hipLaunchKernelGGL((pf_small_conv_mfma<16, 4>), grid, blk, lds, st, a);
+    else if (spw <= 20 && pmax <= 8)
+        hipLaunchKernelGGL((pf_small_conv_mfma<20, 8>), grid, blk, lds, st, a);
+    else if (spw <= 40 && pmax <= 8)
+        hipLaunchKernelGGL((pf_small_conv_mfma<40, 8>), grid, blk, lds, st, a);
+    else if (spw <= 40 && pmax <= 16)
+        hipLaunchKernelGGL((pf_small_conv_mfma<40, 16>), grid, blk, lds, st, a);
     else
         return PF_ERR_BAD_SHAPE;
     return (int)hipGetLastError();
@@ -234,21 +255,31 @@ __global__ void __launch_bounds__(256) pf_stats_partial(const float* __restrict_
         o[0] = s; o[1] = ss;
     }
 }
-__global__ void pf_stats_final(const double* __restrict__ part, float* __restrict__ scale,
-                               float* __restrict__ shift, int C, int nblk, int Np, float eps) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(256) pf_stats_final(const double* __restrict__ part, float* __restrict__ scale,
+                                                       float* __restrict__ shift, int C, int nblk, int Np, float eps) {
+    // block per image; thread (grp, c) sums partials k = grp, grp+g, ... (fixed order), then the
+    // g group sums are added in order: deterministic, and 256/C loads in flight per channel
+    __shared__ double sh[2][256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int g = 256 / C;
+    const int c = tid % C, grp = tid / C;
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        const double* o = part + (((long)b * nblk + k) * C + c) * 2;
-        s += o[0]; ss += o[1];
+    if (grp < g)
+        for (int k = grp; k < nblk; k += g) {
+            const double* o = part + (((long)b * nblk + k) * C + c) * 2;
+            s += o[0]; ss += o[1];
+        }
+    sh[0][tid] = s; sh[1][tid] = ss;
+    __syncthreads();
+    if (tid < C) {
+        for (int k = 1; k < g; ++k) { s += sh[0][tid + k * C]; ss += sh[1][tid + k * C]; }
+        const double mean = s / Np;
+        double var = ss / Np - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        scale[(long)b * C + c] = (float)rstd;
+        shift[(long)b * C + c] = (float)(-mean * rstd);
     }
-    const double mean = s / Np;
-    double var = ss / Np - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    scale[(long)b * C + c] = (float)rstd;
-    shift[(long)b * C + c] = (float)(-mean * rstd);
 }
 int launch_stats(const float* y, int B, int Np, int C, float eps, float* scale, float* shift, double* part,
                  int nblk, void* stream) {
@@ -267,7 +298,8 @@ int launch_stats(const float* y, int B, int Np, int C, float eps, float* scale, 
 static int pf_direct_conv_dispatch(const PfDirectConvArgs& d, long total, void* stream) {
     const int K = d.KH * d.KW * d.Cin;
     const size_t lds = ((size_t)d.KH * (31 * d.stride + d.KW) * (d.Cin | 1) + 4 + 3 * 16 * 64) * 4;
-    if (d.W % 32 == 0 && lds <= 60 * 1024 && (K + 1) / 2 <= 160) {
+    if (d.W % 32 == 0 && lds <= 60 * 1024 && (K + 1) / 2 <= 160 &&
+        d.KH * (31 * d.stride + d.KW) * d.Cin <= 16 * 256 && d.Cin <= 255) {
         PfSmallConvArgs a;
         a.in = d.in; a.ld_in = d.ld_in; a.c_in_off = d.c_in_off; a.Cin = d.Cin; a.nchw = d.nchw;
         a.w = d.w; a.bias = d.bias; a.out = d.out; a.ld_out = d.ld_out; a.c_out_off = d.c_out_off; a.Cout = d.Cout;
