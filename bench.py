@@ -92,7 +92,7 @@ def profile_kernels(model, i1, i2):
     """One eager forward with HIP events around every MFMA-conv and corr-build launch."""
     lib = model._lib()
     recs = []          # (kind, tile, work, start_event, end_event)
-    orig_conv, orig_corr = lib.conv2d, lib.corr_pyramid
+    orig_conv, orig_corr, orig_corr3 = lib.conv2d, lib.corr_pyramid, lib.corr_pyramid_bf16x3
 
     def ev():
         return torch.cuda.Event(enable_timing=True)
@@ -115,7 +115,16 @@ def profile_kernels(model, i1, i2):
         e.record()
         recs.append(("corr", -1, nbytes, s, e))
 
-    lib.conv2d, lib.corr_pyramid = conv2d, corr_pyramid
+    def corr_pyramid_bf16x3(f1s, f2s, levels, B, H8, W8, c):
+        n = H8 * W8
+        nbytes = B * (4.0 * n * n * 85.0 / 64.0 + 2.0 * 4.0 * n * c)
+        s, e = ev(), ev()
+        s.record()
+        orig_corr3(f1s, f2s, levels, B, H8, W8, c)
+        e.record()
+        recs.append(("corr", -1, nbytes, s, e))
+
+    lib.conv2d, lib.corr_pyramid, lib.corr_pyramid_bf16x3 = conv2d, corr_pyramid, corr_pyramid_bf16x3
     was = model.use_graph
     model.use_graph = False
     try:
@@ -125,7 +134,7 @@ def profile_kernels(model, i1, i2):
                 model(i1, i2, iters=ITERS, test_mode=True)
                 torch.cuda.synchronize()
     finally:
-        lib.conv2d, lib.corr_pyramid = orig_conv, orig_corr
+        lib.conv2d, lib.corr_pyramid, lib.corr_pyramid_bf16x3 = orig_conv, orig_corr, orig_corr3
         model.use_graph = was
     by_tile = {}
     corr_t, corr_b, corr_n = 0.0, 0.0, 0
@@ -155,12 +164,14 @@ def profile_kernels(model, i1, i2):
                 "all_conv_kernels": {"gflop": round(all_fl / 1e9, 1), "ms": round(all_ms, 3),
                                      "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}}
     gbps = corr_b / (corr_t * 1e-3) / 1e9
-    roofline_corr = {"kernel": "pf_corr_kernel<true> (corr volume + 4-level pyramid)", "bound": "hbm",
+    roofline_corr = {"kernel": "pf_corr_kernel<fused pool, %s> (corr volume + 4-level pyramid)" % ("bf16x3" if split else "fp32"),
+                     "bound": "hbm",
                      "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                      "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None,
                      "launches_per_forward": corr_n, "avg_launch_us": round(corr_t / corr_n * 1e3, 1),
                      "mb_per_launch": round(corr_b / corr_n / 1e6, 1),
-                     "note": "exact-fp32 MFMA makes this kernel compute-bound (34.4 GFLOP per launch)"}
+                     "note": ("34.4 GFLOP/launch: 3-pass bf16 MFMA + 373 MB of once-written output" if split else
+                              "exact-fp32 MFMA makes this kernel compute-bound (34.4 GFLOP per launch)")}
     return roofline, roofline_corr
 
 
@@ -259,7 +270,8 @@ def main():
                        "parallelism": f"pairs sharded over {world} rank(s), no collective",
                        "weights": "deterministic closed-form fill (no checkpoints offline)",
                        "hip_graph": bool(model.use_graph),
-                       "encoders": "PyTorch-ROCm convs (SURVEY.md 8f rank 1); loop = libpriorflow_hip.so"},
+                       "encoders": ("libpriorflow_hip.so (HIP kernels)" if model._weights()["precision"] == 1
+                                    else "PyTorch-ROCm convs (exact-fp32 mode)")},
         }
         try:
             log("per-kernel HIP-event pass")

@@ -64,6 +64,15 @@ int pf_flo_rotate(const float* flow, const float* g_w2c, const float* g_c2w, flo
 int pf_corr_pyramid(const float* f1, const float* f2, float* lvl0, float* lvl1, float* lvl2,
                     float* lvl3, int B, int H8, int W8, int C, void* stream);
 
+/* Same as pf_corr_pyramid in the 3-pass bf16 split arithmetic (hi*hi + hi*lo + lo*hi, fp32 accumulate):
+ * f1_split / f2_split are the feature rows pre-split by pf_split_bf16. */
+int pf_corr_pyramid_bf16x3(const void* f1_split, const void* f2_split, float* lvl0, float* lvl1,
+                           float* lvl2, float* lvl3, int B, int H8, int W8, int C, void* stream);
+
+/* fp32 rows [rows][C] -> bf16 hi|lo split rows [rows][C/32]{hi[32], lo[32]} (C % 32 == 0): the operand
+ * format of the PF_PREC_BF16X3 GEMMs.  hi = bf16(x) round-to-nearest-even, lo = bf16(x - hi). */
+int pf_split_bf16(const float* in, void* out, long rows, int C, void* stream);
+
 /* DCCL.__call__ steps 1-2 (core/corr.py:119-137): own-view 9x9x4 lookup and the raw
  * cross-view lookup through g_w2c.  coords: planar.  own_out/raw_out: channel-last, 324
  * channels = level*81 + a*9 + b (x += a-4, y += b-4), row stride ld >= 324. */

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "pf_flow_prep": [_fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_flo_rotate": [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_corr_pyramid": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_corr_pyramid_bf16x3": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_split_bf16": [_fp, _fp, C.c_long, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
     "pf_dccl_combine": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_warp_gcorr": [_fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _fp],
@@ -165,6 +167,21 @@ class PfLib:
         self._chk(f1, f2, *levels)
         self._rc(self._dll.pf_corr_pyramid(_ptr(f1), _ptr(f2), *[_ptr(l) for l in levels],
                                            B, H8, W8, f1.shape[-1], self._stream(f1)), "pf_corr_pyramid")
+
+    def split_bf16(self, x, out):
+        """x fp32 [rows, C] -> out bfloat16 [rows, C/32, 2, 32] (hi | lo halves per 32-channel chunk)."""
+        self._chk(x)
+        if out.dtype != torch.bfloat16 or out.numel() != 2 * x.numel() or not out.is_contiguous():
+            raise PfError("split_bf16: out must be contiguous bfloat16 with 2x the elements of x")
+        self._rc(self._dll.pf_split_bf16(_ptr(x), C.c_void_p(out.data_ptr()), x.shape[0], x.shape[-1],
+                                         self._stream(x)), "pf_split_bf16")
+        return out
+
+    def corr_pyramid_bf16x3(self, f1s, f2s, levels, B, H8, W8, Cch):
+        self._chk(*levels)
+        self._rc(self._dll.pf_corr_pyramid_bf16x3(C.c_void_p(f1s.data_ptr()), C.c_void_p(f2s.data_ptr()),
+                                                  *[_ptr(l) for l in levels], B, H8, W8, Cch,
+                                                  self._stream(levels[0])), "pf_corr_pyramid_bf16x3")
 
     def dccl_lookup(self, coords, pyr_own, pyr_other, g_w2c, own_out, raw_out):
         self._chk(coords, g_w2c, own_out, raw_out, *pyr_own, *pyr_other)

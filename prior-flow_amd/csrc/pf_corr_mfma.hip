@@ -27,6 +27,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain 16-byte loads, no struct memcpy
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KC = 32;
 constexpr int LDS_LD = 36;
@@ -42,7 +43,10 @@ struct CorrArgs {
     int n2_tiles;         // number of n2 tiles per batch element
 };
 
-template <bool FUSED_POOL>
+// SPLIT: operands are pre-split bf16 hi|lo rows (pf_split_bf16; same row stride / chunk offsets in
+// bytes as the fp32 rows, so staging is the same 16-byte copy) and the products run as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (3/16 of the exact-fp32 MFMA time).
+template <bool FUSED_POOL, bool SPLIT>
 __global__ void __launch_bounds__(256)
 pf_corr_kernel(const CorrArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
@@ -120,21 +124,51 @@ pf_corr_kernel(const CorrArgs a) {
         // unconditional prefetch (the last one re-reads the final K-step; never stored)
         load_step(step + 1 < nsteps ? step + 1 : step);
         asm volatile("" ::: "memory");   // keep the prefetch above the MFMA block (see pf_conv_mfma.hip)
-        f32x4 af[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(&As[buf][a_off + 4 * q]);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            f32x4 bf[4];
+        if constexpr (SPLIT) {
+            // lane (row li, half lh) owns channels [16lh,16lh+16): bytes [32lh,32lh+32) of hi and of lo (+64)
+            const char* ap = reinterpret_cast<const char*>(&As[buf][a_off]) - 32 * lh;
+            bf16x8 fa[4];
+            fa[0] = *reinterpret_cast<const bf16x8*>(ap);
+            fa[1] = *reinterpret_cast<const bf16x8*>(ap + 16);
+            fa[2] = *reinterpret_cast<const bf16x8*>(ap + 64);
+            fa[3] = *reinterpret_cast<const bf16x8*>(ap + 80);
+            const char* bp0 = reinterpret_cast<const char*>(&Bs[buf][b_off]) - 32 * lh;
+            bf16x8 fb[2][4];      // register double buffer: tile t+1 is fetched during tile t's MFMAs
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                bf[q] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_off + t * 32 * LDS_LD + 4 * q]);
+                fb[0][q] = *reinterpret_cast<const bf16x8*>(bp0 + (q >> 1) * 64 + (q & 1) * 16);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[q].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf[q].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf[q].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf[q].w, acc[t], 0, 0, 0);
+            for (int t = 0; t < 8; ++t) {
+                if (t + 1 < 8) {
+                    const char* bp = bp0 + (t + 1) * 32 * LDS_LD * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        fb[(t + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(bp + (q >> 1) * 64 + (q & 1) * 16);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 + ks], fb[t & 1][ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[t & 1][2 + ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[t & 1][ks], acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+            f32x4 af[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(&As[buf][a_off + 4 * q]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f32x4 bf[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bf[q] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_off + t * 32 * LDS_LD + 4 * q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[q].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf[q].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf[q].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf[q].w, acc[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -222,8 +256,8 @@ pf_pool_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows
 
 }  // namespace
 
-extern "C" int pf_corr_pyramid(const float* f1, const float* f2, float* lvl0, float* lvl1,
-                               float* lvl2, float* lvl3, int B, int H8, int W8, int C, void* stream) {
+static int corr_launch(const float* f1, const float* f2, float* lvl0, float* lvl1, float* lvl2, float* lvl3,
+                       int B, int H8, int W8, int C, bool split, void* stream) {
     if (!f1 || !f2 || !lvl0 || !lvl1 || !lvl2 || !lvl3) return PF_ERR_BAD_ARG;
     if (B <= 0 || H8 <= 0 || W8 <= 0 || C <= 0 || (C % KC) != 0) return PF_ERR_BAD_SHAPE;
     if ((H8 % 8) != 0 || (W8 % 8) != 0) return PF_ERR_BAD_SHAPE;
@@ -238,13 +272,15 @@ extern "C" int pf_corr_pyramid(const float* f1, const float* f2, float* lvl0, fl
         a.tiles_x = W8 / 32;
         a.n2_tiles = (H8 / 8) * a.tiles_x;
         dim3 grid((unsigned)(a.N / BM), (unsigned)a.n2_tiles, (unsigned)B);
-        hipLaunchKernelGGL(pf_corr_kernel<true>, grid, dim3(256), 0, s, a);
+        if (split) hipLaunchKernelGGL((pf_corr_kernel<true, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((pf_corr_kernel<true, false>), grid, dim3(256), 0, s, a);
         return (int)hipGetLastError();
     }
     a.tiles_x = 0;
     a.n2_tiles = (a.N + BN - 1) / BN;
     dim3 grid((unsigned)((a.N + BM - 1) / BM), (unsigned)a.n2_tiles, (unsigned)B);
-    hipLaunchKernelGGL(pf_corr_kernel<false>, grid, dim3(256), 0, s, a);
+    if (split) hipLaunchKernelGGL((pf_corr_kernel<false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pf_corr_kernel<false, false>), grid, dim3(256), 0, s, a);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     float* lv[4] = {lvl0, lvl1, lvl2, lvl3};
@@ -260,4 +296,15 @@ extern "C" int pf_corr_pyramid(const float* f1, const float* f2, float* lvl0, fl
         if (rc) return rc;
     }
     return PF_OK;
+}
+
+extern "C" int pf_corr_pyramid(const float* f1, const float* f2, float* lvl0, float* lvl1,
+                               float* lvl2, float* lvl3, int B, int H8, int W8, int C, void* stream) {
+    return corr_launch(f1, f2, lvl0, lvl1, lvl2, lvl3, B, H8, W8, C, false, stream);
+}
+
+extern "C" int pf_corr_pyramid_bf16x3(const void* f1_split, const void* f2_split, float* lvl0, float* lvl1,
+                                      float* lvl2, float* lvl3, int B, int H8, int W8, int C, void* stream) {
+    return corr_launch((const float*)f1_split, (const float*)f2_split, lvl0, lvl1, lvl2, lvl3, B, H8, W8, C,
+                       true, stream);
 }

@@ -371,6 +371,33 @@ PF_HD void pf_direct_conv_elem(long idx, const PfDirectConvArgs& a) {  // idx ov
 }
 
 // ----------------------------------------------------------------------------------------------
+// fp32 -> bf16 hi|lo split rows (operand format of the PF_PREC_BF16X3 GEMMs):
+// out row = [C/32 chunks] x { bf16 hi[32], bf16 lo[32] }, hi = bf16_rne(x), lo = bf16_rne(x - hi).
+// ----------------------------------------------------------------------------------------------
+PF_HD unsigned short pf_bf16_rne(float f) {
+    union { float f; unsigned u; } v; v.f = f;
+    const unsigned r = v.u + 0x7FFFu + ((v.u >> 16) & 1u);     // round to nearest even (finite inputs)
+    return (unsigned short)(r >> 16);
+}
+PF_HD float pf_bf16_to_f32(unsigned short h) {
+    union { float f; unsigned u; } v; v.u = (unsigned)h << 16;
+    return v.f;
+}
+struct PfSplitArgs { const float* in; unsigned short* out; long rows; int C; };
+PF_HD void pf_split_bf16_elem(long idx, const PfSplitArgs& a) {   // idx over rows*C/4
+    const int c4n = a.C / 4;
+    const int c = (int)(idx % c4n) * 4;
+    const long row = idx / c4n;
+    unsigned short* o = a.out + row * 2 * a.C + (c / 32) * 64 + (c % 32);
+    for (int i = 0; i < 4; ++i) {
+        const float x = a.in[row * a.C + c + i];
+        const unsigned short hi = pf_bf16_rne(x);
+        o[i] = hi;
+        o[32 + i] = pf_bf16_rne(x - pf_bf16_to_f32(hi));
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Encoder glue (core/extractor.py:41-47, :144-150): out = relu( res' + relu(y*s + t) ) with
 // res' = res (identity shortcut) | res*rs + rt (normalised 1x1/2 shortcut) | absent.
 // y, res, out: channel-last [B*Np][C]; s,t,rs,rt: [B][C].  One call = 4 consecutive channels.

@@ -186,6 +186,7 @@ class Workspace:
         # fnet output of the 4 images (f1A, f2A, f1B, f2B), one row block each
         self.f_all = z(4 * rows, 256)
         self.f = {k: self.f_all[i * rows:(i + 1) * rows] for i, k in enumerate(("f1a", "f2a", "f1b", "f2b"))}
+        self.f_split = torch.zeros(4 * rows, 8, 2, 32, dtype=torch.bfloat16, device=device)   # bf16 hi|lo rows
         self.img_c = z(2 * B, 3, H, W)         # cnet input  [image1_A | image1_B]
         self.img_f = z(4 * B, 3, H, W)         # fnet input  [image1_A | image2_A | image1_B | image2_B]
         # ---- pyramids: level i rows [B*N, (H8>>i)*(W8>>i)]
@@ -253,8 +254,15 @@ class Engine:
         lib.to_channel_last(cb, 0, 128, ws.net_b[0], 0, ACT_TANH)
         lib.to_channel_last(cb, 128, 128, ws.x_b, 0, ACT_RELU)
 
-    def build_pyramids(self, ws: Workspace):
+    def build_pyramids(self, ws: Workspace, precision: int = PREC_F32):
         """corr + build_pyramid for both views (core/prior_raft.py:151-159)."""
+        if precision == PREC_BF16X3:
+            self.lib.split_bf16(ws.f_all, ws.f_split)          # all four feature maps at once
+            rows = ws.B * ws.N
+            fs = [ws.f_split[i * rows:(i + 1) * rows] for i in range(4)]
+            self.lib.corr_pyramid_bf16x3(fs[0], fs[1], ws.pyr_a, ws.B, ws.H8, ws.W8, 256)
+            self.lib.corr_pyramid_bf16x3(fs[2], fs[3], ws.pyr_b, ws.B, ws.H8, ws.W8, 256)
+            return
         self.lib.corr_pyramid(ws.f["f1a"], ws.f["f2a"], ws.pyr_a, ws.B, ws.H8, ws.W8)
         self.lib.corr_pyramid(ws.f["f1b"], ws.f["f2b"], ws.pyr_b, ws.B, ws.H8, ws.W8)
 

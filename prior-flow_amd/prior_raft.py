@@ -132,7 +132,7 @@ class PriOr_RAFT(nn.Module):
         eng = Engine(self._lib())
         P = self._weights()
         self._encode(image1, image2, ws, eng)
-        eng.build_pyramids(ws)
+        eng.build_pyramids(ws, P["precision"])
         eng.init_coords(ws, init_flow)
         cur = 0
         for it in range(iters):

@@ -275,6 +275,21 @@ def case_small_conv_stem(lib, dev):
     check(uncl(out.cpu(), 1, 8, 32), want, 3e-5, "3x3/2 channel-last")
 
 
+def case_split_bf16(lib, dev):
+    """fp32 -> bf16 hi|lo rows: hi = bf16(x) (RNE), lo = bf16(x - hi); hi + lo keeps 16 mantissa bits."""
+    x = gc.uni("split/x", (37, 96), -50, 50)
+    x[0, :4] = torch.tensor([0.0, 1.0, -1.0, 3.0e-20])
+    out = torch.zeros(37, 3, 2, 32, dtype=torch.bfloat16, device=dev)
+    lib.split_bf16(x.to(dev), out)
+    o = out.cpu().float()
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    assert torch.equal(o[:, :, 0].reshape(37, 96), hi.float()), "hi halves"
+    assert torch.equal(o[:, :, 1].reshape(37, 96), lo.float()), "lo halves"
+    rec = o[:, :, 0].reshape(37, 96) + o[:, :, 1].reshape(37, 96)
+    assert float(((rec - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
+
+
 def case_bad_args(lib, dev):
     """Error behaviour: negative PF_ERR codes surface as PfError, nothing is written."""
     from prior_flow_amd._lib import PfError
@@ -301,4 +316,4 @@ def case_bad_args(lib, dev):
 
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_upsample, case_coords_add, case_layout,
-                     case_channel_stats_and_norm_act, case_small_conv_stem, case_bad_args]
+                     case_channel_stats_and_norm_act, case_small_conv_stem, case_split_bf16, case_bad_args]

@@ -162,17 +162,26 @@ def test_conv_mfma_groups_and_gru(lib, dev, params, prec):
 # ---- corr volume + pyramid -------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 16, 64), (1, 24, 40), (1, 16, 24)],
                          ids=lambda s: "B%dx%dx%d" % s)
-def test_corr_pyramid(lib, dev, shape):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_corr_pyramid(lib, dev, shape, prec):
     B, h, w = shape
     f1 = gc.uni(f"corrk/f1/{h}x{w}", (B, 256, h, w), -1.7, 1.7)
     f2 = gc.uni(f"corrk/f2/{h}x{w}", (B, 256, h, w), -1.7, 1.7)
     n = h * w
     lv = [torch.full((B * n, (h >> i) * (w >> i)), float("nan"), device=dev) for i in range(4)]
-    lib.corr_pyramid(kc.cl(f1).to(dev), kc.cl(f2).to(dev), lv, B, h, w)
+    if prec == "fp32":
+        lib.corr_pyramid(kc.cl(f1).to(dev), kc.cl(f2).to(dev), lv, B, h, w)
+    else:
+        s1 = torch.empty(B * n, 8, 2, 32, dtype=torch.bfloat16, device=dev)
+        s2 = torch.empty_like(s1)
+        lib.split_bf16(kc.cl(f1).to(dev), s1)
+        lib.split_bf16(kc.cl(f2).to(dev), s2)
+        lib.corr_pyramid_bf16x3(s1, s2, lv, B, h, w, 256)
     torch.cuda.synchronize()
     pyr = po.build_pyramid(po.corr_volume(f1, f2))
     for i in range(4):
-        kc.check(lv[i].cpu(), pyr[i].reshape(B * n, -1), 3e-5, f"level {i}")
+        # bf16x3: 256 products of magnitude <= 2.9, 2^-17 relative each, /16
+        kc.check(lv[i].cpu(), pyr[i].reshape(B * n, -1), 3e-5 if prec == "fp32" else 2e-4, f"level {i}")
 
 
 def test_corr_pyramid_vs_reference_golden(lib, dev):
