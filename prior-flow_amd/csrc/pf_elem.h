@@ -237,31 +237,41 @@ struct PfLookupArgs {
     float* raw_out;                 // channel-last [B*N][ld]
     int B, H, W, ld;
 };
-PF_HD void pf_lookup_elem(long idx, const PfLookupArgs& a) {  // idx over B*N*324
+// One call = PF_LOOKUP_TPT consecutive taps (same level, same slow index a): their gather chains
+// (coords -> grid taps -> other-volume taps) are independent, so the loads of all three are in
+// flight together -- the kernel is bound by 3 dependent global round trips, not by bandwidth.
+#define PF_LOOKUP_TPT 3
+PF_HD void pf_lookup_elem(long idx, const PfLookupArgs& a) {  // idx over B*N*(324/3)
     const long N = (long)a.H * a.W;
-    const int k = (int)(idx % PF_CORR_CH);
-    const long row = idx / PF_CORR_CH;                 // b*N + n
+    const int per_row = PF_CORR_CH / PF_LOOKUP_TPT;
+    const int k0 = (int)(idx % per_row) * PF_LOOKUP_TPT;
+    const long row = idx / per_row;                    // b*N + n
     const long b = row / N, n = row % N;
-    const int lvl = k / PF_TAPS, tap = k % PF_TAPS;
-    const int ta = tap / 9, tb = tap % 9;              // slow axis a offsets x (core/corr.py:120-126)
+    const int lvl = k0 / PF_TAPS, tap0 = k0 % PF_TAPS;
+    const int ta = tap0 / 9, tb0 = tap0 % 9;           // slow axis a offsets x (core/corr.py:120-126)
     const int Hl = a.H >> lvl, Wl = a.W >> lvl;
     const float inv = 1.f / (float)(1 << lvl);         // coords / 2**i : exact
     const float cx = a.coords[(b * 2 + 0) * N + n] * inv + (float)(ta - PF_CORR_RADIUS);
-    const float cy = a.coords[(b * 2 + 1) * N + n] * inv + (float)(tb - PF_CORR_RADIUS);
+    const float cy0 = a.coords[(b * 2 + 1) * N + n] * inv;
     const long lsz = (long)Hl * Wl;
-    // own view: x wrapped mod W_i, zero padded
-    {
-        const PfTaps t = pf_taps0(pf_pymod(cx, (float)Wl), cy, Hl, Wl);
-        a.own_out[row * a.ld + k] = pf_apply(t, a.own[lvl] + row * lsz);
+    const float* own = a.own[lvl] + row * lsz;
+    const float* oth = a.other[lvl] + row * lsz;
+    // own view: x wrapped mod W_i, zero padded.  Cross view: level-i coordinates index the LEVEL-0
+    // grid (core/corr.py:132-133), and the result indexes row n of the OTHER branch's volume (:135-136)
+    const float xo = pf_pymod(cx, (float)Wl), xg = pf_pymod(cx, (float)a.W);
+    float gx[PF_LOOKUP_TPT], gy[PF_LOOKUP_TPT], vo[PF_LOOKUP_TPT];
+    for (int j = 0; j < PF_LOOKUP_TPT; ++j) {
+        const float cy = cy0 + (float)(tb0 + j - PF_CORR_RADIUS);
+        const PfTaps t = pf_taps0(xo, cy, Hl, Wl);
+        vo[j] = pf_apply(t, own);
+        const PfTaps tg = pf_taps0(xg, cy, a.H, a.W);
+        gx[j] = pf_apply(tg, a.g_w2c);
+        gy[j] = pf_apply(tg, a.g_w2c + N);
     }
-    // cross view: level-i coordinates index the LEVEL-0 grid (core/corr.py:132-133) ...
-    const PfTaps tg = pf_taps0(pf_pymod(cx, (float)a.W), cy, a.H, a.W);
-    const float gx = pf_apply(tg, a.g_w2c);
-    const float gy = pf_apply(tg, a.g_w2c + N);
-    // ... and the result indexes row n of the OTHER branch's volume (core/corr.py:135-136)
-    {
-        const PfTaps t = pf_taps0(pf_pymod(gx, (float)Wl), gy, Hl, Wl);
-        a.raw_out[row * a.ld + k] = pf_apply(t, a.other[lvl] + row * lsz);
+    for (int j = 0; j < PF_LOOKUP_TPT; ++j) {
+        const PfTaps t = pf_taps0(pf_pymod(gx[j], (float)Wl), gy[j], Hl, Wl);
+        a.own_out[row * a.ld + k0 + j] = vo[j];
+        a.raw_out[row * a.ld + k0 + j] = pf_apply(t, oth);
     }
 }
 

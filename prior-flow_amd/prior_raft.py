@@ -42,6 +42,8 @@ class PriOr_RAFT(nn.Module):
         self._enc_sig = None
         self.use_graph = os.environ.get("PRIORFLOW_GRAPH", "1") != "0"
         self.precision: Optional[int] = None      # None -> PRIORFLOW_PRECISION env (default bf16x3)
+        self.use_streams = os.environ.get("PRIORFLOW_STREAMS", "1") != "0"
+        self._side_streams = None
 
     # ---- reference API surface ----------------------------------------------------------------
     def freeze_bn(self):
@@ -118,8 +120,25 @@ class PriOr_RAFT(nn.Module):
             ws.img_c[:B].copy_(image1); ws.img_c[B:].copy_(image1_b)
             ws.img_f[:B].copy_(image1); ws.img_f[B:2 * B].copy_(image2)
             ws.img_f[2 * B:3 * B].copy_(image1_b); ws.img_f[3 * B:].copy_(image2_b)
-            cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
-            fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
+            if self.use_streams:
+                # cnet and fnet are independent: fork them onto two side streams (the fork/join
+                # is captured into the HIP graph as parallel branches) so that the latency-bound
+                # kernels of one (stem, statistics) hide behind the other's convolutions
+                cur = torch.cuda.current_stream()
+                if self._side_streams is None:
+                    self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+                s1, s2 = self._side_streams
+                s1.wait_stream(cur)
+                s2.wait_stream(cur)
+                with torch.cuda.stream(s1):
+                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+                with torch.cuda.stream(s2):
+                    fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
+                cur.wait_stream(s1)
+                cur.wait_stream(s2)
+            else:
+                cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+                fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
             return
         # exact-fp32 mode: the encoders stay on PyTorch-ROCm convolutions
         amp = bool(getattr(self.args, "mixed_precision", False))
