@@ -168,6 +168,13 @@ int pf_channel_stats(const float* y, int B, int Np, int C, float eps, float* sca
 int pf_norm_act(const float* y, const float* s, const float* t, const float* res,
                 const float* rs, const float* rt, float* out, int B, int Np, int C, void* stream);
 
+/* FlowHead.conv2 (3x3, C->2; core/update.py:10,13-14) fused with coords1 += delta_flow
+ * (core/prior_raft.py:193,196).  x: channel-last hidden features [B*N][ld] (C channels at column 0);
+ * weight packed [2][9][C] (exact fp32 dot products); coords1 planar, updated in place; delta
+ * (optional, may be NULL): channel-last [B*N][ld_delta] copy of delta_flow. */
+int pf_flow_head_out(const float* x, int ld, int C, const float* weight, const float* bias,
+                     float* coords1, float* delta, int ld_delta, int B, int H8, int W8, void* stream);
+
 /* coords1 += delta (core/prior_raft.py:193,196).  delta: channel-last, 2 channels at column 0. */
 int pf_coords_add(float* coords1, const float* delta, int ld, int B, int H8, int W8, void* stream);
 

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "pf_conv2d_small": [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_channel_stats": [_fp, _i, _i, _i, C.c_float, _fp, _fp, _fp, _i, _fp],
     "pf_norm_act": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pf_flow_head_out": [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_coords_add": [_fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
@@ -242,6 +243,13 @@ class PfLib:
         self._chk(y, s, t, out, res, rs, rt)
         self._rc(self._dll.pf_norm_act(_ptr(y), _ptr(s), _ptr(t), _ptr(res), _ptr(rs), _ptr(rt), _ptr(out),
                                        B, Np, Cc, self._stream(y)), "pf_norm_act")
+
+    def flow_head_out(self, x, Cch, weight, bias, coords1, delta=None):
+        self._chk(x, weight, bias, coords1, delta)
+        B, _, H, W = coords1.shape
+        self._rc(self._dll.pf_flow_head_out(_ptr(x), x.shape[-1], Cch, _ptr(weight), _ptr(bias), _ptr(coords1),
+                                            _ptr(delta), 0 if delta is None else delta.shape[-1], B, H, W,
+                                            self._stream(x)), "pf_flow_head_out")
 
     def coords_add(self, coords1, delta):
         self._chk(coords1, delta)

@@ -381,6 +381,38 @@ PF_HD void pf_direct_conv_elem(long idx, const PfDirectConvArgs& a) {  // idx ov
 }
 
 // ----------------------------------------------------------------------------------------------
+// FlowHead.conv2 (3x3, C->2, core/update.py:10,13-14) fused with the coordinate update
+// coords1 += delta_flow (core/prior_raft.py:193,196).  w packed [2][9][C]; x channel-last.
+// Scalar statement (host/emu); the device kernel spreads C over a wavefront.
+// ----------------------------------------------------------------------------------------------
+struct PfFlowOutArgs {
+    const float* x; int ld, C;
+    const float* w; const float* bias;
+    float* coords1;            // planar [B,2,N], updated in place
+    float* delta;              // optional channel-last [B*N][ld_delta] copy of delta_flow
+    int ld_delta;
+    int B, H, W;
+};
+PF_HD void pf_flow_out_elem(long idx, const PfFlowOutArgs& a) {   // idx over B*N*2
+    const long N = (long)a.H * a.W;
+    const int o = (int)(idx & 1);
+    const long row = idx >> 1;
+    const long b = row / N, n = row % N;
+    const int y = (int)(n / a.W), x = (int)(n % a.W);
+    float acc = 0.f;
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+        const float* xp = a.x + (b * N + (long)yy * a.W + xx) * a.ld;
+        const float* wp = a.w + ((long)o * 9 + t) * a.C;
+        for (int c = 0; c < a.C; ++c) acc = acc + xp[c] * wp[c];
+    }
+    acc = acc + a.bias[o];
+    if (a.delta) a.delta[row * a.ld_delta + o] = acc;
+    a.coords1[(b * 2 + o) * N + n] += acc;
+}
+
+// ----------------------------------------------------------------------------------------------
 // fp32 -> bf16 hi|lo split rows (operand format of the PF_PREC_BF16X3 GEMMs):
 // out row = [C/32 chunks] x { bf16 hi[32], bf16 lo[32] }, hi = bf16_rne(x), lo = bf16_rne(x - hi).
 // ----------------------------------------------------------------------------------------------

@@ -288,8 +288,53 @@ int launch_stats(const float* y, int B, int Np, int C, float eps, float* scale, 
     return (int)hipGetLastError();
 }
 
+// FlowHead.conv2 + coords update on a wavefront: one wave per pixel, 4 channels per lane per
+// 256-channel slab, both output channels at once, butterfly reduction over the 64 lanes.
+__global__ void __launch_bounds__(256) pf_flow_out_wave(const PfFlowOutArgs a, const long rows) {
+    const int lane = threadIdx.x & 63;
+    const long N = (long)a.H * a.W;
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 4;
+    for (; row < rows; row += stride) {
+        const long b = row / N, n = row % N;
+        const int y = (int)(n / a.W), x = (int)(n % a.W);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;        // wave-uniform
+            const float* xp = a.x + (b * N + (long)yy * a.W + xx) * a.ld;
+            for (int c = lane * 4; c < a.C; c += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(xp + c);
+                const float4 w0 = *reinterpret_cast<const float4*>(a.w + (long)t * a.C + c);
+                const float4 w1 = *reinterpret_cast<const float4*>(a.w + (long)(9 + t) * a.C + c);
+                s0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
+                s1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); }
+        if (lane < 2) {
+            const float acc = (lane == 0 ? s0 : s1) + a.bias[lane];
+            if (a.delta) a.delta[row * a.ld_delta + lane] = acc;
+            a.coords1[(b * 2 + lane) * N + n] += acc;
+        }
+    }
+}
+int launch_flow_out(const PfFlowOutArgs& a, long total, void* stream) {
+    if (a.C % 4 == 0 && a.ld % 4 == 0) {
+        const long rows = total / 2;
+        long blocks = (rows + 3) / 4;
+        if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+        hipLaunchKernelGGL(pf_flow_out_wave, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, rows);
+        return (int)hipGetLastError();
+    }
+    return pf_launch_elem<PfFlowOutArgs, pf_flow_out_elem>(a, total, stream);
+}
+
 }  // namespace
 
+#define PF_FLOW_OUT_LAUNCH(a, total, stream) launch_flow_out(a, total, stream)
 #define PF_STATS_LAUNCH launch_stats
 #define PF_LAUNCH(name, args, total, stream) \
     pf_launch_elem<decltype(args), pf_##name##_elem>(args, total, stream)

@@ -41,10 +41,11 @@ def rotation_x(theta: float) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------
 # weight packing (host-side plumbing; runs once per weight version)
 # ------------------------------------------------------------------------------------------
-def pack_mfma(w: torch.Tensor, b: torch.Tensor):
-    """[Cout,Cin,KH,KW] -> [Cout_pad128][KH*KW][Cin_pad32] (zero filled), bias [Cout_pad128]."""
+def pack_mfma(w: torch.Tensor, b: torch.Tensor, cin_to: int = 0):
+    """[Cout,Cin,KH,KW] -> [Cout_pad128][KH*KW][Cin_pad32] (zero filled), bias [Cout_pad128].
+    cin_to > Cin pads the input channels with zero weights (lets two convs share a launch geometry)."""
     cout, cin, kh, kw = w.shape
-    cp = (cin + 31) // 32 * 32
+    cp = (max(cin, cin_to) + 31) // 32 * 32
     op = (cout + 127) // 128 * 128
     wp = torch.zeros(op, kh * kw, cp, dtype=torch.float32, device=w.device)
     wp[:cout, :, :cin] = w.detach().float().permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
@@ -86,10 +87,10 @@ class Conv:
             self.w = split_bf16(w)
 
     @staticmethod
-    def of(mod, precision=PREC_F32) -> "Conv":
-        w, b = pack_mfma(mod.weight, mod.bias)
-        return Conv(w, b, mod.weight.shape[2], mod.weight.shape[3], mod.weight.shape[1], mod.weight.shape[0],
-                    precision)
+    def of(mod, precision=PREC_F32, cin_to: int = 0) -> "Conv":
+        w, b = pack_mfma(mod.weight, mod.bias, cin_to)
+        return Conv(w, b, mod.weight.shape[2], mod.weight.shape[3], max(mod.weight.shape[1], cin_to),
+                    mod.weight.shape[0], precision)
 
     @staticmethod
     def fused(mod_z, mod_r, precision=PREC_F32) -> "Conv":
@@ -141,7 +142,9 @@ def pack_update_blocks(oddc, upd, precision: Optional[int] = None) -> Dict[str, 
         "a.cf1": DirectConv(ea.conv_conf1), "a.cf2": DirectConv(ea.conv_conf2),
         "a.out": C(ea.conv_A),
         "b.c1": C(eb.convc1), "b.c2": C(eb.convc2),
-        "b.f1": DirectConv(eb.convf1), "b.f2": C(eb.convf2), "b.out": C(eb.conv),
+        # branch B's conv sees its 256-channel concat zero-padded to 272 so that it shares the
+        # launch geometry (K = 9 x 272) of branch A's conv_A: one grid instead of two half-empty ones
+        "b.f1": DirectConv(eb.convf1), "b.f2": C(eb.convf2), "b.out": Conv.of(eb.conv, pr, cin_to=272),
     }
     for tag, blk in (("a", oddc), ("b", upd)):
         g = blk.gru
@@ -151,6 +154,9 @@ def pack_update_blocks(oddc, upd, precision: Optional[int] = None) -> Dict[str, 
         P[f"{tag}.q2"] = C(g.convq2)
         P[f"{tag}.fh1"] = C(blk.flow_head.conv1)
         P[f"{tag}.fh2"] = C(blk.flow_head.conv2)
+        w2 = blk.flow_head.conv2.weight.detach().float()          # [2,256,3,3] -> [2][9][256]
+        P[f"{tag}.fh2w"] = w2.permute(0, 2, 3, 1).reshape(2, 9, w2.shape[1]).contiguous()
+        P[f"{tag}.fh2b"] = blk.flow_head.conv2.bias.detach().float().contiguous()
         P[f"{tag}.m0"] = C(blk.mask[0])
         P[f"{tag}.m2"] = C(blk.mask[2])
     return P
@@ -210,7 +216,7 @@ class Workspace:
         self.own, self.raw = z(rows, CORR_CH), z(rows, CORR_CH)
         self.corr_a, self.corr_b = z(rows, CORR_CH), z(rows, CORR_CH)
         self.c1_a, self.c1_b = z(rows, 256), z(rows, 256)
-        self.cat_a, self.cat_b = z(rows, 272), z(rows, 256)
+        self.cat_a, self.cat_b = z(rows, 272), z(rows, 272)     # cat_b columns 256..271 stay zero
         self.flow4_a = z(rows, 4)          # [flow_A | flow_B_A]
         self.flow2_b = z(rows, 2)
         self.t_a, self.t_ba, self.t_b = z(rows, 128), z(rows, 128), z(rows, 128)
@@ -288,11 +294,7 @@ class Engine:
         (two GRU half-steps ping-pong).  need_b=False skips branch B's update (its result is
         dead in the last test_mode iteration); mask_x selects the mask heads."""
         self.prep_and_lookup(ws, need_b)
-        cur = self.update_blocks(ws, P, cur, need_b, mask_a, mask_b)
-        self.lib.coords_add(ws.c1a, ws.delta_a)           # coords1 += delta_flow (:193,196)
-        if need_b:
-            self.lib.coords_add(ws.c1b, ws.delta_b)
-        return cur
+        return self.update_blocks(ws, P, cur, need_b, mask_a, mask_b)   # includes coords1 += delta_flow
 
     def prep_and_lookup(self, ws: Workspace, need_b: bool):
         """flows, flo_rotate, feature warps and the DCCL lookups of one iteration (:171-188)."""
@@ -315,8 +317,8 @@ class Engine:
     def update_blocks(self, ws: Workspace, P: Dict[str, object], cur: int, need_b: bool, mask_a: bool,
                       mask_b: bool) -> int:
         """ODDC (branch A) and update_block (branch B) (core/update.py:152-159, :129-136).
-        Inputs: corr_x, flow4_a / flow2_b, conf_in, x_x (inp + flow tail), net_x[cur].
-        Outputs: net_x[cur], delta_x, mask_x."""
+        Inputs: corr_x, flow4_a / flow2_b, conf_in, x_x (inp + flow tail), net_x[cur], c1x.
+        Outputs: net_x[cur], delta_x, mask_x, and c1x += delta_x (core/prior_raft.py:193,196)."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
         like = ws.x_a
 
@@ -347,9 +349,10 @@ class Engine:
         conv(d)
         direct(P["a.cf1"], ws.conf_in, 0, ws.conf_mid, 0)
         direct(P["a.cf2"], ws.conf_mid, 0, ws.cat_a, 256)
-        conv([P["a.out"].desc(ws.cat_a, 0, 272, ws.x_a, 128, EPI_RELU)])
+        d = [P["a.out"].desc(ws.cat_a, 0, 272, ws.x_a, 128, EPI_RELU)]
         if need_b:
-            conv([P["b.out"].desc(ws.cat_b, 0, 256, ws.x_b, 128, EPI_RELU)])
+            d.append(P["b.out"].desc(ws.cat_b, 0, 272, ws.x_b, 128, EPI_RELU))
+        conv(d)
 
         # SepConvGRU (core/update.py:46-60): z|r fused GEMM with sigmoid + r*h epilogue, then q
         # with the tanh + blend epilogue; horizontal (1x5) then vertical (5x1)
@@ -374,10 +377,10 @@ class Engine:
         if mask_b and need_b:
             d.append(P["b.m0"].desc(ws.net_b[c], 0, 128, ws.mh_b, 0, EPI_RELU))
         conv(d)
-        d = [P["a.fh2"].desc(ws.fh_a, 0, 256, ws.delta_a, 0, EPI_LINEAR)]
+        # FlowHead.conv2 (256 -> 2) + coords1 += delta_flow in one wave-per-pixel kernel
+        lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
         if need_b:
-            d.append(P["b.fh2"].desc(ws.fh_b, 0, 256, ws.delta_b, 0, EPI_LINEAR))
-        conv(d)
+            lib.flow_head_out(ws.fh_b, 256, P["b.fh2w"], P["b.fh2b"], ws.c1b, ws.delta_b)
         d = []
         if mask_a:
             d.append(P["a.m2"].desc(ws.mh_a, 0, 256, ws.mask_a, 0, EPI_LINEAR, scale=0.25))

@@ -41,6 +41,7 @@ static int emu_stats(const float* y, int B, int Np, int C, float eps, float* sca
     return PF_OK;
 }
 #define PF_STATS_LAUNCH emu_stats
+#define PF_FLOW_OUT_LAUNCH(a, total, stream) pf_loop<PfFlowOutArgs, pf_flow_out_elem>(a, total)
 
 #include "pf_api_elem.inc"
 

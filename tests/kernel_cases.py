@@ -275,6 +275,26 @@ def case_small_conv_stem(lib, dev):
     check(uncl(out.cpu(), 1, 8, 32), want, 3e-5, "3x3/2 channel-last")
 
 
+def case_flow_head_out(lib, dev):
+    """FlowHead.conv2 (3x3, 256->2) fused with coords1 += delta_flow (core/update.py:13-14, prior_raft.py:193)."""
+    x = gc.uni("fho/x", (2, 256, H8, W8), -1, 1)
+    w = gc.uni("fho/w", (2, 256, 3, 3), -0.05, 0.05)
+    b = gc.uni("fho/b", (2,), -0.1, 0.1)
+    co = gc.nasty_coords("fho", B=2)
+    want = torch.nn.functional.conv2d(x, w, b, padding=1)
+    c1 = co.clone().to(dev)
+    delta = torch.full((2 * N, 4), 9.0, device=dev)
+    lib.flow_head_out(cl(x).to(dev), 256, w.permute(0, 2, 3, 1).reshape(2, 9, 256).contiguous().to(dev),
+                      b.to(dev), c1, delta)
+    check(uncl(delta[:, :2].cpu(), 2, H8, W8), want, 2e-5, "delta_flow")
+    assert float((delta[:, 2:] - 9.0).abs().max()) == 0.0
+    check(c1, co + uncl(delta[:, :2].cpu(), 2, H8, W8), 0.0, "coords1 += delta_flow")
+    c2 = co.clone().to(dev)
+    lib.flow_head_out(cl(x).to(dev), 256, w.permute(0, 2, 3, 1).reshape(2, 9, 256).contiguous().to(dev),
+                      b.to(dev), c2, None)
+    check(c2, c1, 0.0, "delta buffer is optional")
+
+
 def case_split_bf16(lib, dev):
     """fp32 -> bf16 hi|lo rows: hi = bf16(x) (RNE), lo = bf16(x - hi); hi + lo keeps 16 mantissa bits."""
     x = gc.uni("split/x", (37, 96), -50, 50)
@@ -316,4 +336,5 @@ def case_bad_args(lib, dev):
 
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_upsample, case_coords_add, case_layout,
-                     case_channel_stats_and_norm_act, case_small_conv_stem, case_split_bf16, case_bad_args]
+                     case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
+                     case_bad_args]

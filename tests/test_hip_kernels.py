@@ -233,6 +233,9 @@ def test_update_blocks_vs_reference_golden(lib, dev, params, prec):
     kc.check(back(ws.net_b[cur]), gb["net"], tol, "net B")
     kc.check(back(ws.delta_a[:, :2]), ga["delta"], tol, "delta A")
     kc.check(back(ws.delta_b[:, :2]), gb["delta"], tol, "delta B")
+    # coords1 (zero here) += delta_flow is fused into the flow-head kernel
+    kc.check(ws.c1a, back(ws.delta_a[:, :2]), 0.0, "coords1_A += delta")
+    kc.check(ws.c1b, back(ws.delta_b[:, :2]), 0.0, "coords1_B += delta")
     kc.check(back(ws.mask_a)[:, 3::8], ga["mask"], tol, "mask A")
     kc.check(back(ws.mask_b)[:, 3::8], gb["mask"], tol, "mask B")
 
