@@ -235,8 +235,13 @@ class Workspace:
 
 
 class Engine:
-    def __init__(self, lib: PfLib):
+    def __init__(self, lib: PfLib, side_streams=None):
+        """side_streams: optional (s1, s2) torch streams.  When given, the three independent chains of
+        an iteration -- correlation (lookups, 1x1, 3x3), flow (prep, flo_rotate, 7x7, 3x3) and
+        confidence (warps, 3x3, 3x3) -- run concurrently and join before conv_A (inside a HIP-graph
+        capture they become parallel branches)."""
         self.lib = lib
+        self.side = side_streams
 
     # ---- stage 0: view B images --------------------------------------------------------------
     def rotate_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
@@ -293,52 +298,25 @@ class Engine:
         """Runs one iteration; hidden states are read from net_x[cur] and end in net_x[cur]
         (two GRU half-steps ping-pong).  need_b=False skips branch B's update (its result is
         dead in the last test_mode iteration); mask_x selects the mask heads."""
-        self.prep_and_lookup(ws, need_b)
-        return self.update_blocks(ws, P, cur, need_b, mask_a, mask_b)   # includes coords1 += delta_flow
+        self.motion_inputs(ws, P, need_b)
+        return self.update_blocks(ws, P, cur, need_b, mask_a, mask_b, inputs_ready=True)   # incl. coords1 += delta
 
-    def prep_and_lookup(self, ws: Workspace, need_b: bool):
-        """flows, flo_rotate, feature warps and the DCCL lookups of one iteration (:171-188)."""
-        lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
-        # flows (K6), warps (K5)
+    # -- the three independent chains of an iteration ---------------------------------------------
+    def _flow_chain_head(self, ws: Workspace):
+        """flows + flo_rotate (:171-179): produces flow4_a, flow2_b, flow_ba and the flow tails of x."""
+        lib = self.lib
         lib.flow_prep(ws.c1a, None, ws.flow4_a, 0, ws.x_a, 252)
         lib.flow_prep(ws.c1b, ws.flow_b, ws.flow2_b, 0, ws.x_b, 254)
         # flo_rotate(flow_B, W2C = grid(R_B2A^T) == grid(R_A2B), C2W = grid(R_B2A))  (:179)
         lib.flo_rotate(ws.flow_b, ws.g_a2b_8, ws.g_b2a_8, ws.flow_ba, ws.flow4_a, 2, ws.x_a, 254)
-        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.c1a, False, ws.conf_in, 0)
-        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.flow_ba, True, ws.conf_in, 4)
-        # DCCL lookups (K3+K4): A looks into B through grid(R_A2B^T)==grid(R_B2A), rotates back
-        # with grid(R_B2A) (:185); B the other way round (:186)
-        lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
-        lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
-        if need_b:
-            lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own, ws.raw)
-            lib.dccl_combine(ws.own, ws.raw, ws.g_a2b_8, ws.corr_b, B, H8, W8)
 
-    def update_blocks(self, ws: Workspace, P: Dict[str, object], cur: int, need_b: bool, mask_a: bool,
-                      mask_b: bool) -> int:
-        """ODDC (branch A) and update_block (branch B) (core/update.py:152-159, :129-136).
-        Inputs: corr_x, flow4_a / flow2_b, conf_in, x_x (inp + flow tail), net_x[cur], c1x.
-        Outputs: net_x[cur], delta_x, mask_x, and c1x += delta_x (core/prior_raft.py:193,196)."""
+    def _flow_chain_tail(self, ws: Workspace, P, need_b: bool):
+        """7x7 flow stems + 3x3 (core/update.py:187-191, :94-95) -> cat_a[128:256], cat_b[192:256]."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
-        like = ws.x_a
 
-        def conv(descs):
-            lib.conv2d(descs, B, H8, W8, like)
+        def direct(dc: DirectConv, x, off_in, out, off_out):
+            lib.conv2d_direct(x, off_in, dc.cin, dc.w, dc.b, out, off_out, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
 
-        def direct(dc: DirectConv, x, off_in, out, off_out, relu=True):
-            lib.conv2d_direct(x, off_in, dc.cin, dc.w, dc.b, out, off_out, dc.cout, dc.kh, dc.kw, relu,
-                              B, H8, W8)
-
-        # motion encoders (core/update.py:183-201, :91-99); A and B side by side where the
-        # GEMM geometry matches
-        d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
-        if need_b:
-            d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, ws.c1_b, 0, EPI_RELU))
-        conv(d)
-        d = [P["a.c2"].desc(ws.c1_a, 0, 256, ws.cat_a, 0, EPI_RELU)]
-        if need_b:
-            d.append(P["b.c2"].desc(ws.c1_b, 0, 256, ws.cat_b, 0, EPI_RELU))
-        conv(d)
         direct(P["a.f1a"], ws.flow4_a, 0, ws.t_a, 0)
         direct(P["a.f1b"], ws.flow4_a, 2, ws.t_ba, 0)
         d = [P["a.f2a"].desc(ws.t_a, 0, 128, ws.cat_a, 128, EPI_RELU),
@@ -346,9 +324,95 @@ class Engine:
         if need_b:
             direct(P["b.f1"], ws.flow2_b, 0, ws.t_b, 0)
             d.append(P["b.f2"].desc(ws.t_b, 0, 128, ws.cat_b, 192, EPI_RELU))
-        conv(d)
-        direct(P["a.cf1"], ws.conf_in, 0, ws.conf_mid, 0)
-        direct(P["a.cf2"], ws.conf_mid, 0, ws.cat_a, 256)
+        lib.conv2d(d, B, H8, W8, ws.x_a)
+
+    def _conf_chain(self, ws: Workspace, P):
+        """feature warps + groupwise corr + confidence stem (:173-182, core/update.py:193-194) -> cat_a[256:272]."""
+        lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
+        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.c1a, False, ws.conf_in, 0)
+        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.flow_ba, True, ws.conf_in, 4)
+        for dc, x, out, off in ((P["a.cf1"], ws.conf_in, ws.conf_mid, 0), (P["a.cf2"], ws.conf_mid, ws.cat_a, 256)):
+            lib.conv2d_direct(x, 0, dc.cin, dc.w, dc.b, out, off, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
+
+    def _corr_chain(self, ws: Workspace, P, need_b: bool):
+        """DCCL lookups (K3+K4; :185-188) + 1x1 + 3x3 of the motion encoders -> cat_a[0:128], cat_b[0:192].
+        A looks into B through grid(R_A2B^T)==grid(R_B2A) and rotates back with grid(R_B2A); B the other way."""
+        lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
+        lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+        lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+        if need_b:
+            lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own, ws.raw)
+            lib.dccl_combine(ws.own, ws.raw, ws.g_a2b_8, ws.corr_b, B, H8, W8)
+        d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
+        if need_b:
+            d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, ws.c1_b, 0, EPI_RELU))
+        lib.conv2d(d, B, H8, W8, ws.x_a)
+        d = [P["a.c2"].desc(ws.c1_a, 0, 256, ws.cat_a, 0, EPI_RELU)]
+        if need_b:
+            d.append(P["b.c2"].desc(ws.c1_b, 0, 256, ws.cat_b, 0, EPI_RELU))
+        lib.conv2d(d, B, H8, W8, ws.x_a)
+
+    def prep_and_lookup(self, ws: Workspace, need_b: bool):
+        """flows, flo_rotate and the DCCL lookups of one iteration, single stream (tests)."""
+        lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
+        self._flow_chain_head(ws)
+        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.c1a, False, ws.conf_in, 0)
+        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.flow_ba, True, ws.conf_in, 4)
+        lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+        lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+        if need_b:
+            lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own, ws.raw)
+            lib.dccl_combine(ws.own, ws.raw, ws.g_a2b_8, ws.corr_b, B, H8, W8)
+
+    def motion_inputs(self, ws: Workspace, P, need_b: bool):
+        """Everything of an iteration up to (excluding) conv_A / conv: fills cat_a, cat_b and the flow
+        tails of x_a, x_b from coords1 and the pyramids.  Three concurrent chains when side streams exist."""
+        if self.side is None:
+            self._flow_chain_head(ws)
+            self._corr_chain(ws, P, need_b)
+            self._flow_chain_tail(ws, P, need_b)
+            self._conf_chain(ws, P)
+            return
+        main = torch.cuda.current_stream()
+        s1, s2 = self.side
+        s1.wait_stream(main)
+        with torch.cuda.stream(s1):
+            self._flow_chain_head(ws)
+            head_done = torch.cuda.Event()
+            head_done.record(s1)
+            self._flow_chain_tail(ws, P, need_b)
+        s2.wait_event(head_done)            # warp #2 needs flow_ba
+        with torch.cuda.stream(s2):
+            self._conf_chain(ws, P)
+        self._corr_chain(ws, P, need_b)
+        main.wait_stream(s1)
+        main.wait_stream(s2)
+
+    def update_blocks(self, ws: Workspace, P: Dict[str, object], cur: int, need_b: bool, mask_a: bool,
+                      mask_b: bool, inputs_ready: bool = False) -> int:
+        """ODDC (branch A) and update_block (branch B) (core/update.py:152-159, :129-136).
+        Inputs: corr_x, flow4_a / flow2_b, conf_in, x_x (inp + flow tail), net_x[cur], c1x.
+        Outputs: net_x[cur], delta_x, mask_x, and c1x += delta_x (core/prior_raft.py:193,196).
+        inputs_ready: cat_a / cat_b were already filled by motion_inputs()."""
+        lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
+        like = ws.x_a
+
+        def conv(descs):
+            lib.conv2d(descs, B, H8, W8, like)
+
+        if not inputs_ready:
+            # motion encoders (core/update.py:183-201, :91-99) from corr_x / flows / conf_in
+            d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
+            if need_b:
+                d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, ws.c1_b, 0, EPI_RELU))
+            conv(d)
+            d = [P["a.c2"].desc(ws.c1_a, 0, 256, ws.cat_a, 0, EPI_RELU)]
+            if need_b:
+                d.append(P["b.c2"].desc(ws.c1_b, 0, 256, ws.cat_b, 0, EPI_RELU))
+            conv(d)
+            self._flow_chain_tail(ws, P, need_b)
+            for dc, x, out, off in ((P["a.cf1"], ws.conf_in, ws.conf_mid, 0), (P["a.cf2"], ws.conf_mid, ws.cat_a, 256)):
+                lib.conv2d_direct(x, 0, dc.cin, dc.w, dc.b, out, off, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
         d = [P["a.out"].desc(ws.cat_a, 0, 272, ws.x_a, 128, EPI_RELU)]
         if need_b:
             d.append(P["b.out"].desc(ws.cat_b, 0, 272, ws.x_b, 128, EPI_RELU))

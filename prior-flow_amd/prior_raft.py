@@ -125,9 +125,7 @@ class PriOr_RAFT(nn.Module):
                 # is captured into the HIP graph as parallel branches) so that the latency-bound
                 # kernels of one (stem, statistics) hide behind the other's convolutions
                 cur = torch.cuda.current_stream()
-                if self._side_streams is None:
-                    self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
-                s1, s2 = self._side_streams
+                s1, s2 = self._streams()
                 s1.wait_stream(cur)
                 s2.wait_stream(cur)
                 with torch.cuda.stream(s1):
@@ -147,8 +145,13 @@ class PriOr_RAFT(nn.Module):
             fmaps = self.fnet(torch.cat([image1, image2, image1_b, image2_b], 0))
         eng.load_features(ws, fmaps.float(), cnet.float())
 
+    def _streams(self):
+        if self._side_streams is None:
+            self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        return self._side_streams
+
     def _run(self, ws: Workspace, image1, image2, iters, init_flow, test_mode, out_a, out_b):
-        eng = Engine(self._lib())
+        eng = Engine(self._lib(), self._streams() if self.use_streams else None)
         P = self._weights()
         self._encode(image1, image2, ws, eng)
         eng.build_pyramids(ws, P["precision"])
