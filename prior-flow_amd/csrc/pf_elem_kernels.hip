@@ -235,24 +235,34 @@ int launch_small_conv(const PfSmallConvArgs& a, void* stream) {
 // nblk partial sums per image, then a fixed-order final reduction.
 __global__ void __launch_bounds__(256) pf_stats_partial(const float* __restrict__ y, double* __restrict__ part,
                                                          int Np, int C, int nblk) {
-    __shared__ double sh[2][256];
+    // thread = (pixel group, channel quad): 16-byte loads, 256/(C/4) pixels in flight per block
+    __shared__ double sh[8][256];
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
-    const int g = 256 / C;
-    const int c = tid % C, grp = tid / C;
+    const int cq = C / 4;                      // channel quads (C % 4 == 0)
+    const int g = 256 / cq;
+    const int q = tid % cq, grp = tid / cq;
     const int chunk = (Np + nblk - 1) / nblk;
     const int p0 = blk * chunk, p1 = (p0 + chunk < Np) ? p0 + chunk : Np;
-    double s = 0.0, ss = 0.0;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     if (grp < g)
         for (int p = p0 + grp; p < p1; p += g) {
-            const double v = (double)y[((long)b * Np + p) * C + c];
-            s += v; ss += v * v;
+            const float4 v = *reinterpret_cast<const float4*>(y + ((long)b * Np + p) * C + 4 * q);
+            const double v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
+            s[0] += v0; ss[0] += v0 * v0; s[1] += v1; ss[1] += v1 * v1;
+            s[2] += v2; ss[2] += v2 * v2; s[3] += v3; ss[3] += v3 * v3;
         }
-    sh[0][tid] = s; sh[1][tid] = ss;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sh[i][tid] = s[i]; sh[4 + i][tid] = ss[i]; }
     __syncthreads();
-    if (tid < C) {
-        for (int k = 1; k < g; ++k) { s += sh[0][tid + k * C]; ss += sh[1][tid + k * C]; }
-        double* o = part + (((long)b * nblk + blk) * C + c) * 2;
-        o[0] = s; o[1] = ss;
+    if (tid < cq) {                            // fixed-order sum over the pixel groups
+        for (int k = 1; k < g; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s[i] += sh[i][tid + k * cq]; ss[i] += sh[4 + i][tid + k * cq]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double* o = part + (((long)b * nblk + blk) * C + 4 * tid + i) * 2;
+            o[0] = s[i]; o[1] = ss[i];
+        }
     }
 }
 __global__ void __launch_bounds__(256) pf_stats_final(const double* __restrict__ part, float* __restrict__ scale,
@@ -285,6 +295,42 @@ int launch_stats(const float* y, int B, int Np, int C, float eps, float* scale, 
                  int nblk, void* stream) {
     hipLaunchKernelGGL(pf_stats_partial, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, y, part, Np, C, nblk);
     hipLaunchKernelGGL(pf_stats_final, dim3(B), dim3(256), 0, (hipStream_t)stream, part, scale, shift, C, nblk, Np, eps);
+    return (int)hipGetLastError();
+}
+
+// ResidualBlock tail, 16-byte accesses (same arithmetic as pf_norm_act_elem)
+__global__ void __launch_bounds__(256) pf_norm_act_vec(const PfNormActArgs a, const long total) {
+    const int c4n = a.C / 4;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; idx < total; idx += stride) {
+        const int c = (int)(idx % c4n) * 4;
+        const long row = idx / c4n;
+        const long b = row / a.Np;
+        const long e = row * a.C + c, pc = b * a.C + c;
+        const float4 y = *reinterpret_cast<const float4*>(a.y + e);
+        const float4 s = *reinterpret_cast<const float4*>(a.s + pc);
+        const float4 t = *reinterpret_cast<const float4*>(a.t + pc);
+        float4 v;
+        v.x = fmaxf(y.x * s.x + t.x, 0.f); v.y = fmaxf(y.y * s.y + t.y, 0.f);
+        v.z = fmaxf(y.z * s.z + t.z, 0.f); v.w = fmaxf(y.w * s.w + t.w, 0.f);
+        if (a.res) {
+            float4 r = *reinterpret_cast<const float4*>(a.res + e);
+            if (a.rs) {
+                const float4 rs = *reinterpret_cast<const float4*>(a.rs + pc);
+                const float4 rt = *reinterpret_cast<const float4*>(a.rt + pc);
+                r.x = r.x * rs.x + rt.x; r.y = r.y * rs.y + rt.y; r.z = r.z * rs.z + rt.z; r.w = r.w * rs.w + rt.w;
+            }
+            v.x = fmaxf(r.x + v.x, 0.f); v.y = fmaxf(r.y + v.y, 0.f);
+            v.z = fmaxf(r.z + v.z, 0.f); v.w = fmaxf(r.w + v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(a.out + e) = v;
+    }
+}
+int launch_norm_act(const PfNormActArgs& a, long total, void* stream) {
+    long blocks = (total + 255) / 256;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(pf_norm_act_vec, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, total);
     return (int)hipGetLastError();
 }
 
@@ -335,6 +381,7 @@ int launch_flow_out(const PfFlowOutArgs& a, long total, void* stream) {
 }  // namespace
 
 #define PF_FLOW_OUT_LAUNCH(a, total, stream) launch_flow_out(a, total, stream)
+#define PF_NORM_ACT_LAUNCH(a, total, stream) launch_norm_act(a, total, stream)
 #define PF_STATS_LAUNCH launch_stats
 #define PF_LAUNCH(name, args, total, stream) \
     pf_launch_elem<decltype(args), pf_##name##_elem>(args, total, stream)
