@@ -47,27 +47,78 @@ struct ConvGroups { pf_conv_desc d[MAX_GROUPS]; };
 
 struct ConvGeom { int M, H, W, N; int taps, nchunks, cin_pad, kh, kw; int stride, Hin, Win, Nin; };
 
-// Fused epilogue of one output element (pixel row p, output channel j), v = acc + bias.
-__device__ __forceinline__ void conv_epilogue(const pf_conv_desc& d, long p, int j, float v) {
-    if (d.epilogue == PF_EPI_LINEAR) {
-        d.out[p * d.ld_out + d.off_out + j] = v * d.scale;
-    } else if (d.epilogue == PF_EPI_RELU) {
-        d.out[p * d.ld_out + d.off_out + j] = fmaxf(v, 0.f);
-    } else if (d.epilogue == PF_EPI_GRU_ZR) {
-        const float s = 1.f / (1.f + expf(-v));
-        if (j < 128) {
-            d.out[p * d.ld_out + d.off_out + j] = s;                                  // z
-        } else {
-            d.aux_out[p * d.ld_aux + (j - 128)] = s * d.h[p * d.ld_h + (j - 128)];    // r*h
+// Fused epilogue of a wave's NT 32x32 accumulators.  acc[t][r] is output channel jb + 32 t + li
+// of pixel p0 + (r&3) + 8 (r>>2)  (p0 already holds the lane's +4*(lane>>5) row offset).
+// The first version ran a generic per-element routine (epilogue kind re-tested, 64-bit address
+// products and, for the GRU kinds, a dependent load -> compute -> store chain per element because
+// output and state pointers may alias): 8 360 instructions and 9-15 us of a 65-70 us launch.
+// Here the kind is tested once per tile, a lane keeps one base pointer per array and adds
+// row * ld offsets, the channel-half decisions of the split epilogues are wave-uniform (jb is
+// scalar), and the GRU operands of a tile are gathered before anything is stored.
+template <int NT, bool CHECK>
+__device__ __forceinline__ void tile_epilogue(const pf_conv_desc& d, const f32x16 (&acc)[NT], int jb, int li,
+                                              long p0, long plimit) {
+    const int epi = d.epilogue;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int jt = jb + 32 * t;                 // wave-uniform
+        const int j = jt + li;
+        if (j >= d.cout) continue;
+        const float bias = d.bias[j];
+        auto roff = [](int r) { return (r & 3) + 8 * (r >> 2); };
+        auto live = [&](int r) { return !CHECK || p0 + roff(r) < plimit; };
+        if (epi == PF_EPI_LINEAR) {
+            float* o = d.out + d.off_out + p0 * d.ld_out + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (live(r)) o[roff(r) * d.ld_out] = (acc[t][r] + bias) * d.scale;
+        } else if (epi == PF_EPI_RELU) {
+            float* o = d.out + d.off_out + p0 * d.ld_out + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (live(r)) o[roff(r) * d.ld_out] = fmaxf(acc[t][r] + bias, 0.f);
+        } else if (epi == PF_EPI_GRU_ZR) {
+            if (jt < 128) {                                                       // z
+                float* o = d.out + d.off_out + p0 * d.ld_out + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (live(r)) o[roff(r) * d.ld_out] = 1.f / (1.f + expf(-(acc[t][r] + bias)));
+            } else {                                                              // r * h
+                const float* hp = d.h + p0 * d.ld_h + (j - 128);
+                float* o = d.aux_out + p0 * d.ld_aux + (j - 128);
+                float hv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hv[r] = live(r) ? hp[roff(r) * d.ld_h] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (live(r)) o[roff(r) * d.ld_aux] = (1.f / (1.f + expf(-(acc[t][r] + bias)))) * hv[r];
+            }
+        } else if (epi == PF_EPI_TANH_RELU) {
+            if (jt < 128) {                                                       // net
+                float* o = d.out + d.off_out + p0 * d.ld_out + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (live(r)) o[roff(r) * d.ld_out] = tanhf(acc[t][r] + bias);
+            } else {                                                              // inp
+                float* o = d.aux_out + p0 * d.ld_aux + (j - 128);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (live(r)) o[roff(r) * d.ld_aux] = fmaxf(acc[t][r] + bias, 0.f);
+            }
+        } else {   // PF_EPI_GRU_Q:  h' = (1 - z) h + z tanh(v)
+            const float* zp = d.z + p0 * d.ld_z + j;
+            const float* hp = d.h + p0 * d.ld_h + j;
+            float* o = d.out + d.off_out + p0 * d.ld_out + j;
+            float zv[16], hv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                zv[r] = live(r) ? zp[roff(r) * d.ld_z] : 0.f;
+                hv[r] = live(r) ? hp[roff(r) * d.ld_h] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (live(r)) o[roff(r) * d.ld_out] = (1.f - zv[r]) * hv[r] + zv[r] * tanhf(acc[t][r] + bias);
         }
-    } else if (d.epilogue == PF_EPI_TANH_RELU) {
-        if (j < 128) d.out[p * d.ld_out + d.off_out + j] = tanhf(v);             // net
-        else d.aux_out[p * d.ld_aux + (j - 128)] = fmaxf(v, 0.f);                // inp
-    } else {   // PF_EPI_GRU_Q
-        const float q = tanhf(v);
-        const float z = d.z[p * d.ld_z + j];
-        const float hh = d.h[p * d.ld_h + j];
-        d.out[p * d.ld_out + d.off_out + j] = (1.f - z) * hh + z * q;
     }
 }
 
@@ -92,7 +143,7 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
     else if (blockIdx.z == 2) d = groups.d[2];
     else if (blockIdx.z == 3) d = groups.d[3];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar wave id
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
@@ -253,17 +304,7 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
     }
 
     // ---- epilogue: acc[t][r] = D[row (r&3)+8(r>>2)+4h][col lane&31] ---------------------------
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int j = n0 + 32 * NT * wn + 32 * t + li;
-        const bool jok = j < d.cout;
-        const float bias = jok ? d.bias[j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long p = (long)m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (jok && p < g.M) conv_epilogue(d, p, j, acc[t][r] + bias);
-        }
-    }
+    tile_epilogue<NT, true>(d, acc, n0 + 32 * NT * wn, li, (long)m0 + 32 * wm + 4 * lh, g.M);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -312,7 +353,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     if (n0 >= d.cout) return;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar wave id
     const int li = lane & 31, lh = lane >> 5;
     const int wy = wave >> 1, wn = wave & 1;
     const int tiles_x = g.W / TW, tiles_y = g.H / TH;
@@ -337,69 +378,90 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     const int nchunks = g.nchunks;
     const int nsteps = nchunks * TAPS;
     f32x4 ra[A_V4];
+    unsigned a_loff[A_V4];
+#pragma unroll
+    for (int q = 0; q < A_V4; ++q) a_loff[q] = (unsigned)((((tid + 512 * q) >> 3) * LDS_LD) * 4 + 2 * c4);
     f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};   // input affine of this thread's 4 channels
     const long aff_row = (long)(tile / (tiles_x * tiles_y)) * ctot;     // [image][channel]
     unsigned a_ok = 0;
-    auto load_A = [&](int chunk) __attribute__((always_inline)) {
-        if (chunk >= nchunks) chunk = nchunks - 1;       // tail: harmless re-read, stored to the idle buffer
-        const int c = chunk * KC + c4;
+    // The halo loader/converter works in A_V4 independent slices (q) so that a K-step can spread
+    // them between its MFMAs (see `step`).
+    auto load_A_affine = [&](int chunk) __attribute__((always_inline)) {
         if constexpr (AFFINE) {     // compile-time: a runtime-conditional load would break the counted waits
+            if (chunk >= nchunks) chunk = nchunks - 1;
+            const int c = chunk * KC + c4;
             const int ca = c < ctot ? c : 0;
             a_sc = *reinterpret_cast<const f32x4*>(d.in_scale + aff_row + ca);
             a_sh = *reinterpret_cast<const f32x4*>(d.in_shift + aff_row + ca);
         }
+    };
+    auto load_A_q = [&](int chunk, auto Q) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value;
+        if (chunk >= nchunks) chunk = nchunks - 1;       // tail: harmless re-read, stored to the idle buffer
+        const int c = chunk * KC + c4;
         const float* src; int ld, cc;
         if (c < d.c0) { src = d.in0 + d.off0; ld = d.ld0; cc = c; }
         else          { src = d.in1 + d.off1; ld = d.ld1; cc = c - d.c0; }
-        const bool cok = c < ctot;
-        unsigned okbits = 0;
-#pragma unroll
-        for (int q = 0; q < A_V4; ++q) {
-            const bool ok = cok && a_pix[q] >= 0;
-            const float* ptr = ok ? src + a_pix[q] * ld + cc : d.in0 + d.off0;
-            ra[q] = *reinterpret_cast<const f32x4*>(ptr);
-            okbits |= ok ? (1u << q) : 0u;
+        const bool ok = c < ctot && a_pix[q] >= 0;
+        const float* ptr = ok ? src + a_pix[q] * ld + cc : d.in0 + d.off0;
+        ra[q] = *reinterpret_cast<const f32x4*>(ptr);
+        a_ok = (a_ok & ~(1u << q)) | (ok ? (1u << q) : 0u);
+    };
+    auto store_A_q = [&](int buf, auto Q) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value;
+        // previous layer's norm (+ReLU) folded into this load; zero padding applies AFTER it
+        f32x4 x = ra[q];
+        if constexpr (AFFINE) {
+            x = x * a_sc + a_sh;
+            if (d.in_relu) {
+                x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+            }
         }
-        a_ok = okbits;
+        const f32x4 v = ((a_ok >> q) & 1u) ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+        // hi = bf16(v) (RNE); lo = bf16(v - hi): the subtraction is exact in fp32
+        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+        const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
+        const bf16x4 lo = __builtin_convertvector(rest, bf16x4);
+        char* row = reinterpret_cast<char*>(Ah) + buf * (HALO_ROWS * LDS_LD * 4) + a_loff[q];
+        *reinterpret_cast<bf16x4*>(row) = hi;
+        *reinterpret_cast<bf16x4*>(row + 64) = lo;
+    };
+    auto load_A = [&](int chunk) __attribute__((always_inline)) {
+        load_A_affine(chunk);
+        static_for<0, A_V4>([&](auto Q) { load_A_q(chunk, Q); });
     };
     auto store_A = [&](int buf) __attribute__((always_inline)) {
-        float* ah = Ah + buf * HALO_ROWS * LDS_LD;
-#pragma unroll
-        for (int q = 0; q < A_V4; ++q) {
-            // previous layer's norm (+ReLU) folded into this load; zero padding applies AFTER it
-            f32x4 x = ra[q];
-            if constexpr (AFFINE) {
-                x = x * a_sc + a_sh;
-                if (d.in_relu) {
-                    x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
-                }
-            }
-            const f32x4 v = ((a_ok >> q) & 1u) ? x : f32x4{0.f, 0.f, 0.f, 0.f};
-            // hi = bf16(v) (RNE); lo = bf16(v - hi): the subtraction is exact in fp32
-            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-            const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
-            const bf16x4 lo = __builtin_convertvector(rest, bf16x4);
-            char* row = reinterpret_cast<char*>(ah + ((tid + 512 * q) >> 3) * LDS_LD);
-            *reinterpret_cast<bf16x4*>(row + 2 * c4) = hi;
-            *reinterpret_cast<bf16x4*>(row + 64 + 2 * c4) = lo;
-        }
+        static_for<0, A_V4>([&](auto Q) { store_A_q(buf, Q); });
     };
 
     // ---- weight ring: 3 LDS slots, 2 register sets (steps s+2, s+3 staged; s+4 issued) -----------
+    // Per-thread address parts are computed ONCE (byte offsets, 32-bit): a K-step's loads are then
+    // `wave-uniform base + constant VGPR offset` -- the first version recomputed 64-bit products
+    // per step and spent ~60 VALU instructions per wave per step on addressing alone.
     f32x4 rb0[NT], rb1[NT];
+    unsigned b_goff[NT];          // global: ((n0 + row) * wrow + c4) * 4 bytes
+    unsigned b_loff[NT];          // LDS:    (row * LDS_LD + c4) * 4 bytes
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int r = (tid + 512 * q) >> 3;
+        b_goff[q] = (unsigned)(((long)(n0 + r) * wrow + c4) * 4);
+        b_loff[q] = (unsigned)((r * LDS_LD + c4) * 4);
+    }
+    const char* const wbytes = reinterpret_cast<const char*>(d.weight);
+    char* const bs_bytes = reinterpret_cast<char*>(Bs);
     auto load_B = [&](int step, f32x4 (&rb)[NT]) __attribute__((always_inline)) {
         if (step >= nsteps) step = nsteps - 1;           // tail: harmless re-read
         const int chunk = step / TAPS, tap = step - chunk * TAPS;
-        const float* wp = d.weight + (long)tap * g.cin_pad + chunk * KC + c4;
+        const char* wp = wbytes + ((long)tap * g.cin_pad + chunk * KC) * 4;      // wave-uniform
 #pragma unroll
         for (int q = 0; q < NT; ++q)
-            rb[q] = *reinterpret_cast<const f32x4*>(wp + (long)(n0 + ((tid + 512 * q) >> 3)) * wrow);
+            rb[q] = *reinterpret_cast<const f32x4*>(wp + b_goff[q]);
     };
     auto store_B = [&](int slot, const f32x4 (&rb)[NT]) __attribute__((always_inline)) {
-        float* bs = Bs + slot * BN * LDS_LD;
+        char* bs = bs_bytes + slot * (BN * LDS_LD * 4);                           // wave-uniform
 #pragma unroll
         for (int q = 0; q < NT; ++q)
-            *reinterpret_cast<f32x4*>(bs + ((tid + 512 * q) >> 3) * LDS_LD + c4) = rb[q];
+            *reinterpret_cast<f32x4*>(bs + b_loff[q]) = rb[q];
     };
 
     f32x16 acc[NT];
@@ -415,21 +477,21 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     // ((s+1)&1) is being filled from LDS for step s+1, so the LDS round trip hides behind MFMAs.
     // [0],[1] = hi K-halves, [2],[3] = lo K-halves.
     bf16x8 fa[2][4], fb[2][NT][4];
-    auto fetch = [&](auto SET, int halo_buf, int ky, int kx, int slot) __attribute__((always_inline)) {
+    auto fetch_A = [&](auto SET, int halo_buf, int ky, int kx) __attribute__((always_inline)) {
         constexpr int set = decltype(SET)::value;
         const char* ap = a_lane + (halo_buf * HALO_ROWS + ky * HW + kx) * (LDS_LD * 4);
         fa[set][0] = *reinterpret_cast<const bf16x8*>(ap);
         fa[set][1] = *reinterpret_cast<const bf16x8*>(ap + 16);
         fa[set][2] = *reinterpret_cast<const bf16x8*>(ap + 64);
         fa[set][3] = *reinterpret_cast<const bf16x8*>(ap + 80);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const char* bp = b_lane + (slot * BN + 32 * t) * (LDS_LD * 4);
-            fb[set][t][0] = *reinterpret_cast<const bf16x8*>(bp);
-            fb[set][t][1] = *reinterpret_cast<const bf16x8*>(bp + 16);
-            fb[set][t][2] = *reinterpret_cast<const bf16x8*>(bp + 64);
-            fb[set][t][3] = *reinterpret_cast<const bf16x8*>(bp + 80);
-        }
+    };
+    auto fetch_B = [&](auto SET, auto T, int slot) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value, t = decltype(T)::value;
+        const char* bp = b_lane + (slot * BN + 32 * t) * (LDS_LD * 4);
+        fb[set][t][0] = *reinterpret_cast<const bf16x8*>(bp);
+        fb[set][t][1] = *reinterpret_cast<const bf16x8*>(bp + 16);
+        fb[set][t][2] = *reinterpret_cast<const bf16x8*>(bp + 64);
+        fb[set][t][3] = *reinterpret_cast<const bf16x8*>(bp + 80);
     };
 
     // ---- prologue: halo 0, weight steps 0 and 1 synchronously; steps 2, 3 in flight; frags(0) ------
@@ -443,16 +505,30 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     load_B(3, rb1);
     asm volatile("" ::: "memory");
     __syncthreads();
-    fetch(std::integral_constant<int, 0>{}, 0, 0, 0, 0);
+    fetch_A(std::integral_constant<int, 0>{}, 0, 0, 0);
+    static_for<0, NT>([&](auto T) { fetch_B(std::integral_constant<int, 0>{}, T, 0); });
 
     // One K-step.  U = position inside a PAIR of chunks (0 .. 2*TAPS-1): tap, register-set parity,
     // ring slot arithmetic (the pair loop carries s mod 3 in `slot3`) and the halo load/store
     // points are compile-time, so the instruction stream of a pair is straight-line and hipcc
     // uses exact counted vmcnt waits (a conditional load inside the loop forces vmcnt(0) at the
     // loop header and drains the whole prefetch queue).
-    //   step s:  barrier | B(s+2) regs -> slot (s+2)%3 | halo(c+1) -> LDS at tap TAPS-2 |
-    //            issue B(s+4) (and halo(c+1) loads at tap 0) | fetch frags(s+1) | MFMAs on frags(s)
+    //
+    // Everything a step does besides its MFMAs is independent of them (they read the fragment set
+    // fetched during the previous step), and the two waves of a SIMD leave the barrier together.
+    // s_memtime stamps of the first version (barrier | ring store | loads | fetch | 6*NT MFMAs)
+    // showed both waves spending ~450 cycles on staging before the first MFMA of a step, and
+    // 600-950 cycles of pure VALU at the halo-split step, with the matrix pipe idle: 39 % MFMA
+    // utilisation (PMC).  So the MFMAs go FIRST and the staging work is cut into pieces issued
+    // between them (sched_barrier fences pin the interleave):
+    //   M | fetch A(s+1) | M | fetch B(s+1) ... | M | B(s+2) regs -> slot (s+2)%3, issue B(s+4) |
+    //   M | halo slice 0 | M | halo slice 1 | ...      (halo(c+1): loads at tap 0, split+store at tap TAPS-2)
     int slot3 = 0;            // s % 3
+#ifdef PF_NO_PIN
+#define PF_PIN() do {} while (0)
+#else
+#define PF_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
     auto step = [&](auto U, int chunk) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         constexpr int tap = u % TAPS;
@@ -463,49 +539,72 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         const int nchunk = (tap == TAPS - 1) ? chunk + 1 : chunk;
         const int s1 = slot3 == 2 ? 0 : slot3 + 1;     // (s+1) % 3
         const int s2 = s1 == 2 ? 0 : s1 + 1;           // (s+2) % 3
+        using NXT = std::integral_constant<int, cur ^ 1>;
 #ifndef PF_ABLATE_NO_BARRIER
         __syncthreads();      // slot (s+1)%3 and the halo of step s+1 are complete; slot (s+2)%3 is idle
 #endif
+        constexpr int NM = 6 * NT;                     // MFMAs of the step; accumulators alternate
+        auto halo_slice = [&](auto Q) __attribute__((always_inline)) {
+#ifndef PF_ABLATE_NO_GLOBAL
+            if constexpr (tap == 0) load_A_q(chunk + 1, Q);
+#endif
 #ifndef PF_ABLATE_NO_LDS_WRITE
-        if constexpr (cur == 0) store_B(s2, rb0); else store_B(s2, rb1);
-        if constexpr (tap == TAPS - 2) store_A((chunk + 1) & 1);
+            if constexpr (tap == TAPS - 2) store_A_q((chunk + 1) & 1, Q);
+#endif
+        };
+        static_for<0, NM>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            constexpr int t = i % NT, j = i / NT, ks = j / 3, pass = j % 3;
+#ifdef PF_ABLATE_NO_MFMA
+            if constexpr (pass == 0)                  // keep the fragment reads alive, no matrix work
+                asm volatile("" :: "v"(fa[cur][ks]), "v"(fa[cur][2 + ks]), "v"(fb[cur][t][ks]), "v"(fb[cur][t][2 + ks]));
+#else
+            if constexpr (pass == 0)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][2 + ks], fb[cur][t][ks], acc[t], 0, 0, 0);
+            else if constexpr (pass == 1)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][ks], fb[cur][t][2 + ks], acc[t], 0, 0, 0);
+            else
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][ks], fb[cur][t][ks], acc[t], 0, 0, 0);
+#endif
+            PF_PIN();
+#ifndef PF_ABLATE_NO_FETCH
+            if constexpr (i == 0) fetch_A(NXT{}, nchunk & 1, nky, nkx);
+            if constexpr (i >= 1 && i <= NT) fetch_B(NXT{}, std::integral_constant<int, i - 1>{}, s1);
+#endif
+            if constexpr (i == NT + 1) {
+#ifndef PF_ABLATE_NO_LDS_WRITE
+                if constexpr (cur == 0) store_B(s2, rb0); else store_B(s2, rb1);
 #endif
 #ifndef PF_ABLATE_NO_GLOBAL
-        if constexpr (cur == 0) load_B(s + 4, rb0); else load_B(s + 4, rb1);
-        if constexpr (tap == 0) load_A(chunk + 1);
+                if constexpr (cur == 0) load_B(s + 4, rb0); else load_B(s + 4, rb1);
+                if constexpr (tap == 0) load_A_affine(chunk + 1);
 #endif
-        asm volatile("" ::: "memory");                 // keep the loads above the MFMA block
-        fetch(std::integral_constant<int, cur ^ 1>{}, nchunk & 1, nky, nkx, s1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][2 + ks], fb[cur][t][ks], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][ks], fb[cur][t][2 + ks], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][ks], fb[cur][t][ks], acc[t], 0, 0, 0);
             }
-        }
+            if constexpr (NT == 1) {                    // 6 MFMAs: two halo slices per gap
+                if constexpr (i == 3) { halo_slice(std::integral_constant<int, 0>{}); halo_slice(std::integral_constant<int, 1>{}); }
+                if constexpr (i == 4) { halo_slice(std::integral_constant<int, 2>{}); halo_slice(std::integral_constant<int, 3>{}); }
+            } else {
+                if constexpr (i >= NT + 2 && i < NT + 2 + A_V4) halo_slice(std::integral_constant<int, i - NT - 2>{});
+            }
+            PF_PIN();
+        });
         slot3 = s1;
     };
     int c2 = 0;
+#ifdef PF_ABLATE_NO_LOOP                      // prologue + epilogue only: the fixed cost of a launch
+    if (g.nchunks > 0) c2 = 1 << 20;
+#endif
     for (; c2 + 1 < nchunks; c2 += 2)
         static_for<0, 2 * TAPS>([&](auto U) { step(U, c2 + decltype(U)::value / TAPS); });
-    if (nchunks & 1)
+    if ((nchunks & 1) && c2 < (1 << 20))
         static_for<0, TAPS>([&](auto U) { step(U, nchunks - 1); });
 
     // ---- epilogue -----------------------------------------------------------------------------
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int j = n0 + 32 * NT * wn + 32 * t + li;
-        const bool jok = j < d.cout;
-        const float bias = jok ? d.bias[j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tx = (r & 3) + 8 * (r >> 2) + 4 * lh;          // column inside the tile row
-            const long p = pix0 + (long)(y0 + wy) * g.W + x0 + tx;
-            if (jok) conv_epilogue(d, p, j, acc[t][r] + bias);
-        }
-    }
+#ifndef PF_ABLATE_NO_EPILOGUE
+    tile_epilogue<NT, false>(d, acc, n0 + 32 * NT * wn, li, pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh, 0);
+#else
+    if (acc[0][0] == 123.456f) d.out[0] = acc[NT - 1][3];
+#endif
 }
 
 template <int NT, int KH, int KW, bool AFFINE>

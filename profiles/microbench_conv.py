@@ -20,6 +20,8 @@ prec = PREC_F32 if os.environ.get("PRIORFLOW_PRECISION", "bf16x3") == "fp32" els
 lib = _lib.load()
 dev = torch.device("cuda:0")
 H8, W8 = 64, 128
+BATCH = int(os.environ.get("MB_BATCH", "1"))      # stacked along H for the micro-benchmark (same kernels, longer dispatch)
+H8 *= BATCH
 N = H8 * W8
 g = torch.Generator(device="cpu").manual_seed(0)
 
