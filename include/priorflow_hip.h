@@ -190,6 +190,11 @@ int pf_upsample_flow(const float* coords1, const float* mask, int ld, float* out
 int pf_to_channel_last(const float* in, int c_total, int c_begin, int c, float* out, int ld_out,
                        int off_out, int act, int B, int N, void* stream);
 
+/* 2x2 space-to-depth: NCHW [B,C,H,W] -> channel-last [B*(H/2)*(W/2)][ld_out], column (py*2+px)*C + c.
+ * Feeds the encoders' stem (core/extractor.py:122 `conv1 = Conv2d(3, 64, 7, stride=2, padding=3)`),
+ * which pf_conv2d then runs as a 4x4 stride-1 convolution over the 12 stacked channels. */
+int pf_space_to_depth2(const float* in, int C, float* out, int ld_out, int B, int H, int W, void* stream);
+
 /* channel-last slice -> NCHW. */
 int pf_to_nchw(const float* in, int ld_in, int off_in, int c, float* out, int B, int N,
                void* stream);

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "pf_coords_add": [_fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
+    "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
     "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
 }
 EXPORTS = ["pf_version"] + list(_SIGNATURES)
@@ -272,6 +273,14 @@ class PfLib:
         N = x.shape[2] * x.shape[3]
         self._rc(self._dll.pf_to_channel_last(_ptr(x), Ct, c_begin, c, _ptr(out), out.shape[-1], off_out,
                                               act, B, N, self._stream(x)), "pf_to_channel_last")
+        return out
+
+    def space_to_depth2(self, x, out):
+        """x: NCHW [B,C,H,W] -> out rows [B*(H/2)*(W/2), ld], columns (py*2+px)*C + c."""
+        self._chk(x, out)
+        B, C, H, W = x.shape
+        self._rc(self._dll.pf_space_to_depth2(_ptr(x), C, _ptr(out), out.shape[-1], B, H, W, self._stream(x)),
+                 "pf_space_to_depth2")
         return out
 
     def to_nchw(self, x, off_in, c, out):

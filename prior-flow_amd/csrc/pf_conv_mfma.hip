@@ -635,6 +635,7 @@ int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int 
     if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, false>(grp, ngroups, g, max_cout, stream);
     if (g.kh == 1 && g.kw == 5) return launch_conv_halo_t<NT, 1, 5, false>(grp, ngroups, g, max_cout, stream);
     if (g.kh == 5 && g.kw == 1) return launch_conv_halo_t<NT, 5, 1, false>(grp, ngroups, g, max_cout, stream);
+    if (g.kh == 4 && g.kw == 4) return launch_conv_halo_t<NT, 4, 4, false>(grp, ngroups, g, max_cout, stream);
     return PF_ERR_BAD_SHAPE;
 }
 
@@ -672,7 +673,8 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
         if (d.c0 <= 0 || d.c1 < 0 || (d.c1 > 0 && !d.in1)) return PF_ERR_BAD_ARG;
         // same geometry in every group: one kernel, one K loop
         if (d.kh != f.kh || d.kw != f.kw || d.c0 + d.c1 != f.c0 + f.c1) return PF_ERR_BAD_SHAPE;
-        if (!(d.kh & 1) || !(d.kw & 1) || d.cout <= 0) return PF_ERR_BAD_SHAPE;
+        // odd k: window [-k/2, k/2]; even k: [-k/2, k/2 - 1] (the space-to-depth form of the 7x7/2 stem)
+        if (d.kh < 1 || d.kw < 1 || d.kh > 7 || d.kw > 7 || d.cout <= 0) return PF_ERR_BAD_SHAPE;
         // 16-byte loads: every channel offset / stride must be a multiple of 4 floats
         if ((d.ld0 | d.off0 | d.c0 | d.c1) & 3) return PF_ERR_BAD_SHAPE;
         if (d.c1 > 0 && (((d.ld1 | d.off1) & 3) || (d.c0 % KC) != 0)) return PF_ERR_BAD_SHAPE;
@@ -709,7 +711,8 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
 // 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3, >= 3 taps, W8 % 32 == 0, H8 % 4 == 0)
 static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
-    const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1);
+    const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1) ||
+                            (g.kh == 4 && g.kw == 4);
     if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1 && g.W % 32 == 0 && g.H % 4 == 0 &&
         !pf_conv_force_generic()) {
         const long wgs128 = ((long)g.M / 128) * ngroups * ((max_cout + 127) / 128);

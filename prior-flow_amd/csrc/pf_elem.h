@@ -484,6 +484,23 @@ PF_HD void pf_to_nhwc_elem(long idx, const PfToNhwcArgs& a) {   // idx over B*N*
     a.out[row * a.ld_out + a.c_out_off + c] = pf_act(v, a.act);
 }
 
+// 2x2 space-to-depth of an NCHW image into a channel-last map:
+//   out[b][Y][X][(py*2+px)*C + c] = in[b][c][2Y+py][2X+px]
+// The encoders' 7x7 stride-2 stem (core/extractor.py:122, Cin = 3) is, on this image, a 4x4
+// stride-1 convolution over 12 channels with window rows Y-2..Y+1 (tap KY <-> ky = 2 KY + py - 1),
+// which the implicit-GEMM conv kernels run directly (see engine.EncoderPlan).
+struct PfS2dArgs { const float* in; float* out; int B, C, H, W, ld_out; };   // H, W: INPUT size (even)
+PF_HD void pf_s2d_elem(long idx, const PfS2dArgs& a) {           // idx over B*(H/2)*(W/2)*4*C
+    const int C4 = 4 * a.C, Wo = a.W / 2, Ho = a.H / 2;
+    const int cc = (int)(idx % C4);
+    const long pix = idx / C4;
+    const int X = (int)(pix % Wo), Y = (int)((pix / Wo) % Ho);
+    const long b = pix / ((long)Wo * Ho);
+    const int q = cc / a.C, c = cc % a.C;
+    const int py = q >> 1, px = q & 1;
+    a.out[pix * a.ld_out + cc] = a.in[((b * a.C + c) * a.H + 2 * Y + py) * (long)a.W + 2 * X + px];
+}
+
 // channel-last -> NCHW (debug / boundary export)
 struct PfToNchwArgs { const float* in; float* out; int B, C, N, ld_in, c_in_off; };
 PF_HD void pf_to_nchw_elem(long idx, const PfToNchwArgs& a) {   // idx over B*C*N

@@ -64,6 +64,27 @@ def split_bf16(wp: torch.Tensor) -> torch.Tensor:
     return torch.cat([hi.reshape(shp), lo.reshape(shp)], dim=-2).contiguous()
 
 
+def stem_s2d_weight(w: torch.Tensor) -> torch.Tensor:
+    """7x7 stride-2 pad-3 weights [Cout,C,7,7] -> the equivalent 4x4 stride-1 weights [Cout,4C,4,4]
+    over the 2x2 space-to-depth image (channel (py*2+px)*C + c, window rows Y-2..Y+1):
+    input row 2y + ky - 3 = 2(y + KY - 2) + py  =>  ky = 2 KY + py - 1 (taps outside 0..6 are zero)."""
+    cout, c, kh, kw = w.shape
+    assert kh == 7 and kw == 7
+    w2 = torch.zeros(cout, 4 * c, 4, 4, dtype=torch.float32, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for KY in range(4):
+                ky = 2 * KY + py - 1
+                if not 0 <= ky < 7:
+                    continue
+                for KX in range(4):
+                    kx = 2 * KX + px - 1
+                    if 0 <= kx < 7:
+                        q = py * 2 + px
+                        w2[:, q * c:(q + 1) * c, KY, KX] = w.detach().float()[:, :, ky, kx]
+    return w2
+
+
 def default_precision() -> int:
     """PRIORFLOW_PRECISION=fp32 selects the exact-fp32 MFMA path; default is the 3-pass bf16
     split (same parity class: SURVEY.md §7 measured 2e-5 EPE for split-x3 update blocks)."""
@@ -470,8 +491,10 @@ class Engine:
 class EncoderPlan:
     """fnet (InstanceNorm) or cnet (BatchNorm, eval) as a launch plan.
 
-    conv1 7x7/2 (3->64) runs on the small-Cin exact-fp32 MFMA kernel straight from the NCHW
-    image; every 3x3 stride-1 conv runs on the bf16x3 halo kernel; the stride-2 3x3 / 1x1 convs
+    conv1 7x7/2 (3->64): in bf16x3 mode the image is 2x2 space-to-depth'd (12 channels) and the
+    stem runs on the halo kernel as the equivalent 4x4 stride-1 conv (5x faster than the small-Cin
+    kernel: 351 -> ~70 us per launch); in exact-fp32 mode it runs on the small-Cin fp32 MFMA kernel
+    straight from the NCHW image.  Every 3x3 stride-1 conv runs on the bf16x3 halo kernel; the stride-2 3x3 / 1x1 convs
     and the final 1x1 on the generic bf16x3 kernel.  A conv writes its RAW output (+bias); the
     following norm is never applied as a pass of its own: it is folded, together with the ReLU,
     into the next conv's input load (`in_scale/in_shift`) or into the residual-tail kernel
@@ -485,7 +508,12 @@ class EncoderPlan:
         self.precision = precision
         dev = enc.conv1.weight.device
         self.dev = dev
-        self.stem = DirectConv(enc.conv1)                      # [49][3][64]
+        self.stem = DirectConv(enc.conv1)                      # [49][3][64]  (exact-fp32 mode)
+        # bf16x3 mode: the stem as a 4x4 stride-1 conv over the space-to-depth image (halo kernel)
+        self.stem_s2d = None
+        if precision == PREC_BF16X3:
+            wp, bp = pack_mfma(stem_s2d_weight(enc.conv1.weight), enc.conv1.bias)
+            self.stem_s2d = Conv(wp, bp, 4, 4, 12, 64, precision)
         self.blocks = []
         for layer, stride in ((enc.layer1, 1), (enc.layer2, 2), (enc.layer3, 2)):
             for i, blk in enumerate(layer):
@@ -529,6 +557,7 @@ class EncoderPlan:
         # three rotating activation buffers per resolution (x / y1 / y2 / out rotate through them)
         for lvl, (h, w, c) in enumerate(((H // 2, W // 2, 64), (H // 4, W // 4, 96), (H // 8, W // 8, 128))):
             b[f"act{lvl}"] = [z(Bn * h * w, c) for _ in range(4)]
+        b["s2d"] = z(Bn * (H // 2) * (W // 2), 12)
         b["sc"] = [z(Bn * 128) for _ in range(3)]
         b["sh"] = [z(Bn * 128) for _ in range(3)]
         b["part"] = z(Bn * 128 * 128 * 2, dt=torch.float64)
@@ -544,7 +573,11 @@ class EncoderPlan:
         h, w = H // 2, W // 2
         a0 = bufs["act0"]
         # stem: raw conv -> a0[0]; x0 = relu(norm1(.)) materialised -> a0[1]
-        lib.conv2d_small(images, True, 0, 3, self.stem.w, self.stem.b, a0[0], 0, 64, 7, 7, 2, False, Bn, h, w)
+        if self.stem_s2d is not None:
+            lib.space_to_depth2(images, bufs["s2d"])
+            lib.conv2d([self.stem_s2d.desc(bufs["s2d"], 0, 12, a0[0], 0, EPI_LINEAR)], Bn, h, w, images)
+        else:
+            lib.conv2d_small(images, True, 0, 3, self.stem.w, self.stem.b, a0[0], 0, 64, 7, 7, 2, False, Bn, h, w)
         sc, sh = self._affine(self.norm1, a0[0], Bn, h * w, 64, 0)
         lib.norm_act(a0[0], sc, sh, a0[1], Bn, h * w, 64)
         x = a0[1]

@@ -222,6 +222,13 @@ def case_layout(lib, dev):
     back = torch.empty(2, 6, H8, W8, device=dev)
     lib.to_nchw(out, 3, 6, back)
     check(back, torch.tanh(x[:, 4:10]), 2e-6, "to_nchw")
+    # 2x2 space-to-depth (stem input): column (py*2+px)*C + c of pixel (Y, X) = x[c][2Y+py][2X+px]
+    img = gc.uni("layout/img", (2, 3, H8, W8), -1, 1)
+    s2d = torch.full((2 * (H8 // 2) * (W8 // 2), 14), 7.0, device=dev)
+    lib.space_to_depth2(img.to(dev), s2d)
+    want = torch.stack([img[:, :, py::2, px::2] for py in range(2) for px in range(2)], 1)   # [B,4,C,h,w]
+    check(s2d[:, :12], cl(want.reshape(2, 12, H8 // 2, W8 // 2)), 0.0, "space_to_depth2")
+    assert float((s2d[:, 12:] - 7.0).abs().max()) == 0.0
 
 
 def case_channel_stats_and_norm_act(lib, dev):

@@ -272,6 +272,29 @@ def test_conv_stride2_and_input_affine(lib, dev):
     kc.check(kc.uncl(out.cpu(), 2, 16, 64), want, 1.5e-4, "halo conv with folded norm+relu")
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_stem_as_space_to_depth_conv(lib, dev, prec):
+    """The 7x7 stride-2 stem (core/extractor.py:122) as space-to-depth + 4x4 stride-1 conv (even
+    kernel: window [-2, +1]) on both conv kernels, vs torch conv2d on the original weights."""
+    from prior_flow_amd._lib import EPI_LINEAR, PREC_BF16X3, PREC_F32
+    from prior_flow_amd.engine import Conv, pack_mfma, stem_s2d_weight
+    precision = PREC_F32 if prec == "fp32" else PREC_BF16X3
+    B, H, W = 2, 40, 128                     # output 20 x 64: halo kernel in bf16x3 mode
+    img = gc.uni("stem2/img", (B, 3, H, W), -1, 1)
+    w = gc.uni("stem2/w", (64, 3, 7, 7), -0.15, 0.15)
+    b = gc.uni("stem2/b", (64,), -0.1, 0.1)
+    want = torch.nn.functional.conv2d(img, w, b, stride=2, padding=3)
+    wp, bp = pack_mfma(stem_s2d_weight(w).to(dev), b.to(dev))
+    cv = Conv(wp, bp, 4, 4, 12, 64, precision)
+    s2d = torch.empty(B * (H // 2) * (W // 2), 12, device=dev)
+    lib.space_to_depth2(img.to(dev), s2d)
+    out = torch.empty(B * (H // 2) * (W // 2), 64, device=dev)
+    d = cv.desc(s2d, 0, 12, out, 0, EPI_LINEAR)
+    assert lib.conv2d_tile([d], B, H // 2, W // 2) == (3 if prec == "bf16x3" else 1)
+    lib.conv2d([d], B, H // 2, W // 2, s2d)
+    kc.check(kc.uncl(out.cpu(), B, H // 2, W // 2), want, 3e-6 if prec == "fp32" else 1e-4, f"s2d stem {prec}")
+
+
 @pytest.mark.parametrize("which", ["fnet", "cnet"])
 def test_encoder_plan_vs_reference_golden(lib, dev, params, which):
     """BasicEncoder (core/extractor.py:98-158) through EncoderPlan vs the reference's own output."""
