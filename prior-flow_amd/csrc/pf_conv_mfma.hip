@@ -333,14 +333,19 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int NT, int KH, int KW, bool AFFINE>
+template <int NT, int KH, int KW, bool AFFINE, int TH>
 __global__ void __launch_bounds__(512, 2)      // 8 waves = 2 per SIMD, 256-register budget
 pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
-    constexpr int TH = 4, TW = 32, BN = 64 * NT, TAPS = KH * KW;
+    // TH = 4: waves 4 (rows) x 2 (channel halves), tile 128 px x 64*NT channels.
+    // TH = 8: waves 8 (rows) x 1, tile 256 px x 32*NT channels -- for Cout <= 64 layers (encoder
+    //         stem / layer 1) this gives every wave two accumulators per staged K-step instead of one.
+    static_assert(TH == 4 || TH == 8, "");
+    constexpr int TW = 32, WN = (TH == 4) ? 2 : 1, BN = 32 * NT * WN, TAPS = KH * KW;
+    static_assert(BN % 64 == 0, "weight loader moves 64 rows per pass");
+    constexpr int B_V4 = BN / 64;             // weight float4 per thread per K-step
     constexpr int HW = TW + KW - 1, HH = TH + KH - 1;
-    constexpr int HALO_ROWS = 256;            // >= HH*HW for every supported tap shape; the loader
-    static_assert(HH * HW <= HALO_ROWS, "");  // fills all 256 rows (rows past the halo get zeros)
-    constexpr int A_V4 = HALO_ROWS * 8 / 512; // 4 halo float4 per thread
+    constexpr int A_V4 = (HH * HW + 63) / 64; // halo float4 per thread (64 rows per pass of 512 threads)
+    constexpr int HALO_ROWS = 64 * A_V4;      // rows past HH*HW get zeros
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ah = smem;                                   // [2][HALO_ROWS][LDS_LD]
     float* Bs = smem + 2 * HALO_ROWS * LDS_LD;          // [3][BN][LDS_LD]  (3-slot ring)
@@ -355,7 +360,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar wave id
     const int li = lane & 31, lh = lane >> 5;
-    const int wy = wave >> 1, wn = wave & 1;
+    const int wy = (TH == 4) ? wave >> 1 : wave, wn = (TH == 4) ? wave & 1 : 0;
     const int tiles_x = g.W / TW, tiles_y = g.H / TH;
     const int tile = blockIdx.x;
     const int x0 = (tile % tiles_x) * TW;
@@ -438,29 +443,29 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     // Per-thread address parts are computed ONCE (byte offsets, 32-bit): a K-step's loads are then
     // `wave-uniform base + constant VGPR offset` -- the first version recomputed 64-bit products
     // per step and spent ~60 VALU instructions per wave per step on addressing alone.
-    f32x4 rb0[NT], rb1[NT];
-    unsigned b_goff[NT];          // global: ((n0 + row) * wrow + c4) * 4 bytes
-    unsigned b_loff[NT];          // LDS:    (row * LDS_LD + c4) * 4 bytes
+    f32x4 rb0[B_V4], rb1[B_V4];
+    unsigned b_goff[B_V4];        // global: ((n0 + row) * wrow + c4) * 4 bytes
+    unsigned b_loff[B_V4];        // LDS:    (row * LDS_LD + c4) * 4 bytes
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
+    for (int q = 0; q < B_V4; ++q) {
         const int r = (tid + 512 * q) >> 3;
         b_goff[q] = (unsigned)(((long)(n0 + r) * wrow + c4) * 4);
         b_loff[q] = (unsigned)((r * LDS_LD + c4) * 4);
     }
     const char* const wbytes = reinterpret_cast<const char*>(d.weight);
     char* const bs_bytes = reinterpret_cast<char*>(Bs);
-    auto load_B = [&](int step, f32x4 (&rb)[NT]) __attribute__((always_inline)) {
+    auto load_B = [&](int step, f32x4 (&rb)[B_V4]) __attribute__((always_inline)) {
         if (step >= nsteps) step = nsteps - 1;           // tail: harmless re-read
         const int chunk = step / TAPS, tap = step - chunk * TAPS;
         const char* wp = wbytes + ((long)tap * g.cin_pad + chunk * KC) * 4;      // wave-uniform
 #pragma unroll
-        for (int q = 0; q < NT; ++q)
+        for (int q = 0; q < B_V4; ++q)
             rb[q] = *reinterpret_cast<const f32x4*>(wp + b_goff[q]);
     };
-    auto store_B = [&](int slot, const f32x4 (&rb)[NT]) __attribute__((always_inline)) {
+    auto store_B = [&](int slot, const f32x4 (&rb)[B_V4]) __attribute__((always_inline)) {
         char* bs = bs_bytes + slot * (BN * LDS_LD * 4);                           // wave-uniform
 #pragma unroll
-        for (int q = 0; q < NT; ++q)
+        for (int q = 0; q < B_V4; ++q)
             *reinterpret_cast<f32x4*>(bs + b_loff[q]) = rb[q];
     };
 
@@ -580,10 +585,11 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
                 if constexpr (tap == 0) load_A_affine(chunk + 1);
 #endif
             }
-            if constexpr (NT == 1) {                    // 6 MFMAs: two halo slices per gap
-                if constexpr (i == 3) { halo_slice(std::integral_constant<int, 0>{}); halo_slice(std::integral_constant<int, 1>{}); }
-                if constexpr (i == 4) { halo_slice(std::integral_constant<int, 2>{}); halo_slice(std::integral_constant<int, 3>{}); }
+            if constexpr (NT == 1) {                    // 6 MFMAs: half of the halo slices in each of two gaps
+                if constexpr (i == 3) static_for<0, A_V4 / 2>([&](auto Q) { halo_slice(Q); });
+                if constexpr (i == 4) static_for<A_V4 / 2, A_V4>([&](auto Q) { halo_slice(Q); });
             } else {
+                static_assert(NT == 1 || NT + 2 + A_V4 <= 6 * NT, "halo slices fit between the MFMAs");
                 if constexpr (i >= NT + 2 && i < NT + 2 + A_V4) halo_slice(std::integral_constant<int, i - NT - 2>{});
             }
             PF_PIN();
@@ -607,35 +613,39 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
 #endif
 }
 
-template <int NT, int KH, int KW, bool AFFINE>
+template <int NT, int KH, int KW, bool AFFINE, int TH>
 int launch_conv_halo_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
-    constexpr int BN = 64 * NT;
-    const size_t lds = (size_t)(2 * 256 + 3 * BN) * LDS_LD * sizeof(float);
+    constexpr int BN = 32 * NT * (TH == 4 ? 2 : 1);
+    constexpr int HALO_ROWS = ((TH + KH - 1) * (32 + KW - 1) + 63) / 64 * 64;
+    const size_t lds = (size_t)(2 * HALO_ROWS + 3 * BN) * LDS_LD * sizeof(float);
+    static_assert((2 * HALO_ROWS + 3 * BN) * LDS_LD * sizeof(float) <= 160 * 1024, "LDS budget");
     const int B = g.M / g.N;
-    dim3 grid((unsigned)(B * (g.H / 4) * (g.W / 32)), (unsigned)((max_cout + BN - 1) / BN), (unsigned)ngroups);
-    // 92-110 KB of dynamic LDS: above the 64 KB default limit
+    dim3 grid((unsigned)(B * (g.H / TH) * (g.W / 32)), (unsigned)((max_cout + BN - 1) / BN), (unsigned)ngroups);
+    // up to ~130 KB of dynamic LDS: above the 64 KB default limit
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT, KH, KW, AFFINE>),
+        reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL((pf_conv_halo_kernel<NT, KH, KW, AFFINE>), grid, dim3(512), lds, stream, grp, g);
+    hipLaunchKernelGGL((pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>), grid, dim3(512), lds, stream, grp, g);
     return (int)hipGetLastError();
 }
 
-template <int NT>
+template <int NT, int TH>
 int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
     // every group of a launch must agree on having an input affine (one instantiation per launch)
     bool affine = grp.d[0].in_scale != nullptr;
     for (int i = 1; i < ngroups; ++i)
         if ((grp.d[i].in_scale != nullptr) != affine) return PF_ERR_BAD_ARG;
     if (affine) {                           // only the encoders' 3x3 convs use it
-        if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, true>(grp, ngroups, g, max_cout, stream);
+        if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, true, TH>(grp, ngroups, g, max_cout, stream);
         return PF_ERR_BAD_SHAPE;
     }
-    if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, false>(grp, ngroups, g, max_cout, stream);
-    if (g.kh == 1 && g.kw == 5) return launch_conv_halo_t<NT, 1, 5, false>(grp, ngroups, g, max_cout, stream);
-    if (g.kh == 5 && g.kw == 1) return launch_conv_halo_t<NT, 5, 1, false>(grp, ngroups, g, max_cout, stream);
-    if (g.kh == 4 && g.kw == 4) return launch_conv_halo_t<NT, 4, 4, false>(grp, ngroups, g, max_cout, stream);
+    if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, false, TH>(grp, ngroups, g, max_cout, stream);
+    if (g.kh == 4 && g.kw == 4) return launch_conv_halo_t<NT, 4, 4, false, TH>(grp, ngroups, g, max_cout, stream);
+    if constexpr (TH == 4) {                // the GRU's separable convs only exist at 1/8 resolution
+        if (g.kh == 1 && g.kw == 5) return launch_conv_halo_t<NT, 1, 5, false, TH>(grp, ngroups, g, max_cout, stream);
+        if (g.kh == 5 && g.kw == 1) return launch_conv_halo_t<NT, 5, 1, false, TH>(grp, ngroups, g, max_cout, stream);
+    }
     return PF_ERR_BAD_SHAPE;
 }
 
@@ -710,12 +720,14 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // the smaller tile to put >= 1 workgroup on each of the 256 CUs.
 // 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
 // 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3, >= 3 taps, W8 % 32 == 0, H8 % 4 == 0)
+// 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, H8 % 8 == 0, enough pixels to fill the chip)
 static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
     const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1) ||
                             (g.kh == 4 && g.kw == 4);
     if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1 && g.W % 32 == 0 && g.H % 4 == 0 &&
         !pf_conv_force_generic()) {
         const long wgs128 = ((long)g.M / 128) * ngroups * ((max_cout + 127) / 128);
+        if (max_cout <= 64 && g.kh == g.kw && g.H % 8 == 0 && ((long)g.M / 256) * ngroups >= 512) return 5;
         return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
     }
     const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;
@@ -743,7 +755,8 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
         case 0: return launch_conv<4, 1, 1>(grp, ngroups, g, max_cout, split, s);
         case 1: return launch_conv<2, 2, 1>(grp, ngroups, g, max_cout, split, s);
         case 2: return launch_conv<2, 2, 2>(grp, ngroups, g, max_cout, split, s);
-        case 3: return launch_conv_halo<1>(grp, ngroups, g, max_cout, s);
-        default: return launch_conv_halo<2>(grp, ngroups, g, max_cout, s);
+        case 3: return launch_conv_halo<1, 4>(grp, ngroups, g, max_cout, s);
+        case 4: return launch_conv_halo<2, 4>(grp, ngroups, g, max_cout, s);
+        default: return launch_conv_halo<2, 8>(grp, ngroups, g, max_cout, s);
     }
 }

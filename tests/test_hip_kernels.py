@@ -295,6 +295,45 @@ def test_stem_as_space_to_depth_conv(lib, dev, prec):
     kc.check(kc.uncl(out.cpu(), B, H // 2, W // 2), want, 3e-6 if prec == "fp32" else 1e-4, f"s2d stem {prec}")
 
 
+def test_conv_8row_tile_layer1_size(lib, dev):
+    """Tile 5 (256 px x 64 ch, 8-row halo tile) is only chosen once the map can fill the chip:
+    run the encoder layer-1 shapes at 256x512 (core/extractor.py:122-127) against torch conv2d."""
+    from prior_flow_amd._lib import EPI_LINEAR, EPI_RELU, PREC_BF16X3
+    from prior_flow_amd.engine import Conv, pack_mfma, stem_s2d_weight
+    B, h, w = 2, 256, 512
+    # 3x3 64 -> 64 with the folded input norm + ReLU
+    x = gc.uni("t5/x", (B, 64, h, w), -1, 1)
+    wt = gc.uni("t5/w", (64, 64, 3, 3), -0.1, 0.1)
+    b = gc.uni("t5/b", (64,), -0.1, 0.1)
+    sc = gc.uni("t5/sc", (B, 64), 0.5, 1.5)
+    sh = gc.uni("t5/sh", (B, 64), -0.5, 0.5)
+    want = torch.nn.functional.conv2d(torch.relu(x * sc[:, :, None, None] + sh[:, :, None, None]), wt, b, padding=1)
+    wp, bp = pack_mfma(wt.to(dev), b.to(dev))
+    cv = Conv(wp, bp, 3, 3, 64, 64, PREC_BF16X3)
+    xin = kc.cl(x).to(dev)
+    out = torch.empty(B * h * w, 64, device=dev)
+    d = cv.desc(xin, 0, 64, out, 0, EPI_LINEAR, in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True)
+    assert lib.conv2d_tile([d], B, h, w) == 5
+    lib.conv2d([d], B, h, w, xin)
+    kc.check(kc.uncl(out.cpu(), B, h, w), want, 1.5e-4, "8-row tile 3x3 affine")
+    d = cv.desc(xin, 0, 64, out, 0, EPI_RELU)
+    lib.conv2d([d], B, h, w, xin)
+    kc.check(kc.uncl(out.cpu(), B, h, w), torch.relu(torch.nn.functional.conv2d(x, wt, b, padding=1)), 1.5e-4,
+             "8-row tile 3x3 relu")
+    # 4x4 space-to-depth stem
+    img = gc.uni("t5/img", (B, 3, 2 * h, 2 * w), -1, 1)
+    w7 = gc.uni("t5/w7", (64, 3, 7, 7), -0.15, 0.15)
+    want = torch.nn.functional.conv2d(img, w7, b, stride=2, padding=3)
+    wp, bp = pack_mfma(stem_s2d_weight(w7).to(dev), b.to(dev))
+    cv = Conv(wp, bp, 4, 4, 12, 64, PREC_BF16X3)
+    s2d = torch.empty(B * h * w, 12, device=dev)
+    lib.space_to_depth2(img.to(dev), s2d)
+    d = cv.desc(s2d, 0, 12, out, 0, EPI_LINEAR)
+    assert lib.conv2d_tile([d], B, h, w) == 5
+    lib.conv2d([d], B, h, w, s2d)
+    kc.check(kc.uncl(out.cpu(), B, h, w), want, 1e-4, "8-row tile 4x4 stem")
+
+
 @pytest.mark.parametrize("which", ["fnet", "cnet"])
 def test_encoder_plan_vs_reference_golden(lib, dev, params, which):
     """BasicEncoder (core/extractor.py:98-158) through EncoderPlan vs the reference's own output."""
