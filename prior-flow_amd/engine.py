@@ -235,6 +235,7 @@ class Workspace:
         self.z_a, self.z_b = z(rows, 128), z(rows, 128)
         self.rh_a, self.rh_b = z(rows, 128), z(rows, 128)
         self.own, self.raw = z(rows, CORR_CH), z(rows, CORR_CH)
+        self.own_b, self.raw_b = z(rows, CORR_CH), z(rows, CORR_CH)      # branch B's lookups run concurrently
         self.corr_a, self.corr_b = z(rows, CORR_CH), z(rows, CORR_CH)
         self.c1_a, self.c1_b = z(rows, 256), z(rows, 256)
         self.cat_a, self.cat_b = z(rows, 272), z(rows, 272)     # cat_b columns 256..271 stay zero
@@ -257,7 +258,7 @@ class Workspace:
 
 class Engine:
     def __init__(self, lib: PfLib, side_streams=None):
-        """side_streams: optional (s1, s2) torch streams.  When given, the three independent chains of
+        """side_streams: optional (s1, s2, s3) torch streams.  When given, the three independent chains of
         an iteration -- correlation (lookups, 1x1, 3x3), flow (prep, flo_rotate, 7x7, 3x3) and
         confidence (warps, 3x3, 3x3) -- run concurrently and join before conv_A (inside a HIP-graph
         capture they become parallel branches)."""
@@ -359,11 +360,22 @@ class Engine:
         """DCCL lookups (K3+K4; :185-188) + 1x1 + 3x3 of the motion encoders -> cat_a[0:128], cat_b[0:192].
         A looks into B through grid(R_A2B^T)==grid(R_B2A) and rotates back with grid(R_B2A); B the other way."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
-        lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
-        lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
-        if need_b:
-            lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own, ws.raw)
-            lib.dccl_combine(ws.own, ws.raw, ws.g_a2b_8, ws.corr_b, B, H8, W8)
+        if need_b and self.side is not None:
+            # the two branches' lookups are independent gather chains: B's runs beside A's
+            main, sb = torch.cuda.current_stream(), self.side[2]
+            sb.wait_stream(main)
+            with torch.cuda.stream(sb):
+                lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b)
+                lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
+            lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+            lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+            main.wait_stream(sb)
+        else:
+            lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+            lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+            if need_b:
+                lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b)
+                lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
         d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
         if need_b:
             d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, ws.c1_b, 0, EPI_RELU))
@@ -395,7 +407,7 @@ class Engine:
             self._conf_chain(ws, P)
             return
         main = torch.cuda.current_stream()
-        s1, s2 = self.side
+        s1, s2 = self.side[0], self.side[1]
         s1.wait_stream(main)
         with torch.cuda.stream(s1):
             self._flow_chain_head(ws)
@@ -463,16 +475,34 @@ class Engine:
             d.append(P["b.m0"].desc(ws.net_b[c], 0, 128, ws.mh_b, 0, EPI_RELU))
         conv(d)
         # FlowHead.conv2 (256 -> 2) + coords1 += delta_flow in one wave-per-pixel kernel
-        lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
-        if need_b:
-            lib.flow_head_out(ws.fh_b, 256, P["b.fh2w"], P["b.fh2b"], ws.c1b, ws.delta_b)
         d = []
         if mask_a:
             d.append(P["a.m2"].desc(ws.mh_a, 0, 256, ws.mask_a, 0, EPI_LINEAR, scale=0.25))
         if mask_b and need_b:
             d.append(P["b.m2"].desc(ws.mh_b, 0, 256, ws.mask_b, 0, EPI_LINEAR, scale=0.25))
-        if d:
-            conv(d)
+        if self.side is not None and (need_b or d):
+            # three independent tails of the heads: flow_out A | flow_out B | mask convs
+            main = torch.cuda.current_stream()
+            s1, s2 = self.side[0], self.side[1]
+            if need_b:
+                s1.wait_stream(main)
+                with torch.cuda.stream(s1):
+                    lib.flow_head_out(ws.fh_b, 256, P["b.fh2w"], P["b.fh2b"], ws.c1b, ws.delta_b)
+            if d:
+                s2.wait_stream(main)
+                with torch.cuda.stream(s2):
+                    lib.conv2d(d, B, H8, W8, like)
+            lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
+            if need_b:
+                main.wait_stream(s1)
+            if d:
+                main.wait_stream(s2)
+        else:
+            lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
+            if need_b:
+                lib.flow_head_out(ws.fh_b, 256, P["b.fh2w"], P["b.fh2b"], ws.c1b, ws.delta_b)
+            if d:
+                conv(d)
 
         return c
 

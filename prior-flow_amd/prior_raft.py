@@ -125,7 +125,7 @@ class PriOr_RAFT(nn.Module):
                 # is captured into the HIP graph as parallel branches) so that the latency-bound
                 # kernels of one (stem, statistics) hide behind the other's convolutions
                 cur = torch.cuda.current_stream()
-                s1, s2 = self._streams()
+                s1, s2 = self._streams()[:2]
                 s1.wait_stream(cur)
                 s2.wait_stream(cur)
                 with torch.cuda.stream(s1):
@@ -147,7 +147,7 @@ class PriOr_RAFT(nn.Module):
 
     def _streams(self):
         if self._side_streams is None:
-            self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
         return self._side_streams
 
     def _run(self, ws: Workspace, image1, image2, iters, init_flow, test_mode, out_a, out_b):
