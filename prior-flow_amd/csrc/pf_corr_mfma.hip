@@ -20,6 +20,7 @@
 //
 // Generic path (any H8,W8 % 8 == 0): same GEMM on 256 consecutive n2 columns, level 0 only;
 // levels 1..3 then come from a small pooling kernel.
+#include <type_traits>
 #include "pf_common.h"
 #include "../../include/priorflow_hip.h"
 
@@ -39,25 +40,67 @@ struct CorrArgs {
     float* lvl[4];
     int B, H, W, N, C;
     float inv_scale;      // sqrt(C): level0 = acc / inv_scale
+    float scale_mul;      // 1/sqrt(C) when that is exact (sqrt(C) a power of two: C = 256), else 0 -> true division
     int tiles_x;          // W/32 (fused path)
     int n2_tiles;         // number of n2 tiles per batch element
+    int m_tiles;          // number of 128-row n1 tiles per batch element
 };
+
+// value of lane (lane ^ 1), (lane ^ 2) [quad permutes] or (lane + 4) [row shift] without the LDS
+// crossbar: the pooling partners of the consuming lanes (x2 even / multiple of 4 / of 8) always
+// sit in the same 16-lane DPP row.  The first version used __shfl_down (ds_bpermute + lgkmcnt wait,
+// 224 per wave) and was VALU/latency bound in its store phase.
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+#ifdef PF_ABLATE_NO_POOL_STORE
+constexpr bool PF_POOL_STORE = false;
+#else
+constexpr bool PF_POOL_STORE = true;
+#endif
+constexpr int DPP_XOR1 = 0xB1;      // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;      // quad_perm [2,3,0,1]
+constexpr int DPP_SHL4 = 0x104;     // row_shl:4  (lane i <- lane i+4)
 
 // SPLIT: operands are pre-split bf16 hi|lo rows (pf_split_bf16; same row stride / chunk offsets in
 // bytes as the fp32 rows, so staging is the same 16-byte copy) and the products run as
 // hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (3/16 of the exact-fp32 MFMA time).
+//
+// Occupancy: the kernel is a short GEMM (K = C = 256: 8 K-steps) followed by a long store phase
+// (128 x 256 outputs + pooled levels = 170 KB per workgroup, ~as long as the GEMM).  With
+// double-buffered operand tiles (110 KB of LDS) only one workgroup fitted a CU, so all 256 CUs
+// alternated in lock-step between an MFMA phase with HBM idle and a store phase with the matrix
+// cores idle (223 us per 373 MB launch = 21 % of the HBM peak).  The tiles are therefore SINGLE
+// buffered (55 KB, two barriers per K-step): two workgroups share a CU and one's store phase
+// runs under the other's GEMM; the second workgroup also fills the extra barrier's bubble.
 template <bool FUSED_POOL, bool SPLIT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 pf_corr_kernel(const CorrArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float As[1][BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[1][BN * LDS_LD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.z;
-    const int m0 = blockIdx.x * BM;
-    const int tile = blockIdx.y;
+    // XCD-aware work mapping.  Workgroup ids go round-robin over the 8 XCDs (id % 8), each with its
+    // own L2.  A pooled level's 128-byte line is completed by the 2 (level 1), 4 (level 2) or
+    // 4 x 2 (level 3) neighbouring n2 tiles of the same n1 rows, and the operand rows of f2 are
+    // shared by the tiles of one n2 block: each XCD owns a contiguous range of the work sequence
+    // q = ((b * m_tiles + m) * n2_tiles + tile), tile fastest, so line-mates and operand sharers
+    // run back to back on one XCD.  (Measured neutral on the launch time: the store phase is bound
+    // by the NUMBER of 4-byte-per-lane store instructions -- ~20 cycles each per CU; the pooled
+    // levels are 47 % of them for 24 % of the bytes -- not by partial-line write-backs.)
+    int b, m0, tile;
+    {
+        const unsigned nwg = gridDim.x, orig = blockIdx.x;
+        const unsigned xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;     // bijective for any nwg
+        const unsigned q = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+        tile = (int)(q % (unsigned)a.n2_tiles);
+        const unsigned mt = q / (unsigned)a.n2_tiles;
+        m0 = (int)(mt % (unsigned)a.m_tiles) * BM;
+        b = (int)(mt / (unsigned)a.m_tiles);
+    }
     // n2 of local column col (0..255)
     int ty0 = 0, tx0 = 0;
     if (FUSED_POOL) { ty0 = (tile / a.tiles_x) * 8; tx0 = (tile % a.tiles_x) * 32; }
@@ -71,17 +114,17 @@ pf_corr_kernel(const CorrArgs a) {
     const int c4 = (tid & 7) * 4;
     constexpr int A_V4 = BM * 8 / 256;   // 4
     constexpr int B_V4 = BN * 8 / 256;   // 8
-    long a_src[A_V4], b_src[B_V4];       // row offsets (floats) or -1
+    int a_src[A_V4], b_src[B_V4];        // row offsets (floats; N*C < 2^31 is checked by the launcher) or -1
 #pragma unroll
     for (int q = 0; q < A_V4; ++q) {
         const int r = (tid + 256 * q) >> 3;
-        a_src[q] = (m0 + r < a.N) ? (long)(m0 + r) * a.C : -1;
+        a_src[q] = (m0 + r < a.N) ? (m0 + r) * a.C : -1;
     }
 #pragma unroll
     for (int q = 0; q < B_V4; ++q) {
         const int r = (tid + 256 * q) >> 3;
         const int n2 = n2_of(r);
-        b_src[q] = (n2 < a.N) ? (long)n2 * a.C : -1;
+        b_src[q] = (n2 < a.N) ? n2 * a.C : -1;
     }
     f32x4 ra[A_V4], rb[B_V4];
     auto load_step = [&](int step) __attribute__((always_inline)) {
@@ -112,13 +155,18 @@ pf_corr_kernel(const CorrArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+#ifdef PF_ABLATE_NO_GEMM                // timing-only builds (profiles/): store phase alone / GEMM alone
+    const int nsteps = a.C > (1 << 20) ? a.C / KC : 0;
+#else
     const int nsteps = a.C / KC;
+#endif
     const int a_off = (32 * wave + li) * LDS_LD + 16 * lh;
     const int b_off = li * LDS_LD + 16 * lh;
 
     load_step(0);
     for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
+        constexpr int buf = 0;
+        if (step) __syncthreads();       // every wave has read the previous step's fragments
         store_step(buf);
         __syncthreads();
         // unconditional prefetch (the last one re-reads the final K-step; never stored)
@@ -177,6 +225,9 @@ pf_corr_kernel(const CorrArgs a) {
     // acc[t][r]: n1 = m0 + 32*wave + (r&3) + 8*(r>>2) + 4*lh ; n2 column = 32*t + li
     const long N = a.N;
     float* l0 = a.lvl[0] + (long)b * N * N;
+#ifdef PF_ABLATE_NO_STORE
+    if (acc[0][0] != 123.456f) return;
+#endif
     if (!FUSED_POOL) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -192,47 +243,58 @@ pf_corr_kernel(const CorrArgs a) {
     }
     const int W1 = a.W >> 1, W2 = a.W >> 2, W3 = a.W >> 3;
     const long N1 = N >> 2, N2 = N >> 4, N3 = N >> 6;
-    float* l1 = a.lvl[1] + (long)b * N * N1;
-    float* l2 = a.lvl[2] + (long)b * N * N2;
-    float* l3 = a.lvl[3] + (long)b * N * N3;
+    const bool use_mul = a.scale_mul != 0.f;
+    // per-lane column offsets inside a row of each level (the row bases below are per n1)
+    const int c0 = ty0 * a.W + tx0 + li;
+    const int c1 = (ty0 >> 1) * W1 + ((tx0 + li) >> 1);
+    const int c2 = (ty0 >> 2) * W2 + ((tx0 + li) >> 2);
+    const int c3 = (ty0 >> 3) * W3 + ((tx0 + li) >> 3);
+    const long row0 = (long)b * N + m0 + 32 * wave + 4 * lh;      // n1 of r = 0, batch folded in
+    auto store_rows = [&](auto MUL) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int n1 = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;   // < N: BM divides N here
+        const long row = row0 + (r & 3) + 8 * (r >> 2);           // < B*N: BM divides N here
+        float* p0 = a.lvl[0] + row * N + c0;
+        float* p1o = a.lvl[1] + row * N1 + c1;
+        float* p2o = a.lvl[2] + row * N2 + c2;
+        float* p3o = a.lvl[3] + row * N3 + c3;
         float v[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            v[t] = acc[t][r] / a.inv_scale;
-            l0[(long)n1 * N + (long)(ty0 + t) * a.W + tx0 + li] = v[t];
+            v[t] = decltype(MUL)::value ? acc[t][r] * a.scale_mul : acc[t][r] / a.inv_scale;
+            p0[t * a.W] = v[t];
         }
         // level 1: ((v00 + v01) + v10) + v11, * 0.25  (avg_pool2d order: row-major window sum)
         float p1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float top = v[2 * u], bot = v[2 * u + 1];
-            float s = top + __shfl_down(top, 1);
+            float s = top + dpp_get<DPP_XOR1>(top);
             s = s + bot;
-            s = s + __shfl_down(bot, 1);
+            s = s + dpp_get<DPP_XOR1>(bot);
             p1[u] = s * 0.25f;
-            if ((li & 1) == 0) l1[(long)n1 * N1 + (long)((ty0 >> 1) + u) * W1 + ((tx0 + li) >> 1)] = p1[u];
+            if (PF_POOL_STORE && (li & 1) == 0) p1o[u * W1] = p1[u];
         }
         float p2[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const float top = p1[2 * u], bot = p1[2 * u + 1];
-            float s = top + __shfl_down(top, 2);
+            float s = top + dpp_get<DPP_XOR2>(top);
             s = s + bot;
-            s = s + __shfl_down(bot, 2);
+            s = s + dpp_get<DPP_XOR2>(bot);
             p2[u] = s * 0.25f;
-            if ((li & 3) == 0) l2[(long)n1 * N2 + (long)((ty0 >> 2) + u) * W2 + ((tx0 + li) >> 2)] = p2[u];
+            if (PF_POOL_STORE && (li & 3) == 0) p2o[u * W2] = p2[u];
         }
         {
             const float top = p2[0], bot = p2[1];
-            float s = top + __shfl_down(top, 4);
+            float s = top + dpp_get<DPP_SHL4>(top);
             s = s + bot;
-            s = s + __shfl_down(bot, 4);
-            if ((li & 7) == 0) l3[(long)n1 * N3 + (long)(ty0 >> 3) * W3 + ((tx0 + li) >> 3)] = s * 0.25f;
+            s = s + dpp_get<DPP_SHL4>(bot);
+            if ((li & 7) == 0) p3o[0] = s * 0.25f;   // (kept in the no-pool-store ablation: keeps the chain alive)
         }
     }
+    };
+    if (use_mul) store_rows(std::true_type{}); else store_rows(std::false_type{});
 }
 
 // 2x2 mean of one level into the next (generic path only)
@@ -261,24 +323,33 @@ static int corr_launch(const float* f1, const float* f2, float* lvl0, float* lvl
     if (!f1 || !f2 || !lvl0 || !lvl1 || !lvl2 || !lvl3) return PF_ERR_BAD_ARG;
     if (B <= 0 || H8 <= 0 || W8 <= 0 || C <= 0 || (C % KC) != 0) return PF_ERR_BAD_SHAPE;
     if ((H8 % 8) != 0 || (W8 % 8) != 0) return PF_ERR_BAD_SHAPE;
+    if ((long)H8 * W8 * C >= (1L << 31)) return PF_ERR_BAD_SHAPE;      // 32-bit row offsets in the kernel
+    if ((long)B * ((H8 * W8 + BM - 1) / BM) * ((H8 * W8 + 31) / 32) >= (1L << 31)) return PF_ERR_BAD_SHAPE;   // 1-D grid
     CorrArgs a;
     a.f1 = f1; a.f2 = f2;
     a.lvl[0] = lvl0; a.lvl[1] = lvl1; a.lvl[2] = lvl2; a.lvl[3] = lvl3;
     a.B = B; a.H = H8; a.W = W8; a.N = H8 * W8; a.C = C;
     a.inv_scale = sqrtf((float)C);
+    {   // x / 2^k == x * 2^-k bit for bit; any other divisor keeps the reference's division
+        int e = 0;
+        const float m = frexpf(a.inv_scale, &e);
+        a.scale_mul = (m == 0.5f && a.inv_scale * a.inv_scale == (float)C) ? 1.f / a.inv_scale : 0.f;
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool fused = (W8 % 32) == 0 && (a.N % BM) == 0;
     if (fused) {
         a.tiles_x = W8 / 32;
         a.n2_tiles = (H8 / 8) * a.tiles_x;
-        dim3 grid((unsigned)(a.N / BM), (unsigned)a.n2_tiles, (unsigned)B);
+        a.m_tiles = a.N / BM;
+        dim3 grid((unsigned)((long)a.m_tiles * a.n2_tiles * B));
         if (split) hipLaunchKernelGGL((pf_corr_kernel<true, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((pf_corr_kernel<true, false>), grid, dim3(256), 0, s, a);
         return (int)hipGetLastError();
     }
     a.tiles_x = 0;
     a.n2_tiles = (a.N + BN - 1) / BN;
-    dim3 grid((unsigned)((a.N + BM - 1) / BM), (unsigned)a.n2_tiles, (unsigned)B);
+    a.m_tiles = (a.N + BM - 1) / BM;
+    dim3 grid((unsigned)((long)a.m_tiles * a.n2_tiles * B));
     if (split) hipLaunchKernelGGL((pf_corr_kernel<false, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((pf_corr_kernel<false, false>), grid, dim3(256), 0, s, a);
     int rc = (int)hipGetLastError();

@@ -21,6 +21,19 @@ for r in seg:
     agg[key][1] += d
 tot = sum(v[1] for v in agg.values())
 span = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e3
-print(f"# forward {k}: kernels {len(seg)}, span {span:.1f} us, busy {tot:.1f} us")
+# union of busy intervals: time during which at least one kernel is running; the rest is idle gaps
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in seg)
+union, gaps, cur_s, cur_e = 0, [], iv[0][0], iv[0][1]
+for a, b in iv[1:]:
+    if a > cur_e:
+        union += cur_e - cur_s
+        gaps.append((a - cur_e) / 1e3)
+        cur_s, cur_e = a, b
+    else:
+        cur_e = max(cur_e, b)
+union += cur_e - cur_s
+print(f"# forward {k}: kernels {len(seg)}, span {span:.1f} us, sum of kernel durations {tot:.1f} us, "
+      f"GPU non-idle {union / 1e3:.1f} us, idle {span - union / 1e3:.1f} us in {len(gaps)} gaps "
+      f"(median {sorted(gaps)[len(gaps) // 2] if gaps else 0:.1f} us, max {max(gaps) if gaps else 0:.1f} us)")
 for name, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-102s n=%4d  %9.1f us  avg %8.1f us  %5.1f%%" % (name, v[0], v[1], v[1] / v[0], 100 * v[1] / tot))
