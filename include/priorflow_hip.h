@@ -195,6 +195,21 @@ int pf_to_channel_last(const float* in, int c_total, int c_begin, int c, float* 
  * which pf_conv2d then runs as a 4x4 stride-1 convolution over the 12 stacked channels. */
 int pf_space_to_depth2(const float* in, int C, float* out, int ld_out, int B, int H, int W, void* stream);
 
+/* ---- evaluation counterpart ---------------------------------------------- */
+
+/* Per-pixel EPE (evaluate.py:265 `torch.sum((flow - flow_gt)**2, dim=0).sqrt()`) and SEPE
+ * (core/utils/spherical.py:20-53 `calculate_great_circle_distance`, method 'Haversine', R = 1) of
+ * pred vs gt, both NCHW [B,2,H,W].  epe / sd: [B,H,W]; either may be NULL. */
+int pf_flow_metrics(const float* pred, const float* gt, float* epe, float* sd, int B, int H, int W,
+                    void* stream);
+
+/* Region sums of evaluate.py:246-275 (All / Equator / Poles / Center ...): bit r of bits[n] puts
+ * pixel n into region r (nregions <= 8).  weight: [N] cos-latitude weights (evaluate.py:208-213
+ * `sd_uni`) or NULL.  partials: double [B][nblk][nregions][3] = per pixel-chunk sums of
+ * epe, sd, sd*weight; the caller adds the nblk chunks (deterministic two-stage sum). */
+int pf_region_sums(const float* epe, const float* sd, const float* weight, const unsigned char* bits,
+                   int nregions, double* partials, int nblk, int B, int N, void* stream);
+
 /* channel-last slice -> NCHW. */
 int pf_to_nchw(const float* in, int ld_in, int off_in, int c, float* out, int B, int N,
                void* stream);

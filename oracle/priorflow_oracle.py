@@ -444,3 +444,87 @@ def forward(p: Mapping[str, Tensor], image1: Tensor, image2: Tensor, iters: int 
 def epe(a: Tensor, b: Tensor) -> Tensor:
     """Per-pixel end-point error between two flow fields [B,2,H,W]."""
     return torch.sqrt(((a - b) ** 2).sum(dim=1))
+
+
+# --------------------------------------------------------------------------------------
+# evaluation counterpart (SURVEY.md §8f-2): SEPE, region masks, region metrics
+# --------------------------------------------------------------------------------------
+def _endpoint_sph(flow: Tensor) -> Tuple[Tensor, Tensor]:
+    """(theta, phi) [B,H,W] of the end points of `flow` [B,2,H,W]: x wraps, y clamps
+    (core/utils/projection_prim_ortho.py:200-218 `flow2endpoint`, :397-411 `plane2spherical`)."""
+    B, _, H, W = flow.shape
+    g = coords_grid(B, H, W)
+    e0 = pymod(g[:, 0] + flow[:, 0] + 0.5, W) - 0.5
+    e1 = torch.clamp(g[:, 1] + flow[:, 1], min=-0.5, max=H - 0.5)
+    theta = ((e0 + 0.5) / W - 0.5) * 2 * math.pi
+    phi = (0.5 - (e1 + 0.5) / H) * math.pi
+    return theta, phi
+
+
+def _haversine(x: Tensor) -> Tensor:
+    """core/utils/spherical.py:73-77."""
+    return torch.square(torch.sin(x / 2))
+
+
+def great_circle_distance(pre: Tensor, gt: Tensor) -> Tensor:
+    """SEPE: haversine great-circle distance [B,H,W] between the end points of two flow fields on
+    the unit sphere (core/utils/spherical.py:20-53, method='Haversine', R=1; :80-84 inverse)."""
+    tp, pp = _endpoint_sph(pre)
+    tg, pg = _endpoint_sph(gt)
+    hav = _haversine(pg - pp) + torch.cos(pp) * torch.cos(pg) * _haversine(tg - tp)
+    return 2 * torch.arcsin(torch.sqrt(hav))
+
+
+def spherical_mask(H: int, W: int) -> Tensor:
+    """cos(latitude) weights normalised to sum 1 (core/utils/spherical.py:11-17)."""
+    n = torch.arange(0, H).view(-1, 1).repeat(1, W)
+    phi = (0.5 - (n + 0.5) / H) * math.pi
+    m = torch.cos(phi)
+    return m / m.sum()
+
+
+def generate_polemask(H: int, W: int, delta_phi: float = math.pi / 2) -> Tuple[Tensor, Tensor]:
+    """(pole_mask_A, pole_mask_B) as long [1,H,W] (core/utils/polemask.py:7-26): A = rows outside
+    the +-delta_phi/2 band; B = A seen from view B (img_A2B = img_rotate with Rx(-pi/2),
+    core/utils/projection_prim_ortho.py:517-519), binarised at 0.5."""
+    import numpy as np
+    phi2n = lambda phi: (0.5 - phi / np.pi) * H - 0.5                       # noqa: E731  (:317-327)
+    min_n = int(np.round(phi2n(delta_phi / 2)))
+    max_n = int(np.round(phi2n(-delta_phi / 2)))
+    center = torch.zeros((1, H, W))
+    center[:, min_n:max_n, :] = 1
+    pole_a = 1 - center
+    pole_b = img_rotate(pole_a.unsqueeze(1), sample_grid(H, W, rotation_x(-math.pi / 2))).squeeze(1)
+    pole_b = torch.where(pole_b < 0.5, torch.zeros_like(pole_b), pole_b)
+    pole_b = torch.where(pole_b > 0, torch.ones_like(pole_b), pole_b)
+    return pole_a.long(), pole_b.long()
+
+
+def region_masks(H: int, W: int) -> Dict[str, Tensor]:
+    """Boolean [H*W] masks of evaluate.py:246-254: All / Equator / Poles / Center."""
+    pole, center = generate_polemask(H, W)
+    return {"All": torch.ones(H * W, dtype=torch.bool),
+            "Equator": (1 - pole).view(-1) >= 0.5,
+            "Poles": pole.view(-1) >= 0.5,
+            "Center": center.view(-1) >= 0.5}
+
+
+def region_metrics(preds: Sequence[Tensor], gts: Sequence[Tensor]) -> Dict[str, Dict[str, float]]:
+    """evaluate.py:234-282 on a list of (flow [2,H,W], flow_gt [2,H,W]) pairs: per region the mean EPE
+    and mean SEPE over every masked pixel of every sample, plus the cos-latitude weighted SEPE
+    `sd_uni` of :208-213 (per-image weighted mean, then mean over images)."""
+    H, W = preds[0].shape[-2:]
+    masks = region_masks(H, W)
+    uni = spherical_mask(H, W).view(-1)
+    out = {}
+    for name, mk in masks.items():
+        e_all, s_all, u_all = [], [], []
+        for p, g in zip(preds, gts):
+            e = epe(p[None], g[None])[0].view(-1)
+            s = great_circle_distance(p[None], g[None])[0].view(-1)
+            e_all.append(e[mk]); s_all.append(s[mk])
+            u_all.append(float(((s * uni)[mk] / uni[mk].sum()).sum()))
+        out[name] = {"epe": float(torch.cat(e_all).double().mean()),
+                     "sd": float(torch.cat(s_all).double().mean()),
+                     "sd_uni": float(sum(u_all) / len(u_all))}
+    return out

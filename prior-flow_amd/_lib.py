@@ -63,6 +63,8 @@ _SIGNATURES = {
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
     "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
+    "pf_flow_metrics": [_fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pf_region_sums": [_fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
 }
 EXPORTS = ["pf_version"] + list(_SIGNATURES)
 
@@ -282,6 +284,29 @@ class PfLib:
         self._rc(self._dll.pf_space_to_depth2(_ptr(x), C, _ptr(out), out.shape[-1], B, H, W, self._stream(x)),
                  "pf_space_to_depth2")
         return out
+
+    def flow_metrics(self, pred, gt, epe=None, sd=None):
+        """pred, gt: NCHW [B,2,H,W]; epe / sd: [B,H,W] outputs (either optional)."""
+        self._chk(pred, gt, epe, sd)
+        B, _, H, W = pred.shape
+        if gt.shape != pred.shape:
+            raise PfError("flow_metrics: pred and gt must have the same shape")
+        self._rc(self._dll.pf_flow_metrics(_ptr(pred), _ptr(gt), _ptr(epe), _ptr(sd), B, H, W, self._stream(pred)),
+                 "pf_flow_metrics")
+
+    def region_sums(self, epe, sd, weight, bits, nregions, partials):
+        """epe, sd: [B,H,W]; weight: [H*W] or None; bits: uint8 [H*W]; partials: float64 [B,nblk,nregions,3]."""
+        self._chk(epe, sd, weight)
+        if bits.dtype != torch.uint8 or partials.dtype != torch.float64 or not bits.is_contiguous() \
+                or not partials.is_contiguous():
+            raise PfError("region_sums: bits must be contiguous uint8, partials contiguous float64")
+        B = epe.shape[0]
+        N = epe[0].numel()
+        if bits.numel() != N or partials.shape[0] != B or partials.shape[2] != nregions or partials.shape[3] != 3:
+            raise PfError("region_sums: shape mismatch")
+        self._rc(self._dll.pf_region_sums(_ptr(epe), _ptr(sd), _ptr(weight), C.c_void_p(bits.data_ptr()), nregions,
+                                          C.c_void_p(partials.data_ptr()), partials.shape[1], B, N,
+                                          self._stream(epe)), "pf_region_sums")
 
     def to_nchw(self, x, off_in, c, out):
         self._chk(x, out)

@@ -501,6 +501,47 @@ PF_HD void pf_s2d_elem(long idx, const PfS2dArgs& a) {           // idx over B*(
     a.out[pix * a.ld_out + cc] = a.in[((b * a.C + c) * a.H + 2 * Y + py) * (long)a.W + 2 * X + px];
 }
 
+// ----------------------------------------------------------------------------------------------
+// Evaluation counterpart: per-pixel EPE and SEPE of a predicted flow against the
+// ground truth.  EPE = |flow - gt| (evaluate.py:265); SEPE = haversine great-circle distance on the
+// unit sphere between the two END POINTS (core/utils/spherical.py:20-53, method 'Haversine'):
+// end point x wraps, y clamps (core/utils/projection_prim_ortho.py:200-218), pixel -> (theta, phi)
+// by ERP.plane2spherical (:397-411).
+// ----------------------------------------------------------------------------------------------
+struct PfFlowMetricsArgs { const float* pred; const float* gt; float* epe; float* sd; int B, H, W; };
+PF_HD void pf_endpoint_sph(float x, float y, float u, float v, int H, int W, float& theta, float& phi) {
+    const float pi = 3.14159265358979323846f;
+    const float e0 = pf_pymod(x + u + 0.5f, (float)W) - 0.5f;
+    float e1 = y + v;
+    e1 = e1 < -0.5f ? -0.5f : (e1 > (float)H - 0.5f ? (float)H - 0.5f : e1);
+    theta = (((e0 + 0.5f) / (float)W - 0.5f) * 2.f) * pi;
+    phi = (0.5f - (e1 + 0.5f) / (float)H) * pi;
+}
+PF_HD float pf_haversine(float x) { const float s = sinf(x / 2.f); return s * s; }
+PF_HD void pf_flow_metrics_elem(long idx, const PfFlowMetricsArgs& a) {   // idx over B*H*W
+    const long N = (long)a.H * a.W;
+    const long b = idx / N, n = idx % N;
+    const float x = (float)(n % a.W), y = (float)(n / a.W);
+    const float pu = a.pred[(b * 2 + 0) * N + n], pv = a.pred[(b * 2 + 1) * N + n];
+    const float gu = a.gt[(b * 2 + 0) * N + n], gv = a.gt[(b * 2 + 1) * N + n];
+    const float du = pu - gu, dv = pv - gv;
+    if (a.epe) a.epe[idx] = sqrtf(du * du + dv * dv);
+    if (a.sd) {
+        float tp, pp, tg, pg;
+        pf_endpoint_sph(x, y, pu, pv, a.H, a.W, tp, pp);
+        pf_endpoint_sph(x, y, gu, gv, a.H, a.W, tg, pg);
+        const float hv = pf_haversine(pg - pp) + (cosf(pp) * cosf(pg)) * pf_haversine(tg - tp);
+        a.sd[idx] = 2.f * asinf(sqrtf(hv));
+    }
+}
+
+// Region sums (evaluate.py:246-275): pixel n belongs to region r when bit r of bits[n] is set.
+// partials[((b*nblk + k)*R + r)*3 + {0,1,2}] = sum epe, sum sd, sum sd*weight over block k's pixels.
+struct PfRegionSumArgs {
+    const float* epe; const float* sd; const float* weight; const unsigned char* bits;
+    double* partials; int B, N, R, nblk;
+};
+
 // channel-last -> NCHW (debug / boundary export)
 struct PfToNchwArgs { const float* in; float* out; int B, C, N, ld_in, c_in_off; };
 PF_HD void pf_to_nchw_elem(long idx, const PfToNchwArgs& a) {   // idx over B*C*N

@@ -378,8 +378,49 @@ int launch_flow_out(const PfFlowOutArgs& a, long total, void* stream) {
     return pf_launch_elem<PfFlowOutArgs, pf_flow_out_elem>(a, total, stream);
 }
 
+// Region sums: one block per (pixel chunk k, image b); per-thread fp64 accumulators for up to 8
+// regions, wave shuffle reduction, then LDS across the 4 waves.  Deterministic (no atomics): the
+// host adds the nblk partials.
+__global__ void __launch_bounds__(256) pf_region_sum_kernel(const PfRegionSumArgs a) {
+    __shared__ double red[4][8 * 3];
+    const int k = blockIdx.x, b = blockIdx.y;
+    const int chunk = (a.N + a.nblk - 1) / a.nblk;
+    const int lo = k * chunk, hi = (lo + chunk < a.N) ? lo + chunk : a.N;
+    double acc[8][3];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { acc[r][0] = 0; acc[r][1] = 0; acc[r][2] = 0; }
+    for (int n = lo + threadIdx.x; n < hi; n += 256) {
+        const double e = a.epe[(long)b * a.N + n], s = a.sd[(long)b * a.N + n];
+        const double sw = a.weight ? s * (double)a.weight[n] : 0.0;
+        const unsigned bits = a.bits[n];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if ((bits >> r) & 1u) { acc[r][0] += e; acc[r][1] += s; acc[r][2] += sw; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double v = acc[r][j];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0) red[wave][r * 3 + j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < a.R * 3) {
+        const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        a.partials[((long)(b * a.nblk + k) * a.R) * 3 + threadIdx.x] = v;
+    }
+}
+
+int launch_region_sums(const PfRegionSumArgs& a, void* stream) {
+    hipLaunchKernelGGL(pf_region_sum_kernel, dim3((unsigned)a.nblk, (unsigned)a.B), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
+#define PF_REGION_SUM_LAUNCH(a, stream) launch_region_sums(a, stream)
 #define PF_FLOW_OUT_LAUNCH(a, total, stream) launch_flow_out(a, total, stream)
 #define PF_NORM_ACT_LAUNCH(a, total, stream) launch_norm_act(a, total, stream)
 #define PF_STATS_LAUNCH launch_stats

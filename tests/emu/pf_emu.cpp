@@ -14,6 +14,25 @@ static int pf_loop(const Args& a, long total) {
 #define PF_LAUNCH(name, args, total, stream) pf_loop<decltype(args), pf_##name##_elem>(args, total)
 #define PF_DIRECT_CONV_LAUNCH(a, total, stream) pf_loop<PfDirectConvArgs, pf_direct_conv_elem>(a, total)
 
+// host statement of pf_region_sums (same block partition, sequential sums inside a block)
+static int emu_region_sums(const PfRegionSumArgs& a, void*) {
+    const int chunk = (a.N + a.nblk - 1) / a.nblk;
+    for (int b = 0; b < a.B; ++b)
+        for (int k = 0; k < a.nblk; ++k)
+            for (int r = 0; r < a.R; ++r) {
+                double s0 = 0, s1 = 0, s2 = 0;
+                for (int n = k * chunk; n < (k + 1) * chunk && n < a.N; ++n)
+                    if ((a.bits[n] >> r) & 1u) {
+                        const double e = a.epe[(long)b * a.N + n], s = a.sd[(long)b * a.N + n];
+                        s0 += e; s1 += s; s2 += a.weight ? s * (double)a.weight[n] : 0.0;
+                    }
+                double* o = a.partials + ((long)(b * a.nblk + k) * a.R + r) * 3;
+                o[0] = s0; o[1] = s1; o[2] = s2;
+            }
+    return PF_OK;
+}
+#define PF_REGION_SUM_LAUNCH(a, stream) emu_region_sums(a, stream)
+
 // host statement of pf_channel_stats (same fp64 two-stage sums as the device kernels)
 static int emu_stats(const float* y, int B, int Np, int C, float eps, float* scale, float* shift, double* part,
                      int nblk, void*) {

@@ -341,7 +341,38 @@ def case_bad_args(lib, dev):
         raise AssertionError("expected PfError for an image below the smallest legal size")
 
 
+def case_flow_metrics(lib, dev):
+    """EPE / SEPE per pixel and the region sums (evaluate.py:246-275) vs the oracle."""
+    pre, gt = gc.flows("eval/pre", 2), gc.flows("eval/gt", 2)
+    pre[:, 1, 3, :] = -9.0                        # end points clamped at the top edge
+    gt[0, :, 4, :] = pre[0, :, 4, :]              # identical flows -> exactly zero distance
+    B, _, h, w = pre.shape
+    epe = torch.empty(B, h, w, device=dev)
+    sd = torch.empty(B, h, w, device=dev)
+    lib.flow_metrics(pre.to(dev), gt.to(dev), epe, sd)
+    check(epe, po.epe(pre, gt), 1e-6, "epe")
+    check(sd, po.great_circle_distance(pre, gt), 2e-6, "sepe")
+    assert float(sd[0, 4].abs().max()) == 0.0 and float(epe[0, 4].abs().max()) == 0.0
+    only = torch.empty(B, h, w, device=dev)
+    lib.flow_metrics(pre.to(dev), gt.to(dev), None, only)      # either output is optional
+    check(only, sd, 0.0, "sd only")
+    # region sums: 3 overlapping regions, weights, 5 pixel chunks (ragged last chunk)
+    n = h * w
+    bits = torch.zeros(n, dtype=torch.uint8)
+    bits[:] = 1
+    bits[: n // 3] |= 2
+    bits[n // 2:] |= 4
+    wts = gc.uni("eval/w", (n,), 0.0, 1.0)
+    part = torch.zeros(B, 5, 3, 3, dtype=torch.float64, device=dev)
+    lib.region_sums(epe, sd, wts.to(dev), bits.to(dev), 3, part)
+    got = part.sum(1).cpu()
+    e64, s64 = epe.cpu().double().view(B, n), sd.cpu().double().view(B, n)
+    for r, mk in enumerate([(bits & 1) > 0, (bits & 2) > 0, (bits & 4) > 0]):
+        want = torch.stack([e64[:, mk].sum(1), s64[:, mk].sum(1), (s64 * wts.double())[:, mk].sum(1)], 1)
+        assert float((got[:, r] - want).abs().max()) < 1e-9, ("region_sums", r)
+
+
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
-                     case_bad_args]
+                     case_flow_metrics, case_bad_args]

@@ -242,3 +242,34 @@ def test_forward_demo_config1(params):
     out = po.forward(params, d1, d2, iters=4, test_mode=True)
     mean, mx = _epe_stats(out[:, :, ::2, ::2], g["out"])
     assert mean < NOISE, (mean, mx)
+
+
+# ---- evaluation counterpart: oracle vs the reference's own helpers -------------
+def test_eval_sepe_and_masks():
+    g = gc.load("eval")
+    pre, gt = gc.flows("eval/pre", 2), gc.flows("eval/gt", 2)
+    close(po.great_circle_distance(pre, gt), g["sd_rand"], 0.0, what="SEPE random flows")
+    kat = torch.zeros(1, 2, 64, 128)
+    kat[:, 0] = 4.0
+    sd = po.great_circle_distance(kat, torch.zeros_like(kat))[0, :, 0]
+    close(sd, g["sd_kat"], 0.0, what="SEPE +4 px u-flow")
+    assert abs(float(sd[31]) - 0.19629) < 1e-5            # SURVEY.md 8c known answer at the equator row
+    for h, w, na, nb in ((16, 32, 256, 104), (64, 128, 32 * 128, 1648)):
+        a, b = po.generate_polemask(h, w)
+        assert np.array_equal(a.numpy().astype(np.uint8), g[f"pole_a_{h}x{w}"])
+        assert np.array_equal(b.numpy().astype(np.uint8), g[f"pole_b_{h}x{w}"])
+        assert int(a.sum()) == na and int(b.sum()) == nb
+    u = po.spherical_mask(64, 128)
+    close(u[:, 0], g["uni_col"], 0.0, what="spherical_mask")
+    assert abs(float(u.double().sum()) - 1.0) < 1e-6 and abs(float(g["uni_sum"]) - 1.0) < 1e-6
+
+
+def test_eval_region_metrics():
+    """The arithmetic of evaluate.py:196-227 / :234-282 on fixed flows (reference numbers in eval.npz)."""
+    from gen_golden_eval import eval_samples
+    g = gc.load("eval")
+    s = eval_samples()
+    r = po.region_metrics([p for p, _ in s], [q for _, q in s])
+    for i, name in enumerate(("All", "Equator", "Poles", "Center")):
+        for j, key in enumerate(("epe", "sd", "sd_uni")):
+            assert abs(r[name][key] - g["regions"][i, j]) <= 2e-6 * abs(g["regions"][i, j]), (name, key)
