@@ -77,8 +77,9 @@ constexpr int DPP_SHL4 = 0x104;     // row_shl:4  (lane i <- lane i+4)
 template <bool FUSED_POOL, bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
 pf_corr_kernel(const CorrArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[1][BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[1][BN * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];     // operand tiles; re-used by the epilogue
+    float* const As = smem;                       // [BM][LDS_LD]
+    float* const Bs = smem + BM * LDS_LD;         // [BN][LDS_LD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -138,15 +139,15 @@ pf_corr_kernel(const CorrArgs a) {
             rb[q] = *reinterpret_cast<const f32x4*>(f2b + (b_src[q] >= 0 ? b_src[q] : 0) + c);
         }
     };
-    auto store_step = [&](int buf) __attribute__((always_inline)) {
+    auto store_step = [&](int) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < A_V4; ++q)
-            *reinterpret_cast<f32x4*>(&As[buf][((tid + 256 * q) >> 3) * LDS_LD + c4]) =
-                a_src[q] >= 0 ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&As[((tid + 256 * q) >> 3) * LDS_LD + c4]) =
+                (FUSED_POOL || a_src[q] >= 0) ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};     // fused path: every row exists
 #pragma unroll
         for (int q = 0; q < B_V4; ++q)
-            *reinterpret_cast<f32x4*>(&Bs[buf][((tid + 256 * q) >> 3) * LDS_LD + c4]) =
-                b_src[q] >= 0 ? rb[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&Bs[((tid + 256 * q) >> 3) * LDS_LD + c4]) =
+                (FUSED_POOL || b_src[q] >= 0) ? rb[q] : f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
     f32x16 acc[8];
@@ -174,42 +175,39 @@ pf_corr_kernel(const CorrArgs a) {
         asm volatile("" ::: "memory");   // keep the prefetch above the MFMA block (see pf_conv_mfma.hip)
         if constexpr (SPLIT) {
             // lane (row li, half lh) owns channels [16lh,16lh+16): bytes [32lh,32lh+32) of hi and of lo (+64)
-            const char* ap = reinterpret_cast<const char*>(&As[buf][a_off]) - 32 * lh;
+            const char* ap = reinterpret_cast<const char*>(&As[a_off]) - 32 * lh;
             bf16x8 fa[4];
             fa[0] = *reinterpret_cast<const bf16x8*>(ap);
             fa[1] = *reinterpret_cast<const bf16x8*>(ap + 16);
             fa[2] = *reinterpret_cast<const bf16x8*>(ap + 64);
             fa[3] = *reinterpret_cast<const bf16x8*>(ap + 80);
-            const char* bp0 = reinterpret_cast<const char*>(&Bs[buf][b_off]) - 32 * lh;
-            bf16x8 fb[2][4];      // register double buffer: tile t+1 is fetched during tile t's MFMAs
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                fb[0][q] = *reinterpret_cast<const bf16x8*>(bp0 + (q >> 1) * 64 + (q & 1) * 16);
+            const char* bp0 = reinterpret_cast<const char*>(&Bs[b_off]) - 32 * lh;
+            // (no register double buffer for the B fragments: the second workgroup of the CU hides the
+            // LDS round trip, and 16 more registers spilled inside this loop)
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                if (t + 1 < 8) {
-                    const char* bp = bp0 + (t + 1) * 32 * LDS_LD * 4;
+                const char* bp = bp0 + t * 32 * LDS_LD * 4;
+                bf16x8 fb[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        fb[(t + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(bp + (q >> 1) * 64 + (q & 1) * 16);
-                }
+                for (int q = 0; q < 4; ++q)
+                    fb[q] = *reinterpret_cast<const bf16x8*>(bp + (q >> 1) * 64 + (q & 1) * 16);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 + ks], fb[t & 1][ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[t & 1][2 + ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[t & 1][ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 + ks], fb[ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[2 + ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], acc[t], 0, 0, 0);
                 }
             }
         } else {
             f32x4 af[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(&As[buf][a_off + 4 * q]);
+            for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(&As[a_off + 4 * q]);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 f32x4 bf[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    bf[q] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_off + t * 32 * LDS_LD + 4 * q]);
+                    bf[q] = *reinterpret_cast<const f32x4*>(&Bs[b_off + t * 32 * LDS_LD + 4 * q]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[q].x, acc[t], 0, 0, 0);
@@ -241,60 +239,96 @@ pf_corr_kernel(const CorrArgs a) {
         }
         return;
     }
+    // Fused-pool epilogue.  The accumulator layout puts the target column on the lane and the query
+    // row in the register, so a direct store is 4 bytes per lane: 240 store instructions per wave,
+    // and the store phase was bound by their number (~20 cycles each per CU; timing-only builds:
+    // 82 us of stores, 46 us of them for the pooled levels' 24 % of the bytes).  Each wave therefore
+    // transposes its results through the (now idle) operand LDS: rows of the staging image are
+    // query rows, so a lane reads 16 contiguous bytes and a wave-store writes whole row segments --
+    // 32 + 8 + 2 + 1 = 43 store instructions per wave.  LDS traffic of one wave is processed in
+    // issue order, so the write -> read -> overwrite sequence on a wave-private region needs no barrier.
     const int W1 = a.W >> 1, W2 = a.W >> 2, W3 = a.W >> 3;
     const long N1 = N >> 2, N2 = N >> 4, N3 = N >> 6;
-    const bool use_mul = a.scale_mul != 0.f;
-    // per-lane column offsets inside a row of each level (the row bases below are per n1)
-    const int c0 = ty0 * a.W + tx0 + li;
-    const int c1 = (ty0 >> 1) * W1 + ((tx0 + li) >> 1);
-    const int c2 = (ty0 >> 2) * W2 + ((tx0 + li) >> 2);
-    const int c3 = (ty0 >> 3) * W3 + ((tx0 + li) >> 3);
-    const long row0 = (long)b * N + m0 + 32 * wave + 4 * lh;      // n1 of r = 0, batch folded in
-    auto store_rows = [&](auto MUL) __attribute__((always_inline)) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long row = row0 + (r & 3) + 8 * (r >> 2);           // < B*N: BM divides N here
-        float* p0 = a.lvl[0] + row * N + c0;
-        float* p1o = a.lvl[1] + row * N1 + c1;
-        float* p2o = a.lvl[2] + row * N2 + c2;
-        float* p3o = a.lvl[3] + row * N3 + c3;
-        float v[8];
+    __syncthreads();                               // every wave is done with the operand tiles
+    float* const stage = smem + wave * ((BM + BN) * LDS_LD / 4);      // 3456 floats per wave
+    const long row0 = (long)b * N + m0 + 32 * wave;                   // first query row of this wave (batch folded in)
+    auto epilogue = [&](auto MUL) __attribute__((always_inline)) {
+        auto scaled = [&](float x) { return decltype(MUL)::value ? x * a.scale_mul : x / a.inv_scale; };
+        // ---- level 0: one target row (t) at a time, two alternating 32 x 36 staging images --------
+        constexpr int S0 = 36;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            v[t] = decltype(MUL)::value ? acc[t][r] * a.scale_mul : acc[t][r] / a.inv_scale;
-            p0[t * a.W] = v[t];
-        }
-        // level 1: ((v00 + v01) + v10) + v11, * 0.25  (avg_pool2d order: row-major window sum)
-        float p1[4];
+            float* st = stage + (t & 1) * (32 * S0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float top = v[2 * u], bot = v[2 * u + 1];
-            float s = top + dpp_get<DPP_XOR1>(top);
-            s = s + bot;
-            s = s + dpp_get<DPP_XOR1>(bot);
-            p1[u] = s * 0.25f;
-            if (PF_POOL_STORE && (li & 1) == 0) p1o[u * W1] = p1[u];
-        }
-        float p2[2];
+            for (int r = 0; r < 16; ++r)
+                st[((r & 3) + 8 * (r >> 2) + 4 * lh) * S0 + li] = scaled(acc[t][r]);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float top = p1[2 * u], bot = p1[2 * u + 1];
-            float s = top + dpp_get<DPP_XOR2>(top);
-            s = s + bot;
-            s = s + dpp_get<DPP_XOR2>(bot);
-            p2[u] = s * 0.25f;
-            if (PF_POOL_STORE && (li & 3) == 0) p2o[u * W2] = p2[u];
+            for (int k = 0; k < 4; ++k) {
+                const int row = (lane >> 3) + 8 * k, piece = lane & 7;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * S0 + 4 * piece);
+                *reinterpret_cast<f32x4*>(a.lvl[0] + (row0 + row) * N + (long)(ty0 + t) * a.W + tx0 + 4 * piece) = v;
+            }
         }
-        {
-            const float top = p2[0], bot = p2[1];
-            float s = top + dpp_get<DPP_SHL4>(top);
-            s = s + bot;
-            s = s + dpp_get<DPP_SHL4>(bot);
-            if ((li & 7) == 0) p3o[0] = s * 0.25f;   // (kept in the no-pool-store ablation: keeps the chain alive)
+        // ---- pooled levels: DPP pooling in registers, staged per query row -------------------------
+        constexpr int S1 = 68, S2 = 20, S3 = 4;                       // padded row strides (floats)
+        float* const st1 = stage;                                     // [32][4 rows x 16 cols]
+        float* const st2 = stage + 32 * S1;                           // [32][2 x 8]
+        float* const st3 = st2 + 32 * S2;                             // [32][4]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = scaled(acc[t][r]);
+            // level 1: ((v00 + v01) + v10) + v11, * 0.25  (avg_pool2d order: row-major window sum)
+            float p1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float top = v[2 * u], bot = v[2 * u + 1];
+                float q = top + dpp_get<DPP_XOR1>(top);
+                q = q + bot;
+                q = q + dpp_get<DPP_XOR1>(bot);
+                p1[u] = q * 0.25f;
+                if ((li & 1) == 0) st1[row * S1 + u * 16 + (li >> 1)] = p1[u];
+            }
+            float p2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float top = p1[2 * u], bot = p1[2 * u + 1];
+                float q = top + dpp_get<DPP_XOR2>(top);
+                q = q + bot;
+                q = q + dpp_get<DPP_XOR2>(bot);
+                p2[u] = q * 0.25f;
+                if ((li & 3) == 0) st2[row * S2 + u * 8 + (li >> 2)] = p2[u];
+            }
+            {
+                const float top = p2[0], bot = p2[1];
+                float q = top + dpp_get<DPP_SHL4>(top);
+                q = q + bot;
+                q = q + dpp_get<DPP_SHL4>(bot);
+                if ((li & 7) == 0) st3[row * S3 + (li >> 3)] = q * 0.25f;
+            }
         }
-    }
+        if (PF_POOL_STORE) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {          // level 1: 32 rows x (4 x 64 B)
+                const int idx = lane + 64 * k, row = idx >> 4, u = (idx >> 2) & 3, xp = idx & 3;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(st1 + row * S1 + u * 16 + 4 * xp);
+                *reinterpret_cast<f32x4*>(a.lvl[1] + (row0 + row) * N1 + (long)((ty0 >> 1) + u) * W1 + (tx0 >> 1) + 4 * xp) = v;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {          // level 2: 32 rows x (2 x 32 B)
+                const int idx = lane + 64 * k, row = idx >> 2, u = (idx >> 1) & 1, xp = idx & 1;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(st2 + row * S2 + u * 8 + 4 * xp);
+                *reinterpret_cast<f32x4*>(a.lvl[2] + (row0 + row) * N2 + (long)((ty0 >> 2) + u) * W2 + (tx0 >> 2) + 4 * xp) = v;
+            }
+        }
+        if (lane < 32) {                           // level 3: 32 rows x 16 B
+            const f32x4 v = *reinterpret_cast<const f32x4*>(st3 + lane * S3);
+            *reinterpret_cast<f32x4*>(a.lvl[3] + (row0 + lane) * N3 + (long)(ty0 >> 3) * W3 + (tx0 >> 3)) = v;
+        }
     };
-    if (use_mul) store_rows(std::true_type{}); else store_rows(std::false_type{});
+    if (a.scale_mul != 0.f) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
 // 2x2 mean of one level into the next (generic path only)
