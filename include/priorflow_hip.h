@@ -130,6 +130,11 @@ typedef struct pf_conv_desc {
      * (the previous layer's Instance/BatchNorm folded into this conv): x' = relu?(x*s + t).
      * [B][c0+c1] floats each; NULL = none.  Halo-kernel convolutions only (3x3/1x5/5x1, bf16x3). */
     const float* in_scale; const float* in_shift; int in_relu;
+    /* optional InstanceNorm statistics of THIS conv's output, fused into its epilogue (halo-kernel
+     * tiles 3/4/5 with PF_EPI_LINEAR only): stats_out[((image*nblk + tile)*cout + c)*2 + {0,1}] =
+     * fp64 sum / sum of squares of output channel c over one workgroup tile, nblk = tiles per image =
+     * (H8/TH)*(W8/32), TH = 8 for tile 5 else 4.  Finish with pf_channel_stats_final.  NULL = none. */
+    double* stats_out;
 } pf_conv_desc;
 
 /* Launch `ngroups` (1..4) same-geometry convolutions in ONE kernel (grid.z = group):
@@ -156,6 +161,11 @@ int pf_conv2d_small(const float* in, int nchw, int ld_in, int off_in, int cin,
                     int kh, int kw, int stride, int relu, int B, int Hout, int Wout, void* stream);
 
 /* ---- encoder glue (core/extractor.py) ---------------------------------------------------------- */
+
+/* Second stage of pf_channel_stats on partials some other kernel produced (pf_conv2d with
+ * desc.stats_out): partials [B][nblk][C][2] doubles -> scale / shift [B][C]. */
+int pf_channel_stats_final(const double* partials, int B, int Np, int C, int nblk, float eps,
+                           float* scale, float* shift, void* stream);
 
 /* Per-(image, channel) InstanceNorm statistics of a channel-last map y [B*Np][C] (C <= 256):
  * scale[b][c] = 1/sqrt(var+eps), shift[b][c] = -mean*scale (biased variance).  Deterministic

@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("aux_out", _fp), ("ld_aux", _i),
         ("precision", _i), ("stride", _i),
         ("in_scale", _fp), ("in_shift", _fp), ("in_relu", _i),
+        ("stats_out", _fp),
     ]
 
 
@@ -56,6 +57,7 @@ _SIGNATURES = {
     "pf_conv2d_direct": [_fp, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_conv2d_small": [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_channel_stats": [_fp, _i, _i, _i, C.c_float, _fp, _fp, _fp, _i, _fp],
+    "pf_channel_stats_final": [_fp, _i, _i, _i, _i, C.c_float, _fp, _fp, _fp],
     "pf_norm_act": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pf_flow_head_out": [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_coords_add": [_fp, _fp, _i, _i, _i, _i, _fp],
@@ -241,6 +243,15 @@ class PfLib:
         self._rc(self._dll.pf_channel_stats(_ptr(y), B, Np, Cch, eps, _ptr(scale), _ptr(shift),
                                             C.c_void_p(partials.data_ptr()), nblk, self._stream(y)),
                  "pf_channel_stats")
+
+    def channel_stats_final(self, partials, B, Np, Cch, nblk, scale, shift, eps=1e-5):
+        """Second stage only: partials [B][nblk][C][2] float64 written by a conv launched with stats_out."""
+        self._chk(scale, shift)
+        if partials.dtype != torch.float64 or partials.numel() < B * nblk * Cch * 2:
+            raise PfError("channel_stats_final: partials must be float64 with >= B*nblk*C*2 elements")
+        self._rc(self._dll.pf_channel_stats_final(C.c_void_p(partials.data_ptr()), B, Np, Cch, nblk, eps,
+                                                  _ptr(scale), _ptr(shift), self._stream(scale)),
+                 "pf_channel_stats_final")
 
     def norm_act(self, y, s, t, out, B, Np, Cc, res=None, rs=None, rt=None):
         self._chk(y, s, t, out, res, rs, rt)

@@ -608,6 +608,44 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     // ---- epilogue -----------------------------------------------------------------------------
 #ifndef PF_ABLATE_NO_EPILOGUE
     tile_epilogue<NT, false>(d, acc, n0 + 32 * NT * wn, li, pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh, 0);
+    if (d.stats_out != nullptr) {
+        // InstanceNorm statistics of this tile's outputs (the stored values, (acc + bias) * scale): fp64
+        // sum / sum of squares per channel over the wave's 32 pixels, the wave's two halves by a
+        // lane exchange, the workgroup's pixel rows through the (idle) operand LDS in a fixed order.
+        __syncthreads();                            // every wave has left the K loop: LDS is free
+        double* red = reinterpret_cast<double*>(smem);          // [8 waves][32*NT channels][2]
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = n0 + 32 * NT * wn + 32 * t + li;
+            const float bias = j < d.cout ? d.bias[j] : 0.f;
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double v = (double)((acc[t][r] + bias) * d.scale);
+                s1 += v; s2 += v * v;
+            }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lh == 0) {
+                red[((wave * (32 * NT)) + 32 * t + li) * 2 + 0] = s1;
+                red[((wave * (32 * NT)) + 32 * t + li) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < d.cout) {
+            const int cw = tid / (32 * NT), cl = tid % (32 * NT);      // channel half (wn) and slot inside it
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int y = 0; y < 8 / WN; ++y) {                           // the waves (pixel rows) of this half, in order
+                const int wv = y * WN + cw;
+                s1 += red[(wv * (32 * NT) + cl) * 2 + 0];
+                s2 += red[(wv * (32 * NT) + cl) * 2 + 1];
+            }
+            // tile = image * tiles_per_image + tile_in_image: exactly the [image][nblk] order of the partials
+            double* o = d.stats_out + ((long)tile * d.cout + n0 + tid) * 2;
+            o[0] = s1; o[1] = s2;
+        }
+    }
 #else
     if (acc[0][0] == 123.456f) d.out[0] = acc[NT - 1][3];
 #endif
@@ -749,8 +787,10 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
     hipStream_t s = (hipStream_t)stream;
     const bool split = descs[0].precision == PF_PREC_BF16X3;
     const int tile_id = conv_tile(g, ngroups, max_cout, descs[0].precision);
-    for (int i = 0; i < ngroups; ++i)       // the input affine is implemented by the halo kernel only
+    for (int i = 0; i < ngroups; ++i) {     // the input affine and the fused statistics are implemented by the halo kernel only
         if (descs[i].in_scale && tile_id < 3) return PF_ERR_BAD_SHAPE;
+        if (descs[i].stats_out && (tile_id < 3 || descs[i].epilogue != PF_EPI_LINEAR)) return PF_ERR_BAD_SHAPE;
+    }
     switch (tile_id) {
         case 0: return launch_conv<4, 1, 1>(grp, ngroups, g, max_cout, split, s);
         case 1: return launch_conv<2, 2, 1>(grp, ngroups, g, max_cout, split, s);

@@ -275,9 +275,19 @@ __global__ void __launch_bounds__(256) pf_stats_final(const double* __restrict__
     const int c = tid % C, grp = tid / C;
     double s = 0.0, ss = 0.0;
     if (grp < g)
-        for (int k = grp; k < nblk; k += g) {
-            const double* o = part + (((long)b * nblk + k) * C + c) * 2;
-            s += o[0]; ss += o[1];
+        for (int k0 = grp; k0 < nblk; k0 += 8 * g) {
+            // 8 partials per trip, all loads issued before the first add (the one-load-per-iteration
+            // form was a chain of 32 dependent L2 round trips: 15 us for a few KB)
+            double v[8][2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j * g;
+                const double* o = part + (((long)b * nblk + (k < nblk ? k : k0)) * C + c) * 2;
+                v[j][0] = o[0]; v[j][1] = o[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j * g < nblk) { s += v[j][0]; ss += v[j][1]; }
         }
     sh[0][tid] = s; sh[1][tid] = ss;
     __syncthreads();
@@ -294,6 +304,12 @@ __global__ void __launch_bounds__(256) pf_stats_final(const double* __restrict__
 int launch_stats(const float* y, int B, int Np, int C, float eps, float* scale, float* shift, double* part,
                  int nblk, void* stream) {
     hipLaunchKernelGGL(pf_stats_partial, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, y, part, Np, C, nblk);
+    hipLaunchKernelGGL(pf_stats_final, dim3(B), dim3(256), 0, (hipStream_t)stream, part, scale, shift, C, nblk, Np, eps);
+    return (int)hipGetLastError();
+}
+
+int launch_stats_final(const double* part, int B, int Np, int C, int nblk, float eps, float* scale, float* shift,
+                       void* stream) {
     hipLaunchKernelGGL(pf_stats_final, dim3(B), dim3(256), 0, (hipStream_t)stream, part, scale, shift, C, nblk, Np, eps);
     return (int)hipGetLastError();
 }
@@ -424,6 +440,7 @@ int launch_region_sums(const PfRegionSumArgs& a, void* stream) {
 #define PF_FLOW_OUT_LAUNCH(a, total, stream) launch_flow_out(a, total, stream)
 #define PF_NORM_ACT_LAUNCH(a, total, stream) launch_norm_act(a, total, stream)
 #define PF_STATS_LAUNCH launch_stats
+#define PF_STATS_FINAL_LAUNCH launch_stats_final
 #define PF_LAUNCH(name, args, total, stream) \
     pf_launch_elem<decltype(args), pf_##name##_elem>(args, total, stream)
 

@@ -122,7 +122,8 @@ class Conv:
         return Conv(wp, bp, w.shape[2], w.shape[3], w.shape[1], w.shape[0], precision)
 
     def desc(self, in0, off0, c0, out, off_out, epilogue, in1=None, off1=0, c1=0, scale=1.0,
-             h=None, z=None, aux=None, stride=1, in_scale=None, in_shift=None, in_relu=False) -> ConvDesc:
+             h=None, z=None, aux=None, stride=1, in_scale=None, in_shift=None, in_relu=False,
+             stats=None) -> ConvDesc:
         assert c0 + c1 == self.cin, (c0, c1, self.cin)
         d = ConvDesc()
         d.in0, d.ld0, d.off0, d.c0 = in0.data_ptr(), in0.shape[-1], off0, c0
@@ -142,6 +143,7 @@ class Conv:
         d.in_scale = in_scale.data_ptr() if in_scale is not None else None
         d.in_shift = in_shift.data_ptr() if in_shift is not None else None
         d.in_relu = int(in_relu)
+        d.stats_out = stats.data_ptr() if stats is not None else None
         return d
 
 
@@ -570,6 +572,27 @@ class EncoderPlan:
                 self._bn_cache[key] = (sc[None].repeat(Bn, 1).contiguous(), sh[None].repeat(Bn, 1).contiguous())
         return self._bn_cache[key]
 
+    def _conv_norm(self, cv, norm, x, cin, y, Bn, h, w, cout, slot, **kw):
+        """Launch conv `cv` (x -> raw y) and return the (scale, shift) of the norm that follows it.
+        InstanceNorm statistics ride in the conv's epilogue when the launch runs on a halo tile
+        (per-tile fp64 partials + pf_channel_stats_final); otherwise a separate pass reads y."""
+        lib, bufs = self.lib, self._bufs
+        d = cv.desc(x, 0, cin, y, 0, EPI_LINEAR, **kw)
+        fused = False
+        if self.kind != "batch":
+            tile = lib.conv2d_tile([d], Bn, h, w)
+            if tile >= 3:
+                nblk = (h // (8 if tile == 5 else 4)) * (w // 32)
+                if Bn * nblk * cout * 2 <= bufs["part"].numel():
+                    d.stats_out = bufs["part"].data_ptr()
+                    fused = True
+        lib.conv2d([d], Bn, h, w, x)
+        if not fused:
+            return self._affine(norm, y, Bn, h * w, cout, slot)
+        sc, sh = bufs["sc"][slot][: Bn * cout].view(Bn, cout), bufs["sh"][slot][: Bn * cout].view(Bn, cout)
+        lib.channel_stats_final(bufs["part"], Bn, h * w, cout, nblk, sc, sh)
+        return sc, sh
+
     def _affine(self, norm, y, Bn, Np, C, slot):
         """(scale, shift) [Bn][C] that normalises the raw conv output y."""
         if self.kind == "batch":
@@ -590,7 +613,7 @@ class EncoderPlan:
         b["s2d"] = z(Bn * (H // 2) * (W // 2), 12)
         b["sc"] = [z(Bn * 128) for _ in range(3)]
         b["sh"] = [z(Bn * 128) for _ in range(3)]
-        b["part"] = z(Bn * 128 * 128 * 2, dt=torch.float64)
+        b["part"] = z(Bn * 1024 * 128 * 2, dt=torch.float64)       # [image][<= 1024 tiles or 128 chunks][C][2]
         self._bufs = b
 
     def run(self, images: torch.Tensor, out: torch.Tensor, epilogue: int, aux: Optional[torch.Tensor] = None):
@@ -605,10 +628,10 @@ class EncoderPlan:
         # stem: raw conv -> a0[0]; x0 = relu(norm1(.)) materialised -> a0[1]
         if self.stem_s2d is not None:
             lib.space_to_depth2(images, bufs["s2d"])
-            lib.conv2d([self.stem_s2d.desc(bufs["s2d"], 0, 12, a0[0], 0, EPI_LINEAR)], Bn, h, w, images)
+            sc, sh = self._conv_norm(self.stem_s2d, self.norm1, bufs["s2d"], 12, a0[0], Bn, h, w, 64, 0)
         else:
             lib.conv2d_small(images, True, 0, 3, self.stem.w, self.stem.b, a0[0], 0, 64, 7, 7, 2, False, Bn, h, w)
-        sc, sh = self._affine(self.norm1, a0[0], Bn, h * w, 64, 0)
+            sc, sh = self._affine(self.norm1, a0[0], Bn, h * w, 64, 0)
         lib.norm_act(a0[0], sc, sh, a0[1], Bn, h * w, 64)
         x = a0[1]
         lvl = 0
@@ -622,12 +645,10 @@ class EncoderPlan:
             y1, y2, o = free[0], free[1], free[2]
             Np = h * w
             # conv1 (input x is a materialised activation: no affine)
-            lib.conv2d([blk["c1"].desc(x, 0, cin, y1, 0, EPI_LINEAR, stride=st)], Bn, h, w, x)
-            s1, t1 = self._affine(blk["n1"], y1, Bn, Np, cout, 0)
+            s1, t1 = self._conv_norm(blk["c1"], blk["n1"], x, cin, y1, Bn, h, w, cout, 0, stride=st)
             # conv2 consumes relu(norm1(y1)) folded into its load
-            lib.conv2d([blk["c2"].desc(y1, 0, cout, y2, 0, EPI_LINEAR, in_scale=s1, in_shift=t1, in_relu=True)],
-                       Bn, h, w, x)
-            s2, t2 = self._affine(blk["n2"], y2, Bn, Np, cout, 1)
+            s2, t2 = self._conv_norm(blk["c2"], blk["n2"], y1, cout, y2, Bn, h, w, cout, 1,
+                                     in_scale=s1, in_shift=t1, in_relu=True)
             if st != 1:
                 # shortcut: norm3(conv1x1/2(x)); reuse y1 (conv2 has consumed it) for the raw shortcut
                 lib.conv2d([blk["ds"].desc(x, 0, cin, y1, 0, EPI_LINEAR, stride=st)], Bn, h, w, x)

@@ -14,6 +14,26 @@ static int pf_loop(const Args& a, long total) {
 #define PF_LAUNCH(name, args, total, stream) pf_loop<decltype(args), pf_##name##_elem>(args, total)
 #define PF_DIRECT_CONV_LAUNCH(a, total, stream) pf_loop<PfDirectConvArgs, pf_direct_conv_elem>(a, total)
 
+// host statement of pf_channel_stats_final
+static int emu_stats_final(const double* part, int B, int Np, int C, int nblk, float eps, float* scale, float* shift, void*) {
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            double s = 0, ss = 0;
+            for (int k = 0; k < nblk; ++k) {
+                s += part[(((long)b * nblk + k) * C + c) * 2];
+                ss += part[(((long)b * nblk + k) * C + c) * 2 + 1];
+            }
+            const double mean = s / Np;
+            double var = ss / Np - mean * mean;
+            if (var < 0) var = 0;
+            const double rstd = 1.0 / sqrt(var + (double)eps);
+            scale[(long)b * C + c] = (float)rstd;
+            shift[(long)b * C + c] = (float)(-mean * rstd);
+        }
+    return PF_OK;
+}
+#define PF_STATS_FINAL_LAUNCH emu_stats_final
+
 // host statement of pf_region_sums (same block partition, sequential sums inside a block)
 static int emu_region_sums(const PfRegionSumArgs& a, void*) {
     const int chunk = (a.N + a.nblk - 1) / a.nblk;

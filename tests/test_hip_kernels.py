@@ -270,6 +270,32 @@ def test_conv_stride2_and_input_affine(lib, dev):
     lib.conv2d([cv.desc(xin, 0, 64, out, 0, EPI_LINEAR, in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True)],
                2, 16, 64, xin)
     kc.check(kc.uncl(out.cpu(), 2, 16, 64), want, 1.5e-4, "halo conv with folded norm+relu")
+    _check_fused_stats(lib, dev, cv, xin, 64, 64, 2, 16, 64, expect_tile=3)
+    # Cout = 96 on the 128-channel tile (ragged channel tail), no input affine
+    w = gc.uni("st/w", (96, 64, 3, 3), -0.1, 0.1)
+    wp, bp = pack_mfma(w.to(dev), gc.uni("st/b", (96,), -0.1, 0.1).to(dev))
+    _check_fused_stats(lib, dev, Conv(wp, bp, 3, 3, 64, 96, PREC_BF16X3), xin, 64, 96, 2, 16, 64, expect_tile=3)
+
+
+def _check_fused_stats(lib, dev, cv, xin, cin, cout, B, h, w, expect_tile):
+    """InstanceNorm statistics fused into the conv epilogue == pf_channel_stats of the stored output."""
+    from prior_flow_amd._lib import EPI_LINEAR
+    out = torch.empty(B * h * w, cout, device=dev)
+    d = cv.desc(xin, 0, cin, out, 0, EPI_LINEAR)
+    tile = lib.conv2d_tile([d], B, h, w)
+    assert tile == expect_tile
+    nblk = (h // (8 if tile == 5 else 4)) * (w // 32)
+    part = torch.full((B, nblk, cout, 2), float("nan"), dtype=torch.float64, device=dev)
+    d.stats_out = part.data_ptr()
+    lib.conv2d([d], B, h, w, xin)
+    sc, sh = torch.empty(B, cout, device=dev), torch.empty(B, cout, device=dev)
+    lib.channel_stats_final(part, B, h * w, cout, nblk, sc, sh)
+    sc2, sh2 = torch.empty(B, cout, device=dev), torch.empty(B, cout, device=dev)
+    lib.channel_stats(out, B, h * w, cout, sc2, sh2, torch.empty(B * 16 * cout * 2, dtype=torch.float64, device=dev), 16)
+    y = out.view(B, h * w, cout).double()
+    assert float((part.sum(1)[..., 0] - y.sum(1)).abs().max()) < 1e-9 * h * w
+    kc.check(sc, sc2, 1e-6 * float(sc2.abs().max()), f"fused stats scale (tile {tile})")
+    kc.check(sh, sh2, 1e-6 * float(sh2.abs().max()) + 1e-7, f"fused stats shift (tile {tile})")
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
@@ -316,6 +342,7 @@ def test_conv_8row_tile_layer1_size(lib, dev):
     assert lib.conv2d_tile([d], B, h, w) == 5
     lib.conv2d([d], B, h, w, xin)
     kc.check(kc.uncl(out.cpu(), B, h, w), want, 1.5e-4, "8-row tile 3x3 affine")
+    _check_fused_stats(lib, dev, cv, xin, 64, 64, B, h, w, expect_tile=5)
     d = cv.desc(xin, 0, 64, out, 0, EPI_RELU)
     lib.conv2d([d], B, h, w, xin)
     kc.check(kc.uncl(out.cpu(), B, h, w), torch.relu(torch.nn.functional.conv2d(x, wt, b, padding=1)), 1.5e-4,
