@@ -308,7 +308,7 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// Halo-tile kernel (PF_PREC_BF16X3, KH*KW >= 3, W8 % 32 == 0, H8 % 4 == 0).
+// Halo-tile kernel (PF_PREC_BF16X3; 3x3, 1x5, 5x1, 4x4 and 1x1 taps; W8 % 32 == 0, H8 % 4 == 0).
 //
 // With 3-pass bf16 MFMAs a K-step carries 5x less matrix time than in exact fp32, so the generic
 // kernel above becomes bound by what surrounds the MFMAs: every tap re-loads and re-splits the
@@ -382,13 +382,17 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     const long wrow = (long)TAPS * g.cin_pad;
     const int nchunks = g.nchunks;
     const int nsteps = nchunks * TAPS;
-    f32x4 ra[A_V4];
+    // TAPS == 1 (1x1 convs): a chunk lasts ONE K-step, so the halo follows the weight ring's cadence --
+    // two register sets, chunk s+2 stored and chunk s+4 issued at step s (see `step`).
+    constexpr int NSET = TAPS == 1 ? 2 : 1;
+    static_assert(!(AFFINE && TAPS == 1), "the input affine is loaded once per chunk at tap 0 of a multi-tap conv");
+    f32x4 ra[NSET][A_V4];
     unsigned a_loff[A_V4];
 #pragma unroll
     for (int q = 0; q < A_V4; ++q) a_loff[q] = (unsigned)((((tid + 512 * q) >> 3) * LDS_LD) * 4 + 2 * c4);
     f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};   // input affine of this thread's 4 channels
     const long aff_row = (long)(tile / (tiles_x * tiles_y)) * ctot;     // [image][channel]
-    unsigned a_ok = 0;
+    unsigned a_ok[NSET] = {};
     // The halo loader/converter works in A_V4 independent slices (q) so that a K-step can spread
     // them between its MFMAs (see `step`).
     auto load_A_affine = [&](int chunk) __attribute__((always_inline)) {
@@ -400,8 +404,8 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
             a_sh = *reinterpret_cast<const f32x4*>(d.in_shift + aff_row + ca);
         }
     };
-    auto load_A_q = [&](int chunk, auto Q) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value;
+    auto load_A_q = [&](int chunk, auto Q, auto SET) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value, set = decltype(SET)::value;
         if (chunk >= nchunks) chunk = nchunks - 1;       // tail: harmless re-read, stored to the idle buffer
         const int c = chunk * KC + c4;
         const float* src; int ld, cc;
@@ -409,20 +413,20 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         else          { src = d.in1 + d.off1; ld = d.ld1; cc = c - d.c0; }
         const bool ok = c < ctot && a_pix[q] >= 0;
         const float* ptr = ok ? src + a_pix[q] * ld + cc : d.in0 + d.off0;
-        ra[q] = *reinterpret_cast<const f32x4*>(ptr);
-        a_ok = (a_ok & ~(1u << q)) | (ok ? (1u << q) : 0u);
+        ra[set][q] = *reinterpret_cast<const f32x4*>(ptr);
+        a_ok[set] = (a_ok[set] & ~(1u << q)) | (ok ? (1u << q) : 0u);
     };
-    auto store_A_q = [&](int buf, auto Q) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value;
+    auto store_A_q = [&](int buf, auto Q, auto SET) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value, set = decltype(SET)::value;
         // previous layer's norm (+ReLU) folded into this load; zero padding applies AFTER it
-        f32x4 x = ra[q];
+        f32x4 x = ra[set][q];
         if constexpr (AFFINE) {
             x = x * a_sc + a_sh;
             if (d.in_relu) {
                 x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
             }
         }
-        const f32x4 v = ((a_ok >> q) & 1u) ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = ((a_ok[set] >> q) & 1u) ? x : f32x4{0.f, 0.f, 0.f, 0.f};
         // hi = bf16(v) (RNE); lo = bf16(v - hi): the subtraction is exact in fp32
         const bf16x4 hi = __builtin_convertvector(v, bf16x4);
         const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
@@ -431,12 +435,14 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         *reinterpret_cast<bf16x4*>(row) = hi;
         *reinterpret_cast<bf16x4*>(row + 64) = lo;
     };
-    auto load_A = [&](int chunk) __attribute__((always_inline)) {
+    using SET0 = std::integral_constant<int, 0>;
+    using SET1 = std::integral_constant<int, NSET - 1>;
+    auto load_A = [&](int chunk, auto SET) __attribute__((always_inline)) {
         load_A_affine(chunk);
-        static_for<0, A_V4>([&](auto Q) { load_A_q(chunk, Q); });
+        static_for<0, A_V4>([&](auto Q) { load_A_q(chunk, Q, SET); });
     };
-    auto store_A = [&](int buf) __attribute__((always_inline)) {
-        static_for<0, A_V4>([&](auto Q) { store_A_q(buf, Q); });
+    auto store_A = [&](int buf, auto SET) __attribute__((always_inline)) {
+        static_for<0, A_V4>([&](auto Q) { store_A_q(buf, Q, SET); });
     };
 
     // ---- weight ring: 3 LDS slots, 2 register sets (steps s+2, s+3 staged; s+4 issued) -----------
@@ -500,12 +506,16 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     };
 
     // ---- prologue: halo 0, weight steps 0 and 1 synchronously; steps 2, 3 in flight; frags(0) ------
-    load_A(0);
+    // (TAPS == 1: halo chunks 0 and 1 synchronously, chunks 2 and 3 in flight, like the weights)
+    load_A(0, SET0{});
+    if constexpr (TAPS == 1) load_A(1, SET1{});
     load_B(0, rb0);
     load_B(1, rb1);
-    store_A(0);
+    store_A(0, SET0{});
+    if constexpr (TAPS == 1) store_A(1, SET1{});
     store_B(0, rb0);
     store_B(1, rb1);
+    if constexpr (TAPS == 1) { load_A(2, SET0{}); load_A(3, SET1{}); }
     load_B(2, rb0);
     load_B(3, rb1);
     asm volatile("" ::: "memory");
@@ -550,12 +560,24 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
 #endif
         constexpr int NM = 6 * NT;                     // MFMAs of the step; accumulators alternate
         auto halo_slice = [&](auto Q) __attribute__((always_inline)) {
+            using CUR = std::integral_constant<int, TAPS == 1 ? cur : 0>;
+            if constexpr (TAPS == 1) {
+                // chunk == step: chunk s+2 goes from register set s&1 into halo buffer s&1 (last read by
+                // the fragment fetch of step s-1), then the set is re-issued for chunk s+4
+#ifndef PF_ABLATE_NO_LDS_WRITE
+                store_A_q(cur, Q, CUR{});
+#endif
 #ifndef PF_ABLATE_NO_GLOBAL
-            if constexpr (tap == 0) load_A_q(chunk + 1, Q);
+                load_A_q(chunk + 4, Q, CUR{});
+#endif
+            } else {
+#ifndef PF_ABLATE_NO_GLOBAL
+                if constexpr (tap == 0) load_A_q(chunk + 1, Q, CUR{});
 #endif
 #ifndef PF_ABLATE_NO_LDS_WRITE
-            if constexpr (tap == TAPS - 2) store_A_q((chunk + 1) & 1, Q);
+                if constexpr (tap == TAPS - 2) store_A_q((chunk + 1) & 1, Q, CUR{});
 #endif
+            }
         };
         static_for<0, NM>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
@@ -582,7 +604,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
 #endif
 #ifndef PF_ABLATE_NO_GLOBAL
                 if constexpr (cur == 0) load_B(s + 4, rb0); else load_B(s + 4, rb1);
-                if constexpr (tap == 0) load_A_affine(chunk + 1);
+                if constexpr (tap == 0 && TAPS > 1) load_A_affine(chunk + 1);
 #endif
             }
             if constexpr (NT == 1) {                    // 6 MFMAs: half of the halo slices in each of two gaps
@@ -680,7 +702,8 @@ int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int 
     }
     if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, false, TH>(grp, ngroups, g, max_cout, stream);
     if (g.kh == 4 && g.kw == 4) return launch_conv_halo_t<NT, 4, 4, false, TH>(grp, ngroups, g, max_cout, stream);
-    if constexpr (TH == 4) {                // the GRU's separable convs only exist at 1/8 resolution
+    if constexpr (TH == 4) {                // the GRU's separable convs and the 1x1 convs only exist at 1/8 resolution
+        if (g.kh == 1 && g.kw == 1) return launch_conv_halo_t<NT, 1, 1, false, TH>(grp, ngroups, g, max_cout, stream);
         if (g.kh == 1 && g.kw == 5) return launch_conv_halo_t<NT, 1, 5, false, TH>(grp, ngroups, g, max_cout, stream);
         if (g.kh == 5 && g.kw == 1) return launch_conv_halo_t<NT, 5, 1, false, TH>(grp, ngroups, g, max_cout, stream);
     }
@@ -761,11 +784,11 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, H8 % 8 == 0, enough pixels to fill the chip)
 static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
     const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1) ||
-                            (g.kh == 4 && g.kw == 4);
+                            (g.kh == 4 && g.kw == 4) || (g.kh == 1 && g.kw == 1);
     if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1 && g.W % 32 == 0 && g.H % 4 == 0 &&
         !pf_conv_force_generic()) {
         const long wgs128 = ((long)g.M / 128) * ngroups * ((max_cout + 127) / 128);
-        if (max_cout <= 64 && g.kh == g.kw && g.H % 8 == 0 && ((long)g.M / 256) * ngroups >= 512) return 5;
+        if (max_cout <= 64 && g.kh == g.kw && g.kh > 1 && g.H % 8 == 0 && ((long)g.M / 256) * ngroups >= 512) return 5;
         return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
     }
     const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of single pf_conv2d launches at the 512x1024 problem size (B=1, 64x128 map):
    python profiles/microbench_conv.py [reps] [which]
-which: zr (grouped 1x5 384->256 GRU gates), q (1x5 384->128), c2 (3x3 256->128|192), fh1 (3x3 128->256 x3)
+which: c1 (1x1 324->256 x2), zr (grouped 1x5 384->256 GRU gates), q (1x5 384->128), c2 (3x3 256->128|192), fh1 (3x3 128->256 x3)
 Prints HIP-event time per launch and algorithmic TFLOP/s; used under rocprofv3 --pmc."""
 import os
 import sys
@@ -50,6 +50,11 @@ elif which == "q":
     cv = [conv(384, 128, 1, 5) for _ in range(2)]
     descs = [cv[i].desc(rh[i], 0, 128, out[i], 0, EPI_GRU_Q, in1=x[i], off1=0, c1=256, h=net[i], z=z[i]) for i in range(2)]
     flops = 2 * 2.0 * N * 128 * 5 * 384
+elif which == "c1":      # convc1: 1x1 324 -> 256 on both branches' correlation features
+    corr = [rnd(N, 324) for _ in range(2)]
+    cv = [conv(324, 256, 1, 1) for _ in range(2)]
+    descs = [cv[i].desc(corr[i], 0, 324, out[i], 0, EPI_RELU) for i in range(2)]
+    flops = 2 * 2.0 * N * 256 * 324
 elif which == "c2":
     cv = [conv(256, 128, 3, 3), conv(256, 192, 3, 3)]
     descs = [cv[i].desc(x[i], 0, 256, out[i], 0, EPI_RELU) for i in range(2)]
