@@ -88,6 +88,22 @@ def build_model(device):
     return model.to(device).eval(), params
 
 
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/pmc_traffic.py:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950, KiB -> bytes).
+    Counters cannot be collected inside this process; None when the profile file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, v in kernels.items():
+        if kernel_substr in name:
+            return round(v["hbm_bytes_per_launch"])
+    return None
+
+
 def profile_kernels(model, i1, i2):
     """One eager forward with HIP events around every MFMA-conv and corr-build launch."""
     lib = model._lib()
@@ -101,8 +117,9 @@ def profile_kernels(model, i1, i2):
         flops = sum(2.0 * B * H8 * W8 * d.cout * d.kh * d.kw * (d.c0 + d.c1) for d in descs)
         tile = lib.conv2d_tile(descs, B, H8, W8)
         d0 = descs[0]
-        if tile >= 3:      # halo kernel: the instantiation is <NT, KH, KW, AFFINE> exactly as rocprof names it
-            tile = "pf_conv_halo_kernel<%d, %d, %d, %s>" % (tile - 2, d0.kh, d0.kw, "true" if d0.in_scale else "false")
+        if tile >= 3:      # halo kernel: the instantiation is <NT, KH, KW, AFFINE, TH> exactly as rocprof names it
+            tile = "pf_conv_halo_kernel<%d, %d, %d, %s, %d>" % (
+                1 if tile == 3 else 2, d0.kh, d0.kw, "true" if d0.in_scale else "false", 8 if tile == 5 else 4)
         else:
             tile = TILE_NAMES[tile].split(" ")[0][:-1] + (", true>" if d0.precision == 1 else ", false>")
         s, e = ev(), ev()
@@ -167,7 +184,8 @@ def profile_kernels(model, i1, i2):
                 # the 3-pass split issues 3 bf16 MFMA FLOPs per algorithmic FLOP: pipe utilisation
                 "mfma_issue_tflops": round(achieved * (3 if split else 1), 2),
                 "mfma_pipe_util": round(achieved * (3 if split else 1) / peak, 4),
-                "traffic": None, "launches_per_forward": n, "avg_launch_us": round(ms / n * 1e3, 1),
+                "traffic": pmc_traffic(str(dom)), "traffic_note": "HBM-side bytes/launch, profiles/r1_pmc_traffic.json",
+                "launches_per_forward": n, "avg_launch_us": round(ms / n * 1e3, 1),
                 "gflop_per_forward": round(fl / 1e9, 1),
                 "all_conv_kernels": {"gflop": round(all_fl / 1e9, 1), "ms": round(all_ms, 3),
                                      "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}}
@@ -175,7 +193,8 @@ def profile_kernels(model, i1, i2):
     roofline_corr = {"kernel": "pf_corr_kernel<fused pool, %s> (corr volume + 4-level pyramid)" % ("bf16x3" if split else "fp32"),
                      "bound": "hbm",
                      "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                     "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None,
+                     "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("pf_corr_kernel"),
+                     "traffic_note": "HBM-side bytes/launch, profiles/r1_pmc_traffic.json",
                      "launches_per_forward": corr_n, "avg_launch_us": round(corr_t / corr_n * 1e3, 1),
                      "mb_per_launch": round(corr_b / corr_n / 1e6, 1),
                      "note": ("34.4 GFLOP/launch: 3-pass bf16 MFMA + 373 MB of once-written output" if split else

@@ -85,22 +85,25 @@ pf_corr_kernel(const CorrArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     // XCD-aware work mapping.  Workgroup ids go round-robin over the 8 XCDs (id % 8), each with its
-    // own L2.  A pooled level's 128-byte line is completed by the 2 (level 1), 4 (level 2) or
-    // 4 x 2 (level 3) neighbouring n2 tiles of the same n1 rows, and the operand rows of f2 are
-    // shared by the tiles of one n2 block: each XCD owns a contiguous range of the work sequence
-    // q = ((b * m_tiles + m) * n2_tiles + tile), tile fastest, so line-mates and operand sharers
-    // run back to back on one XCD.  (Measured neutral on the launch time: the store phase is bound
-    // by the NUMBER of 4-byte-per-lane store instructions -- ~20 cycles each per CU; the pooled
-    // levels are 47 % of them for 24 % of the bytes -- not by partial-line write-backs.)
+    // own 4 MB L2; every XCD gets a contiguous range of the work sequence
+    //     q = ((band * m_tiles + m) * tiles_x + tx)        (band = batch x 8-row band of n2 tiles)
+    // i.e. ONE band of target tiles (tiles_x * 256 rows of f2 = 1 MB, L2 resident) against all query
+    // tiles m, the tiles_x neighbours of a band back to back (they share the f1 tile and complete each
+    // other's pooled-level lines).  The first mapping (n2 tile fastest over ALL tiles, then m) made
+    // every XCD stream the whole of f2 (8 MB > L2) once per pair of query tiles: the PMC pass read
+    // 383 MB of fabric-side fetches per launch against 16.8 MB of inputs.
     int b, m0, tile;
     {
         const unsigned nwg = gridDim.x, orig = blockIdx.x;
         const unsigned xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;     // bijective for any nwg
         const unsigned q = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
-        tile = (int)(q % (unsigned)a.n2_tiles);
-        const unsigned mt = q / (unsigned)a.n2_tiles;
-        m0 = (int)(mt % (unsigned)a.m_tiles) * BM;
-        b = (int)(mt / (unsigned)a.m_tiles);
+        const unsigned tx_n = FUSED_POOL ? (unsigned)a.tiles_x : 1u;    // generic path: one "band" per n2 tile
+        const unsigned bands = (unsigned)a.n2_tiles / tx_n;
+        const unsigned tx = q % tx_n, r = q / tx_n;
+        const unsigned bb = r / (unsigned)a.m_tiles;                    // batch * bands + band
+        m0 = (int)(r % (unsigned)a.m_tiles) * BM;
+        b = (int)(bb / bands);
+        tile = (int)((bb % bands) * tx_n + tx);
     }
     // n2 of local column col (0..255)
     int ty0 = 0, tx0 = 0;
