@@ -220,6 +220,23 @@ int pf_flow_metrics(const float* pred, const float* gt, float* epe, float* sd, i
 int pf_region_sums(const float* epe, const float* sd, const float* weight, const unsigned char* bits,
                    int nregions, double* partials, int nblk, int B, int N, void* stream);
 
+/* ---- training-step counterpart (the network's backward is NOT built) ------- */
+
+/* One term of `uniform_loss.__call__` (train_flow.py:62-71): with m = (valid >= 0.5 && |gt| < max_flow) * weight[n],
+ * partials[b][k][0] = sum m (|du|+|dv|) over pixel chunk k; [1..5] = sum epe, n_valid, n(epe<1), n(<3), n(<5)
+ * over the valid pixels (the metrics of :73-79, meaningful for the last prediction).  grad (optional):
+ * d(i_weight * loss_i)/d pred = i_weight * m * sign(pred - gt).  pred, gt, grad: [B,2,N]; valid [B,N]; weight [N]. */
+int pf_seq_loss(const float* pred, const float* gt, const float* valid, const float* weight, float i_weight,
+                float max_flow, float* grad, double* partials, int nblk, int B, int N, void* stream);
+
+/* partials[k] = sum of squares of chunk k of x[0..n): the total norm of `clip_grad_norm_` (train_flow.py:137). */
+int pf_sum_squares(const float* x, long n, double* partials, int nblk, void* stream);
+
+/* One fused AdamW step over a flat parameter buffer (torch.optim.AdamW as built by train_flow.py:86-88):
+ * g*grad_scale (the clip coefficient), decoupled weight decay, bias-corrected update; step counts from 1. */
+int pf_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, float beta1, float beta2,
+                  float eps, double weight_decay, int step, float grad_scale, void* stream);
+
 /* channel-last slice -> NCHW. */
 int pf_to_nchw(const float* in, int ld_in, int off_in, int c, float* out, int B, int N,
                void* stream);

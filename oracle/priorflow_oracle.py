@@ -528,3 +528,61 @@ def region_metrics(preds: Sequence[Tensor], gts: Sequence[Tensor]) -> Dict[str, 
                      "sd": float(torch.cat(s_all).double().mean()),
                      "sd_uni": float(sum(u_all) / len(u_all))}
     return out
+
+
+# --------------------------------------------------------------------------------------
+# training-step counterpart: loss, schedule, optimiser, clipping
+# --------------------------------------------------------------------------------------
+MAX_FLOW = 400.0     # train_flow.py:46
+
+
+def uniform_loss(flow_preds: Sequence[Tensor], flow_gt: Tensor, valid: Tensor, gamma: float = 0.8,
+                 max_flow: float = MAX_FLOW):
+    """train_flow.py:55-79: (loss, metrics, gradients of the loss w.r.t. every prediction).
+    loss = sum_i gamma^(n-i-1) * sum(valid * cos-latitude mask * |pred_i - gt|_1); metrics over the
+    valid pixels of the last prediction.  Gradients are written out by hand (abs' = sign)."""
+    B, _, H, W = flow_gt.shape
+    uni = spherical_mask(H, W)[None]
+    mag = torch.sum(flow_gt ** 2, dim=1).sqrt()
+    ok = (valid >= 0.5) & (mag < max_flow)
+    n = len(flow_preds)
+    loss = torch.zeros((), dtype=torch.float64)
+    grads = []
+    for i, p in enumerate(flow_preds):
+        wgt = gamma ** (n - i - 1)
+        m = ok * uni
+        loss = loss + wgt * torch.sum((m * torch.sum((p - flow_gt).abs(), dim=1)).double())
+        grads.append(wgt * m[:, None] * torch.sign(p - flow_gt))
+    e = torch.sum((flow_preds[-1] - flow_gt) ** 2, dim=1).sqrt().view(-1)[ok.view(-1)]
+    metrics = {"epe": float(e.double().mean()), "1px": float((e < 1).double().mean()),
+               "3px": float((e < 3).double().mean()), "5px": float((e < 5).double().mean())}
+    return float(loss), metrics, grads
+
+
+def one_cycle_lr(step: int, max_lr: float, num_steps: int, pct_start: float = 0.05, div_factor: float = 25.0,
+                 final_div_factor: float = 1e4) -> float:
+    """Learning rate after `step` scheduler steps of OneCycleLR(max_lr, num_steps + 100, pct_start=0.05,
+    cycle_momentum=False, anneal_strategy='linear') (train_flow.py:89-90)."""
+    total = num_steps + 100
+    initial, min_lr = max_lr / div_factor, max_lr / div_factor / final_div_factor
+    end1 = float(pct_start * total) - 1
+    if step <= end1:
+        return (max_lr - initial) * (step / end1) + initial
+    pct = (step - end1) / ((total - 1) - end1)
+    return (min_lr - max_lr) * pct + max_lr
+
+
+def clip_coef(total_norm: float, max_norm: float) -> float:
+    """torch.nn.utils.clip_grad_norm_ (train_flow.py:137): grads *= min(1, max_norm / (norm + 1e-6))."""
+    return min(1.0, max_norm / (total_norm + 1e-6))
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, wd: float, eps: float = 1e-8,
+               b1: float = 0.9, b2: float = 0.999):
+    """One torch.optim.AdamW update (single-tensor form), fp32 tensors, python-float scalars."""
+    p = p * (1 - lr * wd)
+    m = m + (g - m) * (1 - b1)
+    v = v * b2 + (g * g) * (1 - b2)
+    denom = v.sqrt() / math.sqrt(1 - b2 ** step) + eps
+    p = p + (m / denom) * (-(lr / (1 - b1 ** step)))
+    return p, m, v

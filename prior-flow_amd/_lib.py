@@ -65,6 +65,10 @@ _SIGNATURES = {
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
     "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
+    "pf_seq_loss": [_fp, _fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, _i, _i, _i, _fp],
+    "pf_sum_squares": [_fp, C.c_long, _fp, _i, _fp],
+    "pf_adamw_step": [_fp, _fp, _fp, _fp, C.c_long, C.c_double, C.c_float, C.c_float, C.c_float, C.c_double, _i,
+                      C.c_float, _fp],
     "pf_flow_metrics": [_fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pf_region_sums": [_fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
 }
@@ -295,6 +299,34 @@ class PfLib:
         self._rc(self._dll.pf_space_to_depth2(_ptr(x), C, _ptr(out), out.shape[-1], B, H, W, self._stream(x)),
                  "pf_space_to_depth2")
         return out
+
+    # ---- training-step pieces ---------------------------------------------------------------
+    def seq_loss(self, pred, gt, valid, weight, i_weight, max_flow, grad, partials):
+        """pred, gt [B,2,H,W]; valid [B,H,W]; weight [H*W]; grad [B,2,H,W] or None; partials float64 [B,nblk,6]."""
+        self._chk(pred, gt, valid, weight, grad)
+        B = pred.shape[0]
+        N = pred.shape[2] * pred.shape[3]
+        if partials.dtype != torch.float64 or partials.dim() != 3 or partials.shape[0] != B or partials.shape[2] != 6:
+            raise PfError("seq_loss: partials must be float64 [B, nblk, 6]")
+        if gt.shape != pred.shape or valid.numel() != B * N or weight.numel() != N:
+            raise PfError("seq_loss: shape mismatch")
+        self._rc(self._dll.pf_seq_loss(_ptr(pred), _ptr(gt), _ptr(valid), _ptr(weight), i_weight, max_flow, _ptr(grad),
+                                       C.c_void_p(partials.data_ptr()), partials.shape[1], B, N, self._stream(pred)),
+                 "pf_seq_loss")
+
+    def sum_squares(self, x, partials):
+        self._chk(x)
+        if partials.dtype != torch.float64 or not partials.is_contiguous():
+            raise PfError("sum_squares: partials must be contiguous float64")
+        self._rc(self._dll.pf_sum_squares(_ptr(x), x.numel(), C.c_void_p(partials.data_ptr()), partials.numel(),
+                                          self._stream(x)), "pf_sum_squares")
+
+    def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+        self._chk(p, g, m, v)
+        if not (p.numel() == g.numel() == m.numel() == v.numel()):
+            raise PfError("adamw_step: buffers must have the same size")
+        self._rc(self._dll.pf_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps,
+                                         weight_decay, step, grad_scale, self._stream(p)), "pf_adamw_step")
 
     def flow_metrics(self, pred, gt, epe=None, sd=None):
         """pred, gt: NCHW [B,2,H,W]; epe / sd: [B,H,W] outputs (either optional)."""

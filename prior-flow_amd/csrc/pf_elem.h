@@ -594,6 +594,58 @@ struct PfRegionSumArgs {
     double* partials; int B, N, R, nblk;
 };
 
+// ----------------------------------------------------------------------------------------------
+// Training-step counterpart, the parts that do not need the network's backward.
+// Sequence loss of ONE prediction (train_flow.py:62-71): m = (valid >= 0.5 && |gt| < max_flow) * w[n],
+// loss_i = sum m * (|du| + |dv|); its gradient seed d loss / d pred = i_weight * m * sign(pred - gt);
+// and the metrics of train_flow.py:73-79 (epe and <1/<3/<5 px fractions over the valid pixels).
+// sums[6] = { sum m*(|du|+|dv|), sum_valid epe, n_valid, n(epe<1), n(epe<3), n(epe<5) }
+// ----------------------------------------------------------------------------------------------
+struct PfSeqLossArgs {
+    const float* pred; const float* gt; const float* valid; const float* w;   // [B,2,N] x2, [B,N], [N]
+    float* grad;                 // [B,2,N] or null
+    double* partials;            // [B][nblk][6]
+    int B, N, nblk; float i_weight, max_flow;
+};
+PF_HD void pf_seq_loss_pixel(const PfSeqLossArgs& a, long b, int n, double (&sums)[6]) {
+    const long N = a.N;
+    const float gu = a.gt[(b * 2 + 0) * N + n], gv = a.gt[(b * 2 + 1) * N + n];
+    const float du = a.pred[(b * 2 + 0) * N + n] - gu, dv = a.pred[(b * 2 + 1) * N + n] - gv;
+    const float mag = sqrtf(gu * gu + gv * gv);
+    const bool ok = (a.valid[b * N + n] >= 0.5f) && (mag < a.max_flow);
+    const float m = ok ? a.w[n] : 0.f;
+    if (a.grad) {
+        const float gs = a.i_weight * m;
+        a.grad[(b * 2 + 0) * N + n] = du > 0.f ? gs : (du < 0.f ? -gs : 0.f);
+        a.grad[(b * 2 + 1) * N + n] = dv > 0.f ? gs : (dv < 0.f ? -gs : 0.f);
+    }
+    sums[0] += (double)(m * (fabsf(du) + fabsf(dv)));
+    if (ok) {
+        const float e = sqrtf(du * du + dv * dv);
+        sums[1] += (double)e; sums[2] += 1.0;
+        sums[3] += e < 1.f ? 1.0 : 0.0; sums[4] += e < 3.f ? 1.0 : 0.0; sums[5] += e < 5.f ? 1.0 : 0.0;
+    }
+}
+
+// sum of squares (gradient norm for clip_grad_norm_, train_flow.py:137): partials[k] = chunk sums
+struct PfSumSqArgs { const float* x; double* partials; long n; int nblk; };
+
+// AdamW (torch.optim.AdamW as train_flow.py:86-88 builds it; amsgrad off), one element:
+//   g' = g * gscale (the clip coefficient); p *= 1 - lr*wd; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),  bc_k = 1 - beta_k^step
+struct PfAdamWArgs { float* p; const float* g; float* m; float* v; long n;
+                     float decay, b1, b2, eps, step_size, sqrt_bc2, gscale; };   // scalars rounded from double like torch's
+PF_HD void pf_adamw_elem(long i, const PfAdamWArgs& a) {
+    const float g = a.g[i] * a.gscale;
+    float p = a.p[i];
+    p = p * a.decay;                                                    // param.mul_(1 - lr * weight_decay)
+    const float m = a.m[i] + (g - a.m[i]) * (1.f - a.b1);               // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = a.v[i] * a.b2 + (g * g) * (1.f - a.b2);             // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(v) / a.sqrt_bc2 + a.eps;
+    p = p + (m / denom) * (-a.step_size);                               // addcdiv_(exp_avg, denom, value=-step_size)
+    a.p[i] = p; a.m[i] = m; a.v[i] = v;
+}
+
 // channel-last -> NCHW (debug / boundary export)
 struct PfToNchwArgs { const float* in; float* out; int B, C, N, ld_in, c_in_off; };
 PF_HD void pf_to_nchw_elem(long idx, const PfToNchwArgs& a) {   // idx over B*C*N

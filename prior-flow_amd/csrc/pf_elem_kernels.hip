@@ -429,6 +429,47 @@ __global__ void __launch_bounds__(256) pf_region_sum_kernel(const PfRegionSumArg
     }
 }
 
+// block (k, b): pixels [k*chunk, (k+1)*chunk) of image b; deterministic two-stage sums as above
+__global__ void __launch_bounds__(256) pf_seq_loss_kernel(const PfSeqLossArgs a) {
+    __shared__ double red[4][6];
+    const int k = blockIdx.x, b = blockIdx.y;
+    const int chunk = (a.N + a.nblk - 1) / a.nblk;
+    const int lo = k * chunk, hi = (lo + chunk < a.N) ? lo + chunk : a.N;
+    double sums[6] = {0, 0, 0, 0, 0, 0};
+    for (int n = lo + threadIdx.x; n < hi; n += 256) pf_seq_loss_pixel(a, b, n, sums);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double v = sums[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+        a.partials[((long)b * a.nblk + k) * 6 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+int launch_seq_loss(const PfSeqLossArgs& a, void* stream) {
+    hipLaunchKernelGGL(pf_seq_loss_kernel, dim3((unsigned)a.nblk, (unsigned)a.B), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) pf_sumsq_kernel(const PfSumSqArgs a) {
+    __shared__ double red[4];
+    const long chunk = (a.n + a.nblk - 1) / a.nblk;
+    const long lo = blockIdx.x * chunk, hi = (lo + chunk < a.n) ? lo + chunk : a.n;
+    double s = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) { const double v = a.x[i]; s += v * v; }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+int launch_sumsq(const PfSumSqArgs& a, void* stream) {
+    hipLaunchKernelGGL(pf_sumsq_kernel, dim3((unsigned)a.nblk), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 int launch_region_sums(const PfRegionSumArgs& a, void* stream) {
     hipLaunchKernelGGL(pf_region_sum_kernel, dim3((unsigned)a.nblk, (unsigned)a.B), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
@@ -437,6 +478,8 @@ int launch_region_sums(const PfRegionSumArgs& a, void* stream) {
 }  // namespace
 
 #define PF_REGION_SUM_LAUNCH(a, stream) launch_region_sums(a, stream)
+#define PF_SEQ_LOSS_LAUNCH(a, stream) launch_seq_loss(a, stream)
+#define PF_SUMSQ_LAUNCH(a, stream) launch_sumsq(a, stream)
 #define PF_FLOW_OUT_LAUNCH(a, total, stream) launch_flow_out(a, total, stream)
 #define PF_NORM_ACT_LAUNCH(a, total, stream) launch_norm_act(a, total, stream)
 #define PF_STATS_LAUNCH launch_stats

@@ -1,0 +1,183 @@
+"""Training-step counterpart of the reference on the HIP kernels -- everything of
+``train_flow.py``'s step EXCEPT the network's backward, which is not built (``PriOr_RAFT.forward``
+raises in ``train()`` mode with autograd on).
+
+Mirrors, with the reference's names and argument meaning:
+  * ``uniform_loss(H, W)(flow_preds, flow_gt, valid, gamma, extro_info, max_flow)`` (train_flow.py:55-79)
+    -> ``(loss, metrics)``; there being no autograd graph, the gradient of the loss with respect to every
+    prediction (what ``loss.backward()`` would feed the network) is left in ``.grads``;
+  * ``rotate_gt(flow_gt)`` -> ``(flow_gt_B, valid_B)`` (train_flow.py:123-126, ``flo_A2B`` + validity);
+  * ``fetch_optimizer(args, model)`` -> ``(FlatAdamW, OneCycleLinearLR)`` (train_flow.py:86-91): AdamW over
+    ONE flat parameter / gradient buffer (the parameters become views of it, so the single RCCL
+    all-reduce of ``parallel.FlatGradAllReduce`` and the fused ``pf_adamw_step`` both see one array)
+    and OneCycleLR(max_lr, num_steps + 100, pct_start=0.05, linear, cycle_momentum=False) in closed form;
+  * ``clip_grad_norm_(optimizer, max_norm)`` (train_flow.py:137): total norm by ``pf_sum_squares``; the
+    clip coefficient is applied inside the AdamW kernel instead of rewriting the gradients.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .engine import rotation_x
+from .evaluate import spherical_mask
+
+MAX_FLOW = 400      # train_flow.py:46
+
+
+class uniform_loss:
+    NBLK = 64
+
+    def __init__(self, H: int, W: int, device=None):
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.H, self.W = H, W
+        self.uniform_mask = torch.from_numpy(spherical_mask(H, W)).float().to(self.device).contiguous()   # H x W
+        self.grads: List[torch.Tensor] = []
+
+    @torch.no_grad()
+    def __call__(self, flow_preds: Sequence[torch.Tensor], flow_gt: torch.Tensor, valid: torch.Tensor,
+                 gamma: float = 0.8, extro_info: str = "", max_flow: float = MAX_FLOW,
+                 need_grads: bool = True) -> Tuple[torch.Tensor, Dict[str, float]]:
+        n = len(flow_preds)
+        gt = flow_gt.float().contiguous()
+        vd = valid.float().contiguous()
+        B = gt.shape[0]
+        part = torch.empty(n, B, self.NBLK, 6, dtype=torch.float64, device=gt.device)
+        self.grads = []
+        weights = []
+        for i, p in enumerate(flow_preds):
+            i_weight = gamma ** (n - i - 1)
+            weights.append(i_weight)
+            g = torch.empty_like(gt) if need_grads else None
+            self.lib.seq_loss(p.float().contiguous(), gt, vd, self.uniform_mask.view(-1), i_weight, float(max_flow),
+                              g, part[i])
+            if need_grads:
+                self.grads.append(g)
+        tot = part.sum(dim=(1, 2))                                     # [n, 6]
+        w = torch.tensor(weights, dtype=torch.float64, device=gt.device)
+        flow_loss = (w * tot[:, 0]).sum().float()
+        last = tot[-1].tolist()
+        nv = max(last[2], 1.0)
+        metrics = {extro_info + "epe": last[1] / nv, extro_info + "1px": last[3] / nv,
+                   extro_info + "3px": last[4] / nv, extro_info + "5px": last[5] / nv}
+        return flow_loss, metrics
+
+
+_GT_GRIDS: Dict[tuple, tuple] = {}
+
+
+@torch.no_grad()
+def rotate_gt(flow_gt: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """flow_gt_B = flo_A2B(flow_gt) (core/utils/projection_prim_ortho.py:563-565) and
+    valid_B = (|u| < 1000) & (|v| < 1000) as float (train_flow.py:123-126)."""
+    lib = _lib.load()
+    fl = flow_gt.float().contiguous()
+    B, _, H, W = fl.shape
+    key = (H, W, fl.device)
+    if key not in _GT_GRIDS:
+        g_a2b = torch.empty(2, H, W, device=fl.device)
+        g_b2a = torch.empty(2, H, W, device=fl.device)
+        lib.sample_grid(g_a2b, rotation_x(-math.pi / 2))
+        lib.sample_grid(g_b2a, rotation_x(math.pi / 2))
+        _GT_GRIDS[key] = (g_a2b, g_b2a)
+    g_a2b, g_b2a = _GT_GRIDS[key]
+    out = torch.empty_like(fl)
+    # flo_rotate(flow, W2C = grid(R_A2B^T) == grid(R_B2A), C2W = grid(R_A2B))
+    lib.flo_rotate(fl, g_b2a, g_a2b, out)
+    valid_b = ((out[:, 0].abs() < 1000) & (out[:, 1].abs() < 1000)).float()
+    return out, valid_b
+
+
+class OneCycleLinearLR:
+    """OneCycleLR(optimizer, max_lr, total_steps, pct_start=0.05, cycle_momentum=False, anneal_strategy='linear')."""
+
+    def __init__(self, optimizer: "FlatAdamW", max_lr: float, total_steps: int, pct_start: float = 0.05,
+                 div_factor: float = 25.0, final_div_factor: float = 1e4):
+        self.optimizer, self.max_lr, self.total = optimizer, max_lr, total_steps
+        self.initial = max_lr / div_factor
+        self.min_lr = self.initial / final_div_factor
+        self.end1 = float(pct_start * total_steps) - 1
+        self.step_num = 0
+        self._apply()
+
+    def lr_at(self, step: int) -> float:
+        if step <= self.end1:
+            return (self.max_lr - self.initial) * (step / self.end1) + self.initial
+        return (self.min_lr - self.max_lr) * ((step - self.end1) / ((self.total - 1) - self.end1)) + self.max_lr
+
+    def _apply(self):
+        for grp in self.optimizer.param_groups:
+            grp["lr"] = self.lr_at(self.step_num)
+
+    def step(self):
+        self.step_num += 1
+        if self.step_num > self.total:
+            raise ValueError(f"Tried to step {self.step_num} times. The specified number of total steps is {self.total}")
+        self._apply()
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+
+class FlatAdamW:
+    """AdamW(model.parameters(), lr, weight_decay, eps) with every parameter, gradient and moment in one
+    flat fp32 buffer each; ``p.data`` / ``p.grad`` of the model become views of ``flat`` / ``grad``."""
+
+    def __init__(self, params, lr: float, weight_decay: float, eps: float, betas=(0.9, 0.999)):
+        self.lib = _lib.load()
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        o = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + k].view_as(p)
+            p.grad = self.grad[o:o + k].view_as(p)
+            o += k
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "eps": eps, "betas": betas}]
+        self.step_count = 0
+        self.grad_scale = 1.0
+        self._norm_part = torch.empty(256, dtype=torch.float64, device=dev)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def total_grad_norm(self) -> float:
+        self.lib.sum_squares(self.grad, self._norm_part)
+        return float(self._norm_part.sum().sqrt())
+
+    @torch.no_grad()
+    def step(self):
+        g = self.param_groups[0]
+        self.step_count += 1
+        self.lib.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
+                            g["eps"], g["weight_decay"], self.step_count, self.grad_scale)
+        self.grad_scale = 1.0
+
+
+def clip_grad_norm_(optimizer: FlatAdamW, max_norm: float) -> float:
+    """torch.nn.utils.clip_grad_norm_: returns the total norm; the coefficient min(1, max_norm/(norm+1e-6))
+    is applied to the gradients by the next ``optimizer.step()`` (inside the AdamW kernel)."""
+    total = optimizer.total_grad_norm()
+    optimizer.grad_scale = min(1.0, float(max_norm) / (total + 1e-6))
+    return total
+
+
+def fetch_optimizer(args, model):
+    """Create the optimizer and learning rate scheduler (train_flow.py:86-91)."""
+    optimizer = FlatAdamW(model.parameters(), lr=args.lr, weight_decay=args.wdecay, eps=args.epsilon)
+    scheduler = OneCycleLinearLR(optimizer, args.lr, args.num_steps + 100, pct_start=0.05)
+    return optimizer, scheduler

@@ -14,6 +14,29 @@ static int pf_loop(const Args& a, long total) {
 #define PF_LAUNCH(name, args, total, stream) pf_loop<decltype(args), pf_##name##_elem>(args, total)
 #define PF_DIRECT_CONV_LAUNCH(a, total, stream) pf_loop<PfDirectConvArgs, pf_direct_conv_elem>(a, total)
 
+// host statements of pf_seq_loss / pf_sum_squares (same chunk partition, sequential sums inside a chunk)
+static int emu_seq_loss(const PfSeqLossArgs& a, void*) {
+    const int chunk = (a.N + a.nblk - 1) / a.nblk;
+    for (int b = 0; b < a.B; ++b)
+        for (int k = 0; k < a.nblk; ++k) {
+            double sums[6] = {0, 0, 0, 0, 0, 0};
+            for (int n = k * chunk; n < (k + 1) * chunk && n < a.N; ++n) pf_seq_loss_pixel(a, b, n, sums);
+            for (int j = 0; j < 6; ++j) a.partials[((long)b * a.nblk + k) * 6 + j] = sums[j];
+        }
+    return PF_OK;
+}
+static int emu_sumsq(const PfSumSqArgs& a, void*) {
+    const long chunk = (a.n + a.nblk - 1) / a.nblk;
+    for (int k = 0; k < a.nblk; ++k) {
+        double s = 0;
+        for (long i = k * chunk; i < (k + 1) * chunk && i < a.n; ++i) s += (double)a.x[i] * (double)a.x[i];
+        a.partials[k] = s;
+    }
+    return PF_OK;
+}
+#define PF_SEQ_LOSS_LAUNCH(a, stream) emu_seq_loss(a, stream)
+#define PF_SUMSQ_LAUNCH(a, stream) emu_sumsq(a, stream)
+
 // host statement of pf_channel_stats_final
 static int emu_stats_final(const double* part, int B, int Np, int C, int nblk, float eps, float* scale, float* shift, void*) {
     for (int b = 0; b < B; ++b)

@@ -372,7 +372,43 @@ def case_flow_metrics(lib, dev):
         assert float((got[:, r] - want).abs().max()) < 1e-9, ("region_sums", r)
 
 
+def case_training_pieces(lib, dev):
+    """pf_seq_loss / pf_sum_squares / pf_adamw_step vs the oracle's restatement of train_flow.py."""
+    from gen_golden_train import adam_case, loss_case
+    preds, gt, valid = loss_case(16, 32, 2, 2)
+    B, _, h, w = gt.shape
+    uni = po.spherical_mask(h, w).contiguous()
+    want_loss, want_metrics, want_grads = po.uniform_loss(preds, gt, valid, gamma=0.8)
+    total = 0.0
+    for i, p in enumerate(preds):
+        part = torch.zeros(B, 3, 6, dtype=torch.float64, device=dev)
+        g = torch.empty(B, 2, h, w, device=dev)
+        wgt = 0.8 ** (len(preds) - i - 1)
+        lib.seq_loss(p.to(dev), gt.to(dev), valid.to(dev), uni.view(-1).to(dev), wgt, 400.0, g, part)
+        check(g, want_grads[i], 1e-9, f"loss gradient {i}")
+        tot = part.sum((0, 1)).cpu()
+        total += wgt * float(tot[0])
+    assert abs(total - want_loss) < 1e-9 * abs(want_loss)
+    assert abs(float(tot[1] / tot[2]) - want_metrics["epe"]) < 1e-7
+    for j, key in ((3, "1px"), (4, "3px"), (5, "5px")):
+        assert abs(float(tot[j] / tot[2]) - want_metrics[key]) < 1e-12
+    p0, grads = adam_case(1031, 3)
+    part = torch.zeros(7, dtype=torch.float64, device=dev)
+    lib.sum_squares(grads[0].to(dev), part)
+    assert abs(float(part.sum()) - float((grads[0].double() ** 2).sum())) < 1e-9 * float((grads[0].double() ** 2).sum())
+    p, m, v = p0.clone().to(dev), torch.zeros(1031, device=dev), torch.zeros(1031, device=dev)
+    wp, wm, wv = p0.clone(), torch.zeros(1031), torch.zeros(1031)
+    for k, gk in enumerate(grads):
+        lr = po.one_cycle_lr(k, 1e-4, 60000)
+        c = po.clip_coef(float((gk.double() ** 2).sum().sqrt()), 1.0)
+        lib.adamw_step(p, gk.to(dev), m, v, lr, 0.9, 0.999, 1e-8, 5e-5, k + 1, c)
+        wp, wm, wv = po.adamw_step(wp, gk * np.float32(c), wm, wv, lr, k + 1, 5e-5)
+    check(p, wp, 2e-8, "adamw params")
+    check(m, wm, 1e-7, "adamw exp_avg")
+    check(v, wv, 1e-7, "adamw exp_avg_sq")
+
+
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
-                     case_flow_metrics, case_bad_args]
+                     case_flow_metrics, case_training_pieces, case_bad_args]

@@ -1,0 +1,69 @@
+"""GPU tests of the training-step counterpart (everything except the network's backward):
+uniform_loss, rotate_gt, fetch_optimizer (FlatAdamW + OneCycleLinearLR), clip_grad_norm_ against the
+reference-generated goldens in tests/golden/train.npz."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from gen_golden_train import adam_case, loss_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_uniform_loss_and_gt_rotation_vs_reference():
+    from prior_flow_amd import train as tr
+    g = gc.load("train")
+    preds, gt, valid = loss_case()
+    crit = tr.uniform_loss(64, 128)
+    loss, metrics = crit([p.cuda() for p in preds], gt.cuda(), valid.cuda(), 0.8, extro_info="A-")
+    assert loss.dtype == torch.float32 and abs(float(loss) - float(g["loss"])) < 2e-6 * float(g["loss"])
+    for j, key in enumerate(("A-epe", "A-1px", "A-3px", "A-5px")):
+        assert abs(metrics[key] - g["metrics"][j]) < 1e-6
+    assert float((crit.grads[0].cpu()[:, :, ::4, ::4] - torch.from_numpy(g["grad0"])).abs().max()) < 1e-9
+    assert float((crit.grads[2].cpu()[:, :, ::2, ::2] - torch.from_numpy(g["grad2"])).abs().max()) < 1e-9
+    gt_b, valid_b = tr.rotate_gt(gt.cuda())
+    # the grids are generated on the device (fp32 trig differs from the CPU's by ulps) and this GT has
+    # flows of up to 350 px sampled near the poles, where the grid is steep: a few 1e-4 px at worst
+    err = (gt_b.cpu()[:, :, ::2, ::2] - torch.from_numpy(g["gt_b"])).abs()
+    assert float(err.max()) < 3e-3 and float(err.mean()) < 2e-5
+    assert float(valid_b.sum()) == float(g["valid_b_sum"])
+
+
+def test_fetch_optimizer_trajectory_vs_reference():
+    from prior_flow_amd import train as tr
+    g = gc.load("train")
+    args = argparse.Namespace(lr=1e-4, wdecay=5e-5, epsilon=1e-8, num_steps=60000, clip=1.0)
+    p0, grads = adam_case()
+    model = torch.nn.ParameterList([torch.nn.Parameter(p0[:1000].clone().cuda()), torch.nn.Parameter(p0[1000:].clone().cuda())])
+    opt, sched = tr.fetch_optimizer(args, model)
+    assert model[0].data.data_ptr() == opt.flat.data_ptr() and model[1].grad.data_ptr() == opt.grad[1000:].data_ptr()
+    for k, gk in enumerate(grads):
+        opt.zero_grad()
+        model[0].grad.copy_(gk[:1000]); model[1].grad.copy_(gk[1000:])
+        norm = tr.clip_grad_norm_(opt, args.clip)
+        assert abs(norm - g["norms"][k]) < 2e-6 * norm
+        opt.step(); sched.step()
+        assert abs(opt.param_groups[0]["lr"] - g["lrs"][k]) < 1e-15
+    got = torch.cat([model[0].detach().cpu(), model[1].detach().cpu()])
+    assert float((got - torch.from_numpy(g["p_final"])).abs().max()) < 5e-8
+    for i, lr in zip(g["sched_idx"], g["sched_lr"]):
+        assert abs(sched.lr_at(int(i)) - lr) <= 1e-15 + 1e-12 * lr
+    with pytest.raises(ValueError):
+        s2 = tr.OneCycleLinearLR(opt, 1e-4, 3)
+        for _ in range(4):
+            s2.step()
+
+
+def test_train_mode_forward_still_raises():
+    """The backward kernels are not built: the drop-in module must fail loudly, not fall back."""
+    from prior_flow_amd.modules import state_dict_shapes
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    m.load_state_dict(gc.det_state_dict(state_dict_shapes()), strict=True)
+    m = m.cuda().train()
+    i1, i2 = gc.synthetic_pair(1, 128, 256)
+    with pytest.raises(NotImplementedError):
+        m(i1.cuda(), i2.cuda(), iters=2)

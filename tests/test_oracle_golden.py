@@ -273,3 +273,28 @@ def test_eval_region_metrics():
     for i, name in enumerate(("All", "Equator", "Poles", "Center")):
         for j, key in enumerate(("epe", "sd", "sd_uni")):
             assert abs(r[name][key] - g["regions"][i, j]) <= 2e-6 * abs(g["regions"][i, j]), (name, key)
+
+
+# ---- training-step counterpart: oracle vs the reference's train_flow.py helpers -------
+def test_train_loss_schedule_optimizer():
+    from gen_golden_train import adam_case, loss_case
+    g = gc.load("train")
+    preds, gt, valid = loss_case()
+    loss, met, grads = po.uniform_loss(preds, gt, valid, gamma=0.8)
+    assert abs(loss - float(g["loss"])) < 2e-7 * abs(loss)                     # reference sums in fp32
+    for j, key in enumerate(("epe", "1px", "3px", "5px")):
+        assert abs(met[key] - g["metrics"][j]) < 1e-6
+    close(grads[0][:, :, ::4, ::4], g["grad0"], 0.0, what="autograd grad of prediction 0")
+    close(grads[2][:, :, ::2, ::2], g["grad2"], 0.0, what="autograd grad of prediction 2")
+    for i, lr in zip(g["sched_idx"], g["sched_lr"]):
+        assert abs(po.one_cycle_lr(int(i), 1e-4, 60000) - lr) <= 1e-15 + 1e-12 * lr
+    assert abs(po.one_cycle_lr(1, 1e-4, 60000) - 4.032e-6) < 1e-9           # SURVEY.md 8c known answers
+    assert abs(po.one_cycle_lr(2, 1e-4, 60000) - 4.064e-6) < 1e-9
+    p0, grads = adam_case()
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for k, gk in enumerate(grads):
+        norm = float((gk.double() ** 2).sum().sqrt())
+        assert abs(norm - g["norms"][k]) < 2e-6 * norm
+        p, m, v = po.adamw_step(p, gk * np.float32(po.clip_coef(norm, 1.0)), m, v, po.one_cycle_lr(k, 1e-4, 60000), k + 1, 5e-5)
+        assert abs(po.one_cycle_lr(k + 1, 1e-4, 60000) - g["lrs"][k]) < 1e-15
+    close(p, g["p_final"], 5e-8, what="AdamW + clip trajectory")
