@@ -133,7 +133,7 @@ typedef struct pf_conv_desc {
     /* optional InstanceNorm statistics of THIS conv's output, fused into its epilogue (halo-kernel
      * tiles 3/4/5 with PF_EPI_LINEAR only): stats_out[((image*nblk + tile)*cout + c)*2 + {0,1}] =
      * fp64 sum / sum of squares of output channel c over one workgroup tile, nblk = tiles per image =
-     * (H8/TH)*(W8/32), TH = 8 for tile 5 else 4.  Finish with pf_channel_stats_final.  NULL = none. */
+     * ceil(H8/TH)*ceil(W8/32), TH = 8 for tile 5 else 4.  Finish with pf_channel_stats_final.  NULL = none. */
     double* stats_out;
 } pf_conv_desc;
 

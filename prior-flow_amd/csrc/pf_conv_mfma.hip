@@ -308,7 +308,7 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// Halo-tile kernel (PF_PREC_BF16X3; 3x3, 1x5, 5x1, 4x4 and 1x1 taps; W8 % 32 == 0, H8 % 4 == 0).
+// Halo-tile kernel (PF_PREC_BF16X3; 3x3, 1x5, 5x1, 4x4 and 1x1 taps; any map size, partial edge tiles).
 //
 // With 3-pass bf16 MFMAs a K-step carries 5x less matrix time than in exact fp32, so the generic
 // kernel above becomes bound by what surrounds the MFMAs: every tap re-loads and re-splits the
@@ -361,7 +361,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar wave id
     const int li = lane & 31, lh = lane >> 5;
     const int wy = (TH == 4) ? wave >> 1 : wave, wn = (TH == 4) ? wave & 1 : 0;
-    const int tiles_x = g.W / TW, tiles_y = g.H / TH;
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;   // edge tiles may be partial
     const int tile = blockIdx.x;
     const int x0 = (tile % tiles_x) * TW;
     const int y0 = ((tile / tiles_x) % tiles_y) * TH;
@@ -629,7 +629,14 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
 
     // ---- epilogue -----------------------------------------------------------------------------
 #ifndef PF_ABLATE_NO_EPILOGUE
-    tile_epilogue<NT, false>(d, acc, n0 + 32 * NT * wn, li, pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh, 0);
+    // ragged maps (W % 32 or H % TH != 0): the loader already zero-fills what lies outside the image;
+    // here columns >= W and rows >= H of an edge tile are neither stored nor counted
+    const bool ragged = (g.W % TW) != 0 || (g.H % TH) != 0;                       // uniform
+    const bool row_ok = y0 + wy < g.H;
+    const int xlim = row_ok ? g.W - x0 - 4 * lh : 0;                              // pixel r is live iff roff(r) < xlim
+    const long p0 = pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh;
+    if (ragged) tile_epilogue<NT, true>(d, acc, n0 + 32 * NT * wn, li, p0, p0 + (xlim > 0 ? xlim : 0));
+    else tile_epilogue<NT, false>(d, acc, n0 + 32 * NT * wn, li, p0, 0);
     if (d.stats_out != nullptr) {
         // InstanceNorm statistics of this tile's outputs (the stored values, (acc + bias) * scale): fp64
         // sum / sum of squares per channel over the wave's 32 pixels, the wave's two halves by a
@@ -643,7 +650,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const double v = (double)((acc[t][r] + bias) * d.scale);
+                const double v = ((r & 3) + 8 * (r >> 2) < xlim) ? (double)((acc[t][r] + bias) * d.scale) : 0.0;
                 s1 += v; s2 += v * v;
             }
             s1 += __shfl_xor(s1, 32);
@@ -680,7 +687,8 @@ int launch_conv_halo_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, in
     const size_t lds = (size_t)(2 * HALO_ROWS + 3 * BN) * LDS_LD * sizeof(float);
     static_assert((2 * HALO_ROWS + 3 * BN) * LDS_LD * sizeof(float) <= 160 * 1024, "LDS budget");
     const int B = g.M / g.N;
-    dim3 grid((unsigned)(B * (g.H / TH) * (g.W / 32)), (unsigned)((max_cout + BN - 1) / BN), (unsigned)ngroups);
+    dim3 grid((unsigned)(B * ((g.H + TH - 1) / TH) * ((g.W + 31) / 32)), (unsigned)((max_cout + BN - 1) / BN),
+              (unsigned)ngroups);
     // up to ~130 KB of dynamic LDS: above the 64 KB default limit
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>),
@@ -780,15 +788,16 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // BN in {32,64,128} is legal.  Small problems (one 512x1024 pair = 8192 pixels per branch) need
 // the smaller tile to put >= 1 workgroup on each of the 256 CUs.
 // 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
-// 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3, >= 3 taps, W8 % 32 == 0, H8 % 4 == 0)
-// 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, H8 % 8 == 0, enough pixels to fill the chip)
+// 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3; any map size: edge tiles may be partial)
+// 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, enough pixels to fill the chip)
 static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
     const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1) ||
                             (g.kh == 4 && g.kw == 4) || (g.kh == 1 && g.kw == 1);
-    if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1 && g.W % 32 == 0 && g.H % 4 == 0 &&
-        !pf_conv_force_generic()) {
-        const long wgs128 = ((long)g.M / 128) * ngroups * ((max_cout + 127) / 128);
-        if (max_cout <= 64 && g.kh == g.kw && g.kh > 1 && g.H % 8 == 0 && ((long)g.M / 256) * ngroups >= 512) return 5;
+    if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1 && !pf_conv_force_generic()) {
+        const long B = g.M / g.N;
+        const long tiles4 = B * ((g.H + 3) / 4) * ((g.W + 31) / 32), tiles8 = B * ((g.H + 7) / 8) * ((g.W + 31) / 32);
+        const long wgs128 = tiles4 * ngroups * ((max_cout + 127) / 128);
+        if (max_cout <= 64 && g.kh == g.kw && g.kh > 1 && tiles8 * ngroups >= 512) return 5;
         return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
     }
     const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;

@@ -18,8 +18,9 @@
 // Exact fp32: v_mfma_f32_32x32x2_f32 with the same K permutation / LDS staging as
 // pf_conv_mfma.hip (16-byte coalesced fills, ds_read_b128 operands, 144-byte padded rows).
 //
-// Generic path (any H8,W8 % 8 == 0): same GEMM on 256 consecutive n2 columns, level 0 only;
-// levels 1..3 then come from a small pooling kernel.
+// Generic path (any H8, W8 >= 16): same GEMM on 256 consecutive n2 columns, level 0 only; levels
+// 1..3 then come from a small pooling kernel (odd sizes drop the last row / column like
+// F.avg_pool2d(2, stride=2), core/corr.py:108).
 #include <type_traits>
 #include "pf_common.h"
 #include "../../include/priorflow_hip.h"
@@ -359,7 +360,8 @@ static int corr_launch(const float* f1, const float* f2, float* lvl0, float* lvl
                        int B, int H8, int W8, int C, bool split, void* stream) {
     if (!f1 || !f2 || !lvl0 || !lvl1 || !lvl2 || !lvl3) return PF_ERR_BAD_ARG;
     if (B <= 0 || H8 <= 0 || W8 <= 0 || C <= 0 || (C % KC) != 0) return PF_ERR_BAD_SHAPE;
-    if ((H8 % 8) != 0 || (W8 % 8) != 0) return PF_ERR_BAD_SHAPE;
+    // any map with a 2x2 (or larger) level 3; odd sizes pool with avg_pool2d's floor semantics on the generic path
+    if ((H8 >> 3) < 2 || (W8 >> 3) < 2) return PF_ERR_BAD_SHAPE;
     if ((long)H8 * W8 * C >= (1L << 31)) return PF_ERR_BAD_SHAPE;      // 32-bit row offsets in the kernel
     if ((long)B * ((H8 * W8 + BM - 1) / BM) * ((H8 * W8 + 31) / 32) >= (1L << 31)) return PF_ERR_BAD_SHAPE;   // 1-D grid
     CorrArgs a;
@@ -373,7 +375,7 @@ static int corr_launch(const float* f1, const float* f2, float* lvl0, float* lvl
         a.scale_mul = (m == 0.5f && a.inv_scale * a.inv_scale == (float)C) ? 1.f / a.inv_scale : 0.f;
     }
     hipStream_t s = (hipStream_t)stream;
-    const bool fused = (W8 % 32) == 0 && (a.N % BM) == 0;
+    const bool fused = (W8 % 32) == 0 && (H8 % 8) == 0 && (a.N % BM) == 0;
     if (fused) {
         a.tiles_x = W8 / 32;
         a.n2_tiles = (H8 / 8) * a.tiles_x;

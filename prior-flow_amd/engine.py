@@ -190,9 +190,9 @@ class Workspace:
     """All device buffers of one (B, H, W) problem; allocated once, reused every call."""
 
     def __init__(self, lib: PfLib, B: int, H: int, W: int, device):
-        if H % 64 or W % 64:
-            raise PfError(f"image size {H}x{W}: the HIP path needs H and W to be multiples of 64 "
-                          "(H/8 and W/8 multiples of 8 so that every pyramid level pools exactly)")
+        if H % 8 or W % 8 or H < 128 or W < 128:
+            raise PfError(f"image size {H}x{W}: H and W must be multiples of 8 (callers pad, core/utils/utils.py:7-27) "
+                          "and at least 128 (the coarsest pyramid level must be 2x2 or larger)")
         self.B, self.H, self.W = B, H, W
         self.H8, self.W8 = H // 8, W // 8
         self.N = self.H8 * self.W8
@@ -582,7 +582,8 @@ class EncoderPlan:
         if self.kind != "batch":
             tile = lib.conv2d_tile([d], Bn, h, w)
             if tile >= 3:
-                nblk = (h // (8 if tile == 5 else 4)) * (w // 32)
+                th = 8 if tile == 5 else 4
+                nblk = ((h + th - 1) // th) * ((w + 31) // 32)
                 if Bn * nblk * cout * 2 <= bufs["part"].numel():
                     d.stats_out = bufs["part"].data_ptr()
                     fused = True

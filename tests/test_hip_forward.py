@@ -158,6 +158,31 @@ def test_training_mode_raises(model):
 
 def test_bad_size_raises(model):
     from prior_flow_amd._lib import PfError
-    x = torch.zeros(1, 3, 136, 256, device="cuda")
-    with pytest.raises(PfError):
-        model(x, x, iters=1, test_mode=True)
+    for h, w in ((132, 256), (128, 250), (120, 256)):      # not multiples of 8 / coarsest level below 2x2
+        x = torch.zeros(1, 3, h, w, device="cuda")
+        with pytest.raises(PfError):
+            model(x, x, iters=1, test_mode=True)
+
+
+@pytest.mark.parametrize("size", [(136, 216), (160, 360), (480, 960)])
+def test_forward_sizes_that_are_only_multiples_of_8(model, size):
+    """The reference accepts any H, W % 8 == 0 (callers pad, core/utils/utils.py:7-27): 1/8 maps of 17x27
+    and 20x45 (odd pyramid levels, partial conv tiles everywhere) against the reference's own output,
+    and the common ERP size 480x960 (60x120) against the CPU oracle."""
+    h, w = size
+    i1, i2 = gc.synthetic_pair(1, h, w, seed=31)
+    pa, pb = model(i1.cuda(), i2.cuda(), iters=3)
+    assert pa[-1].shape == (1, 2, h, w)
+    if (h, w) == (480, 960):
+        from prior_flow_amd.modules import state_dict_shapes
+        want_a, want_b = po.forward(gc.det_state_dict(state_dict_shapes()), i1, i2, iters=3)
+        ma, _ = epe(pa[-1], want_a[-1])
+        mb, _ = epe(pb[-1], want_b[-1])
+    else:
+        g = gc.load("forward_odd")
+        ma, _ = epe(pa[-1], g[f"a_{h}x{w}"])
+        mb, _ = epe(pb[-1][:, :, ::2, ::2], g[f"b_{h}x{w}"])
+    # 160x360: branch B sits on the reference's own odd-W8 knife edge (tests/test_oracle_golden.py)
+    assert ma < EPE_BAR and mb < (5e-3 if (h, w) == (160, 360) else EPE_BAR), (size, ma, mb)
+    tm = model(i1.cuda(), i2.cuda(), iters=3, test_mode=True)          # graph-captured path, same result
+    assert float((tm - pa[-1]).abs().max()) < 1e-4

@@ -284,7 +284,8 @@ def _check_fused_stats(lib, dev, cv, xin, cin, cout, B, h, w, expect_tile):
     d = cv.desc(xin, 0, cin, out, 0, EPI_LINEAR)
     tile = lib.conv2d_tile([d], B, h, w)
     assert tile == expect_tile
-    nblk = (h // (8 if tile == 5 else 4)) * (w // 32)
+    th = 8 if tile == 5 else 4
+    nblk = ((h + th - 1) // th) * ((w + 31) // 32)
     part = torch.full((B, nblk, cout, 2), float("nan"), dtype=torch.float64, device=dev)
     d.stats_out = part.data_ptr()
     lib.conv2d([d], B, h, w, xin)
