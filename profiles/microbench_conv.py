@@ -37,6 +37,27 @@ def conv(cin, cout, kh, kw):
     return Conv(wp, bp, kh, kw, cin, cout, prec)
 
 
+if which == "l1":        # encoder layer-1 conv: 3x3 64 -> 64 at 1/2 resolution (256 x 512), MB_BATCH images
+    H8, W8 = 256, 512
+    N = H8 * W8
+    xin = rnd(BATCH * N, 64)
+    yout = torch.empty(BATCH * N, 64, device=dev)
+    cv1 = conv(64, 64, 3, 3)
+    descs = [cv1.desc(xin, 0, 64, yout, 0, EPI_RELU)]
+    flops = 2.0 * BATCH * N * 64 * 9 * 64
+    for _ in range(3):
+        lib.conv2d(descs, BATCH, H8, W8, xin)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        lib.conv2d(descs, BATCH, H8, W8, xin)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / reps
+    print(f"l1 x{BATCH}: tile {lib.conv2d_tile(descs, BATCH, H8, W8)}  {us:.1f} us/launch  {flops / us / 1e6:.1f} TFLOP/s algorithmic  "
+          f"{BATCH * N * 64 * 8 / us / 1e6:.2f} TB/s in+out")
+    sys.exit(0)
 net = [rnd(N, 128) for _ in range(2)]
 x = [rnd(N, 256) for _ in range(2)]
 z = [torch.empty(N, 128, device=dev) for _ in range(2)]
