@@ -10,7 +10,13 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "pf_corr_kernel" in r["Kernel_Name"]]
 starts = idx[0::2]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else max(0, len(starts) - 4)
+if len(sys.argv) > 2:
+    k = int(sys.argv[2])
+else:
+    # the shortest complete window = a steady-state HIP-graph replay (bench.py also runs warm-up,
+    # eager kernel-profiling and capture forwards, which are longer)
+    spans = [int(rows[starts[j + 1] - 1]["End_Timestamp"]) - int(rows[starts[j]]["Start_Timestamp"]) for j in range(len(starts) - 1)]
+    k = min(range(len(spans)), key=lambda j: spans[j])
 seg = rows[starts[k]:starts[k + 1]]
 agg = collections.OrderedDict()
 for r in seg:
