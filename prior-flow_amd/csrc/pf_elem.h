@@ -13,12 +13,21 @@
 // ----------------------------------------------------------------------------------------------
 // scalar helpers
 // ----------------------------------------------------------------------------------------------
-// Python-style float remainder in [0,b) for b>0 (`xgrid % W`, core/utils/utils.py:83;
-// ATen: fmod then +b when the signs differ).
+// Python-style float remainder for b > 0 (`xgrid % W`, core/utils/utils.py:83; ATen: fmod, then +b when
+// the signs differ), bit for bit, without the device's (long, loop-based) fmodf:
+//   0 <= a < b            -> a                       (fmod is the identity)
+//   -b < a < 0            -> a + b, ROUNDED          (ATen adds b to fmod = a; a tiny negative gives exactly b)
+//   otherwise             -> a - b*floor(a/b): q from a*(1/b) can be off by one, r = fma(-q, b, a) is exact
+//                            (for |a| >= b the true remainder lies on a's own ulp grid), one correction step.
+// NaN / +-inf propagate to NaN like fmod.  b is an image width (an integer <= 2^20) here.
 PF_HD float pf_pymod(float a, float b) {
-    float m = fmodf(a, b);
-    if (m != 0.f && m < 0.f) m += b;
-    return m;
+    if (a >= 0.f && a < b) return a;
+    if (a < 0.f && a > -b) return a + b;
+    const float q = floorf(a * (1.f / b));
+    float r = fmaf(-q, b, a);
+    if (r < 0.f) r += b;
+    else if (r >= b) r -= b;
+    return r == 0.f ? copysignf(0.f, a) : r;       // fmod keeps the dividend's sign on an exact multiple
 }
 
 // pixel -> [-1,1] -> pixel round trip of `2x/(W-1)-1` (core/utils/utils.py:85-86) followed

@@ -45,3 +45,15 @@ def test_emu_case(emu, case):
 
 def test_emu_direct_conv(emu, params):
     kc.case_direct_conv(emu, torch.device("cpu"), params)
+
+
+def test_pymod_matches_aten_remainder_bitwise(tmp_path):
+    """pf_pymod replaces fmodf by a floor/FMA step + correction: it must reproduce ATen's `%` bit for bit
+    (exact multiples incl. the signed zero, neighbours of multiples, tiny negatives that round to W)."""
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler")
+    exe = str(tmp_path / "pf_pymod_check")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "prior-flow_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "emu", "pf_pymod_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-500:]
