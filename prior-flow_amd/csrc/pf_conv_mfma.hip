@@ -599,7 +599,10 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
             if constexpr (i >= 1 && i <= NT) fetch_B(NXT{}, std::integral_constant<int, i - 1>{}, s1);
 #endif
             if constexpr (i == NT + 1) {
-#ifndef PF_ABLATE_NO_LDS_WRITE
+#if defined(PF_ABLATE_NO_B_STORE)           // timing-only: bound on what an LDS-DMA weight path could save
+                if constexpr (cur == 0) asm volatile("" :: "v"(rb0[0]), "v"(rb0[B_V4 - 1]));
+                else asm volatile("" :: "v"(rb1[0]), "v"(rb1[B_V4 - 1]));
+#elif !defined(PF_ABLATE_NO_LDS_WRITE)
                 if constexpr (cur == 0) store_B(s2, rb0); else store_B(s2, rb1);
 #endif
 #ifndef PF_ABLATE_NO_GLOBAL
