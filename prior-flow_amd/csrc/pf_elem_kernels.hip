@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvArgs 
     const int li = lane & 31, lh = lane >> 5;
     const int ngrp = (a.Cout + 31) / 32;
     const int ph = a.KH / 2, pw = a.KW / 2;
-    const int segs_x = a.Wo / 32;
+    const int segs_x = (a.Wo + 31) / 32;            // the last 32-pixel segment of a row may be partial
     const long nitems = (long)a.B * a.Ho * segs_x * ngrp;
     const long Nin = (long)a.H * a.W, Nout = (long)a.Ho * a.Wo;
     const int a_lane = li * a.stride * CinP;
@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvArgs 
                 v = v + bias;
                 if (a.relu) v = fmaxf(v, 0.f);
                 const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                a.out[(b * Nout + (long)yo * a.Wo + sx * 32 + px) * a.ld_out + a.c_out_off + j] = v;
+                if (sx * 32 + px < a.Wo)
+                    a.out[(b * Nout + (long)yo * a.Wo + sx * 32 + px) * a.ld_out + a.c_out_off + j] = v;
             }
         }
     }
@@ -208,7 +209,7 @@ int launch_small_conv(const PfSmallConvArgs& a, void* stream) {
     const int PW = 31 * a.stride + a.KW;
     const int patch_elems = a.KH * PW * (a.Cin | 1);
     const size_t lds = ((size_t)((patch_elems + 3) & ~3) + 3 * 16 * 64) * 4;
-    const long nitems = (long)a.B * a.Ho * (a.Wo / 32) * ((a.Cout + 31) / 32);
+    const long nitems = (long)a.B * a.Ho * ((a.Wo + 31) / 32) * ((a.Cout + 31) / 32);
     const int ngrp = (a.Cout + 31) / 32;
     const long cap = (256L * 8 / ngrp) * ngrp;      // ~8 workgroups per CU, a multiple of ngrp (see kernel)
     const long blocks = nitems < cap ? nitems : cap;
@@ -491,7 +492,7 @@ int launch_region_sums(const PfRegionSumArgs& a, void* stream) {
 static int pf_direct_conv_dispatch(const PfDirectConvArgs& d, long total, void* stream) {
     const int K = d.KH * d.KW * d.Cin;
     const size_t lds = ((size_t)d.KH * (31 * d.stride + d.KW) * (d.Cin | 1) + 4 + 3 * 16 * 64) * 4;
-    if (d.W % 32 == 0 && lds <= 60 * 1024 && (K + 1) / 2 <= 160 &&
+    if (lds <= 60 * 1024 && (K + 1) / 2 <= 160 &&
         d.KH * (31 * d.stride + d.KW) * d.Cin <= 16 * 256 && d.Cin <= 255) {
         PfSmallConvArgs a;
         a.in = d.in; a.ld_in = d.ld_in; a.c_in_off = d.c_in_off; a.Cin = d.Cin; a.nchw = d.nchw;

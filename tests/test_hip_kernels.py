@@ -299,6 +299,21 @@ def _check_fused_stats(lib, dev, cv, xin, cin, cout, B, h, w, expect_tile):
     kc.check(sh, sh2, 1e-6 * float(sh2.abs().max()) + 1e-7, f"fused stats shift (tile {tile})")
 
 
+def test_small_conv_partial_segments(lib, dev):
+    """The small-Cin MFMA kernel works on 32-pixel row segments: a width that is not a multiple of 32
+    (W8 = 27, 45, 120) ends in a partial segment (core/update.py:171-178 at sizes like 480x960)."""
+    for H8, W8 in ((17, 27), (9, 45), (6, 120)):
+        x = gc.uni(f"rag/x{W8}", (2, 2, H8, W8), -3, 3)
+        w = gc.uni("rag/w", (128, 2, 7, 7), -0.2, 0.2)
+        b = gc.uni("rag/b", (128,), -0.1, 0.1)
+        want = torch.relu(torch.nn.functional.conv2d(x, w, b, padding=3))
+        out = torch.full((2 * H8 * W8, 130), 5.0, device=dev)
+        lib.conv2d_direct(kc.cl(x).to(dev), 0, 2, w.permute(2, 3, 1, 0).reshape(49, 2, 128).contiguous().to(dev),
+                          b.to(dev), out, 1, 128, 7, 7, True, 2, H8, W8)
+        kc.check(kc.uncl(out[:, 1:129].cpu(), 2, H8, W8), want, 2e-5, f"7x7 small conv W8={W8}")
+        assert float((out[:, 0] - 5.0).abs().max()) == 0.0 and float((out[:, 129] - 5.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 def test_stem_as_space_to_depth_conv(lib, dev, prec):
     """The 7x7 stride-2 stem (core/extractor.py:122) as space-to-depth + 4x4 stride-1 conv (even
