@@ -525,5 +525,5 @@ extern "C" int pf_warp_gcorr(const float* f1, const float* f2, const float* coor
 }
 
 extern "C" const char* pf_version(void) {
-    return "priorflow-hip r1 gfx950 (fp32 MFMA 32x32x2 implicit-GEMM convs, fused corr+pyramid)";
+    return "priorflow-hip r1 gfx950 (bf16x3 / exact-fp32 MFMA implicit-GEMM convs, fused corr+pyramid, HIP encoders)";
 }
