@@ -186,3 +186,25 @@ def test_forward_sizes_that_are_only_multiples_of_8(model, size):
     assert ma < EPE_BAR and mb < (5e-3 if (h, w) == (160, 360) else EPE_BAR), (size, ma, mb)
     tm = model(i1.cuda(), i2.cuda(), iters=3, test_mode=True)          # graph-captured path, same result
     assert float((tm - pa[-1]).abs().max()) < 1e-4
+
+
+def test_streams_and_graph_are_bitwise_reproducible(params):
+    """Race screen for the fork/join side streams inside the captured graph: every run must equal the
+    single-stream eager result bit for bit (profiles/repro_check.py runs the long version)."""
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+
+    def build(streams, graph):
+        m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+        m.load_state_dict(params, strict=True)
+        m = m.cuda().eval()
+        m.use_streams, m.use_graph = streams, graph
+        return m
+
+    i1, i2 = gc.synthetic_pair(1, 256, 512, seed=11)
+    i1, i2 = i1.cuda(), i2.cuda()
+    with torch.no_grad():
+        ref = build(False, False)(i1, i2, iters=5, test_mode=True).clone()
+        for graph in (True, False):
+            m = build(True, graph)
+            for _ in range(6):
+                assert torch.equal(m(i1, i2, iters=5, test_mode=True), ref), f"streams=True graph={graph}"
