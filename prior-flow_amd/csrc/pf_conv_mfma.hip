@@ -346,9 +346,27 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     constexpr int HW = TW + KW - 1, HH = TH + KH - 1;
     constexpr int A_V4 = (HH * HW + 63) / 64; // halo float4 per thread (64 rows per pass of 512 threads)
     constexpr int HALO_ROWS = 64 * A_V4;      // rows past HH*HW get zeros
+    // Weight tiles by LDS-DMA (global_load_lds_dwordx4; multi-tap kernels): no VGPR staging, no ds_write.
+    // The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the ring slots are UNPADDED 128-B rows
+    // with the 16-byte pieces XOR-swizzled by (row >> 1) & 7 on the source address and on the fragment read
+    // (conflict-free ds_read_b128); 4 slots: the tile of step s+3 is issued at step s and retired by a
+    // counted s_waitcnt vmcnt(N) in front of the raw barrier of step s+2 (a __syncthreads would add
+    // vmcnt(0) while a DMA is in flight); the halo loads are then inline-asm loads with counted waits too.
+    // OPT-IN (-DPF_DMA_B): validated by the full GPU suite, but measured a wash -- back-to-back launches of
+    // one conv: -3..-6 % (z|r 55.3 vs 57.4 us, heads 58.2 vs 62.1, q 33.5 vs 34.4) at TH = 4, +5 % at TH = 8;
+    // inside the forward (same-call traces): NT = 2 kernels -2..-3 %, NT = 1 kernels up to +6 %, end to end
+    // 107.7 vs 108.8 pairs/s.  The default stays the register-staged weight ring.
+#ifdef PF_DMA_B
+    constexpr bool DMA_B = TAPS > 1 && TH == 4;
+#else
+    constexpr bool DMA_B = false;
+#endif
+    constexpr int B_SLOTS = DMA_B ? 4 : 3;
+    constexpr int B_ROW = DMA_B ? 128 : LDS_LD * 4;     // bytes per weight row in LDS
+    constexpr int B_DMA = BN / 64;                      // 1-KiB DMA pieces per wave per K-step
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ah = smem;                                   // [2][HALO_ROWS][LDS_LD]
-    float* Bs = smem + 2 * HALO_ROWS * LDS_LD;          // [3][BN][LDS_LD]  (3-slot ring)
+    float* Bs = smem + 2 * HALO_ROWS * LDS_LD;          // [B_SLOTS][BN][B_ROW bytes]  (ring)
 
     pf_conv_desc d = groups.d[0];
     if (blockIdx.z == 1) d = groups.d[1];
@@ -393,6 +411,23 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};   // input affine of this thread's 4 channels
     const long aff_row = (long)(tile / (tiles_x * tiles_y)) * ctot;     // [image][channel]
     unsigned a_ok[NSET] = {};
+    // 16-byte global load.  With the weight DMA in flight hipcc cannot count past it and waits vmcnt(0) at
+    // the first use of ANY ordinary load result (draining the DMA queue once per chunk); in that mode the
+    // halo loads are issued by inline asm -- invisible to the compiler's wait tracking -- and retired by the
+    // counted waits of `wait_A` below.
+    auto load16 = [&](f32x4& dst, const float* ptr) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DMA_B) {
+            f32x4 t;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(ptr) : "memory");
+            dst = t;
+        } else {
+            dst = *reinterpret_cast<const f32x4*>(ptr);
+        }
+#else
+        dst = *reinterpret_cast<const f32x4*>(ptr);
+#endif
+    };
     // The halo loader/converter works in A_V4 independent slices (q) so that a K-step can spread
     // them between its MFMAs (see `step`).
     auto load_A_affine = [&](int chunk) __attribute__((always_inline)) {
@@ -400,8 +435,8 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
             if (chunk >= nchunks) chunk = nchunks - 1;
             const int c = chunk * KC + c4;
             const int ca = c < ctot ? c : 0;
-            a_sc = *reinterpret_cast<const f32x4*>(d.in_scale + aff_row + ca);
-            a_sh = *reinterpret_cast<const f32x4*>(d.in_shift + aff_row + ca);
+            load16(a_sc, d.in_scale + aff_row + ca);
+            load16(a_sh, d.in_shift + aff_row + ca);
         }
     };
     auto load_A_q = [&](int chunk, auto Q, auto SET) __attribute__((always_inline)) {
@@ -413,7 +448,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         else          { src = d.in1 + d.off1; ld = d.ld1; cc = c - d.c0; }
         const bool ok = c < ctot && a_pix[q] >= 0;
         const float* ptr = ok ? src + a_pix[q] * ld + cc : d.in0 + d.off0;
-        ra[set][q] = *reinterpret_cast<const f32x4*>(ptr);
+        load16(ra[set][q], ptr);
         a_ok[set] = (a_ok[set] & ~(1u << q)) | (ok ? (1u << q) : 0u);
     };
     auto store_A_q = [&](int buf, auto Q, auto SET) __attribute__((always_inline)) {
@@ -469,10 +504,33 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
             rb[q] = *reinterpret_cast<const f32x4*>(wp + b_goff[q]);
     };
     auto store_B = [&](int slot, const f32x4 (&rb)[B_V4]) __attribute__((always_inline)) {
-        char* bs = bs_bytes + slot * (BN * LDS_LD * 4);                           // wave-uniform
+        char* bs = bs_bytes + slot * (BN * B_ROW);                                 // wave-uniform
 #pragma unroll
         for (int q = 0; q < B_V4; ++q)
             *reinterpret_cast<f32x4*>(bs + b_loff[q]) = rb[q];
+    };
+
+    // DMA path: piece j of this wave covers rows (wave*B_DMA + j)*8 + (lane>>3), LDS position lane&7
+    unsigned dma_goff[B_DMA];
+#pragma unroll
+    for (int j = 0; j < B_DMA; ++j) {
+        const int r = (wave * B_DMA + j) * 8 + (lane >> 3);
+        dma_goff[j] = (unsigned)(((long)(n0 + r) * wrow) * 4 + (((lane & 7) ^ ((r >> 1) & 7)) * 16));
+    }
+    auto dma_B = [&](int step, int slot) __attribute__((always_inline)) {
+        if (step >= nsteps) step = nsteps - 1;           // tail: harmless re-read into a free slot
+        const int chunk = step / TAPS, tap = step - chunk * TAPS;
+        const char* wp = wbytes + ((long)tap * g.cin_pad + chunk * KC) * 4;      // wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)       // (the host pass parses kernel bodies too; these are device-only constructs)
+#pragma unroll
+        for (int j = 0; j < B_DMA; ++j) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            lds_void* dst = (lds_void*)(bs_bytes + slot * (BN * B_ROW) + (wave * B_DMA + j) * 1024);
+            __builtin_amdgcn_global_load_lds(wp + dma_goff[j], dst, 16, 0, 0);
+        }
+#else
+        (void)wp; (void)slot;
+#endif
     };
 
     f32x16 acc[NT];
@@ -482,7 +540,14 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const char* a_lane = reinterpret_cast<const char*>(Ah + (wy * HW + li) * LDS_LD) + 32 * lh;
-    const char* b_lane = reinterpret_cast<const char*>(Bs + (32 * NT * wn + li) * LDS_LD) + 32 * lh;
+    const char* b_lane = bs_bytes + (32 * NT * wn + li) * B_ROW + (DMA_B ? 0 : 32 * lh);
+    // byte offsets of this lane's four 16-byte pieces (hi k0-7, hi k8-15, lo k0-7, lo k8-15) inside its row
+    unsigned b_piece[4];
+    {
+        const unsigned swz = DMA_B ? (unsigned)((li >> 1) & 7) : 0u, p0 = DMA_B ? 2u * lh : 0u;
+        b_piece[0] = ((p0 + 0) ^ swz) * 16; b_piece[1] = ((p0 + 1) ^ swz) * 16;
+        b_piece[2] = ((p0 + 4) ^ swz) * 16; b_piece[3] = ((p0 + 5) ^ swz) * 16;
+    }
 
     // MFMA operand fragments, double buffered in registers: set (s&1) feeds step s while set
     // ((s+1)&1) is being filled from LDS for step s+1, so the LDS round trip hides behind MFMAs.
@@ -498,26 +563,35 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     };
     auto fetch_B = [&](auto SET, auto T, int slot) __attribute__((always_inline)) {
         constexpr int set = decltype(SET)::value, t = decltype(T)::value;
-        const char* bp = b_lane + (slot * BN + 32 * t) * (LDS_LD * 4);
-        fb[set][t][0] = *reinterpret_cast<const bf16x8*>(bp);
-        fb[set][t][1] = *reinterpret_cast<const bf16x8*>(bp + 16);
-        fb[set][t][2] = *reinterpret_cast<const bf16x8*>(bp + 64);
-        fb[set][t][3] = *reinterpret_cast<const bf16x8*>(bp + 80);
+        const char* bp = b_lane + (slot * BN + 32 * t) * B_ROW;
+        fb[set][t][0] = *reinterpret_cast<const bf16x8*>(bp + b_piece[0]);
+        fb[set][t][1] = *reinterpret_cast<const bf16x8*>(bp + b_piece[1]);
+        fb[set][t][2] = *reinterpret_cast<const bf16x8*>(bp + b_piece[2]);
+        fb[set][t][3] = *reinterpret_cast<const bf16x8*>(bp + b_piece[3]);
     };
 
     // ---- prologue: halo 0, weight steps 0 and 1 synchronously; steps 2, 3 in flight; frags(0) ------
     // (TAPS == 1: halo chunks 0 and 1 synchronously, chunks 2 and 3 in flight, like the weights)
+    // (DMA path: weight steps 0, 1, 2 by DMA, all retired here; steps 3, 4, ... issued from the K loop)
     load_A(0, SET0{});
     if constexpr (TAPS == 1) load_A(1, SET1{});
-    load_B(0, rb0);
-    load_B(1, rb1);
-    store_A(0, SET0{});
-    if constexpr (TAPS == 1) store_A(1, SET1{});
-    store_B(0, rb0);
-    store_B(1, rb1);
-    if constexpr (TAPS == 1) { load_A(2, SET0{}); load_A(3, SET1{}); }
-    load_B(2, rb0);
-    load_B(3, rb1);
+    if constexpr (DMA_B) {
+        dma_B(0, 0); dma_B(1, 1); dma_B(2, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_for<0, A_V4>([&](auto Q) { f32x4 t = ra[0][decltype(Q)::value]; asm volatile("" : "+v"(t)); ra[0][decltype(Q)::value] = t; });
+        if constexpr (AFFINE) { f32x4 t0 = a_sc, t1 = a_sh; asm volatile("" : "+v"(t0), "+v"(t1)); a_sc = t0; a_sh = t1; }
+        store_A(0, SET0{});
+    } else {
+        load_B(0, rb0);
+        load_B(1, rb1);
+        store_A(0, SET0{});
+        if constexpr (TAPS == 1) store_A(1, SET1{});
+        store_B(0, rb0);
+        store_B(1, rb1);
+        if constexpr (TAPS == 1) { load_A(2, SET0{}); load_A(3, SET1{}); }
+        load_B(2, rb0);
+        load_B(3, rb1);
+    }
     asm volatile("" ::: "memory");
     __syncthreads();
     fetch_A(std::integral_constant<int, 0>{}, 0, 0, 0);
@@ -552,11 +626,21 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         constexpr int ntap = (tap + 1) % TAPS;         // tap of step s+1
         constexpr int nky = ntap / KW, nkx = ntap % KW;
         const int nchunk = (tap == TAPS - 1) ? chunk + 1 : chunk;
-        const int s1 = slot3 == 2 ? 0 : slot3 + 1;     // (s+1) % 3
-        const int s2 = s1 == 2 ? 0 : s1 + 1;           // (s+2) % 3
+        const int s1 = slot3 == B_SLOTS - 1 ? 0 : slot3 + 1;   // (s+1) % B_SLOTS
+        const int s2 = s1 == B_SLOTS - 1 ? 0 : s1 + 1;         // (s+2) % B_SLOTS
+        const int s3 = s2 == B_SLOTS - 1 ? 0 : s2 + 1;         // (s+3) % B_SLOTS   (DMA path)
         using NXT = std::integral_constant<int, cur ^ 1>;
 #ifndef PF_ABLATE_NO_BARRIER
-        __syncthreads();      // slot (s+1)%3 and the halo of step s+1 are complete; slot (s+2)%3 is idle
+        if constexpr (DMA_B) {
+            // the weight DMA of step s+1 was issued at step s-2; VMEM operations issued after it, in order:
+            // the halo loads (+ affine rows) of step s-2 / s-1 when that was a chunk's first tap, and the DMA
+            // of step s+2.  Everything older must have landed before any wave reads slot (s+1).
+            constexpr int A_OPS = A_V4 + (AFFINE ? 2 : 0);
+            constexpr int YOUNGER = B_DMA + A_OPS * (((tap + TAPS - 1) % TAPS == 0 ? 1 : 0) + ((tap + TAPS - 2) % TAPS == 0 ? 1 : 0));
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "n"(YOUNGER) : "memory");
+        } else {
+            __syncthreads();  // slot (s+1)%3 and the halo of step s+1 are complete; slot (s+2)%3 is idle
+        }
 #endif
         constexpr int NM = 6 * NT;                     // MFMAs of the step; accumulators alternate
         auto halo_slice = [&](auto Q) __attribute__((always_inline)) {
@@ -575,7 +659,22 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
                 if constexpr (tap == 0) load_A_q(chunk + 1, Q, CUR{});
 #endif
 #ifndef PF_ABLATE_NO_LDS_WRITE
-                if constexpr (tap == TAPS - 2) store_A_q((chunk + 1) & 1, Q, CUR{});
+                if constexpr (tap == TAPS - 2) {
+                    if constexpr (DMA_B) {
+                        // slice q was loaded at the chunk's first tap; younger VMEM operations: the later slices'
+                        // loads and the weight DMAs of the TAPS-2 steps since (this step's included)
+                        constexpr int q = decltype(Q)::value;
+                        f32x4 t = ra[0][q];
+                        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(t) : "n"(A_V4 - 1 - q + B_DMA * (TAPS - 2)));
+                        ra[0][q] = t;
+                        if constexpr (AFFINE && q == 0) {
+                            f32x4 t0 = a_sc, t1 = a_sh;
+                            asm volatile("" : "+v"(t0), "+v"(t1));
+                            a_sc = t0; a_sh = t1;
+                        }
+                    }
+                    store_A_q((chunk + 1) & 1, Q, CUR{});
+                }
 #endif
             }
         };
@@ -598,7 +697,13 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
             if constexpr (i == 0) fetch_A(NXT{}, nchunk & 1, nky, nkx);
             if constexpr (i >= 1 && i <= NT) fetch_B(NXT{}, std::integral_constant<int, i - 1>{}, s1);
 #endif
-            if constexpr (i == NT + 1) {
+            if constexpr (i == NT + 1 && DMA_B) {
+                dma_B(s + 3, s3);
+#ifndef PF_ABLATE_NO_GLOBAL
+                if constexpr (tap == 0 && TAPS > 1) load_A_affine(chunk + 1);
+#endif
+            }
+            if constexpr (i == NT + 1 && !DMA_B) {
 #if defined(PF_ABLATE_NO_B_STORE)           // timing-only: bound on what an LDS-DMA weight path could save
                 if constexpr (cur == 0) asm volatile("" :: "v"(rb0[0]), "v"(rb0[B_V4 - 1]));
                 else asm volatile("" :: "v"(rb1[0]), "v"(rb1[B_V4 - 1]));
@@ -687,8 +792,14 @@ template <int NT, int KH, int KW, bool AFFINE, int TH>
 int launch_conv_halo_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
     constexpr int BN = 32 * NT * (TH == 4 ? 2 : 1);
     constexpr int HALO_ROWS = ((TH + KH - 1) * (32 + KW - 1) + 63) / 64 * 64;
-    const size_t lds = (size_t)(2 * HALO_ROWS + 3 * BN) * LDS_LD * sizeof(float);
-    static_assert((2 * HALO_ROWS + 3 * BN) * LDS_LD * sizeof(float) <= 160 * 1024, "LDS budget");
+#ifdef PF_DMA_B
+    constexpr bool DMA_B = KH * KW > 1 && TH == 4;
+#else
+    constexpr bool DMA_B = false;
+#endif
+    constexpr size_t lds = (size_t)2 * HALO_ROWS * LDS_LD * sizeof(float) +
+                           (DMA_B ? (size_t)4 * BN * 128 : (size_t)3 * BN * LDS_LD * sizeof(float));
+    static_assert(lds <= 160 * 1024, "LDS budget");
     const int B = g.M / g.N;
     dim3 grid((unsigned)(B * ((g.H + TH - 1) / TH) * ((g.W + 31) / 32)), (unsigned)((max_cout + BN - 1) / BN),
               (unsigned)ngroups);
