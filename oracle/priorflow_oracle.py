@@ -380,10 +380,9 @@ def grids_for(H: int, W: int) -> Dict[str, Tensor]:
     }
 
 
-@torch.no_grad()
-def forward(p: Mapping[str, Tensor], image1: Tensor, image2: Tensor, iters: int = 12,
-            init_flow: Optional[Tensor] = None, test_mode: bool = False,
-            trace: Optional[dict] = None):
+def forward_with_grad(p: Mapping[str, Tensor], image1: Tensor, image2: Tensor, iters: int = 12,
+                      init_flow: Optional[Tensor] = None, test_mode: bool = False,
+                      trace: Optional[dict] = None):
     """PriOr_RAFT.forward (core/prior_raft.py:107-215).  ``trace`` (if given) collects
     per-stage tensors for per-kernel parity tests."""
     image1 = 2 * (image1 / 255.0) - 1.0
@@ -414,6 +413,7 @@ def forward(p: Mapping[str, Tensor], image1: Tensor, image2: Tensor, iters: int 
 
     preds_a, preds_b = [], []
     for _ in range(iters):
+        c1a, c1b = c1a.detach(), c1b.detach()      # core/prior_raft.py:171,176 (no gradient through the coordinates)
         flow_a = c1a - c0
         flaw_a = warp_groupwise_corr(f1a, f2a, c1a)
         flow_b = c1b - c0
@@ -439,6 +439,14 @@ def forward(p: Mapping[str, Tensor], image1: Tensor, image2: Tensor, iters: int 
     if test_mode:
         return preds_a[-1]
     return preds_a, preds_b
+
+
+@torch.no_grad()
+def forward(p: Mapping[str, Tensor], image1: Tensor, image2: Tensor, iters: int = 12,
+            init_flow: Optional[Tensor] = None, test_mode: bool = False, trace: Optional[dict] = None):
+    """Inference form of `forward_with_grad` (no autograd graph).  `forward_with_grad` on parameters with
+    requires_grad reproduces the reference's training-step gradients (tests/golden/train_step.npz)."""
+    return forward_with_grad(p, image1, image2, iters, init_flow, test_mode, trace)
 
 
 def epe(a: Tensor, b: Tensor) -> Tensor:

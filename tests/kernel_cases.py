@@ -109,6 +109,24 @@ def case_flo_rotate(lib, dev):
     out = torch.empty_like(z)
     lib.flo_rotate(z, g["b2aT_16x32"], g["b2a_16x32"], out)
     assert float(out.abs().max()) == 0.0, "zero flow must rotate to exactly zero"
+    # known answer: flo_B2A(flo_A2B(f)) ~= f away from the poles of both views
+    import math
+    H, W = 64, 128
+    ga = torch.empty(2, H, W, device=dev)
+    gb = torch.empty(2, H, W, device=dev)
+    lib.sample_grid(ga, po.rotation_x(-math.pi / 2))
+    lib.sample_grid(gb, po.rotation_x(math.pi / 2))
+    ys = torch.arange(H).view(1, H, 1).float()
+    xs = torch.arange(W).view(1, 1, W).float()
+    f = torch.stack([1.5 * torch.sin(2 * math.pi * xs / W) * torch.ones(1, H, W) + 0.5,
+                     0.8 * torch.cos(2 * math.pi * ys / H) * torch.ones(1, H, W)], 1).contiguous()
+    fb, back = torch.empty(1, 2, H, W, device=dev), torch.empty(1, 2, H, W, device=dev)
+    lib.flo_rotate(f.to(dev), gb, ga, fb)
+    lib.flo_rotate(fb, ga, gb, back)
+    pole_a, pole_b = po.generate_polemask(H, W)
+    keep = ((pole_a == 0) & (pole_b == 0))[0]
+    e = po.epe(back.cpu(), f)[0][keep]
+    assert float(e.mean()) < 5e-3 and float(e.max()) < 3e-2, "flow rotation round trip"
 
 
 def _pyr_rows(pyr):

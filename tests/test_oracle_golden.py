@@ -315,3 +315,52 @@ def test_forward_odd_sizes(params):
         ea = po.epe(pa[-1], T(g[f"a_{h}x{w}"]))
         eb = po.epe(pb[-1][:, :, ::2, ::2], T(g[f"b_{h}x{w}"]))
         assert float(ea.mean()) < tol_a and float(eb.mean()) < tol_b, (h, w, float(ea.mean()), float(eb.mean()))
+
+
+def test_flow_rotation_round_trip():
+    """SURVEY.md 8c known answer: flo_B2A(flo_A2B(f)) ~= f away from the poles of both views (bilinear
+    resampling of a smooth flow: measured 2e-3 px mean / 1e-2 px max at 64x128)."""
+    H, W = 64, 128
+    ga, gb = po.sample_grid(H, W, po.rotation_x(-math.pi / 2)), po.sample_grid(H, W, po.rotation_x(math.pi / 2))
+    ys = torch.arange(H).view(1, H, 1).float()
+    xs = torch.arange(W).view(1, 1, W).float()
+    f = torch.stack([1.5 * torch.sin(2 * math.pi * xs / W) * torch.ones(1, H, W) + 0.5,
+                     0.8 * torch.cos(2 * math.pi * ys / H) * torch.ones(1, H, W)], 1)
+    back = po.flo_rotate(po.flo_rotate(f, gb, ga), ga, gb)
+    pole_a, pole_b = po.generate_polemask(H, W)
+    keep = ((pole_a == 0) & (pole_b == 0))[0]
+    e = po.epe(back, f)[0][keep]
+    assert float(e.mean()) < 5e-3 and float(e.max()) < 3e-2
+
+
+def test_train_step_gradients_vs_reference(params):
+    """One training step of the reference (forward in train mode with frozen BN, uniform_loss on both
+    branches, backward; B=2, 128x256, iters=3; oracle/gen_golden_train_step.py): autograd through the
+    oracle's forward reproduces the loss, the total gradient norm and the gradient slices -- the pin for
+    the backward kernels."""
+    from gen_golden_train_step import SLICES, step_inputs
+    g = gc.load("train_step")
+    p = {k: v.clone() for k, v in params.items()}
+    leaf = [k for k, v in p.items() if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
+    for k in leaf:
+        p[k].requires_grad_(True)
+    i1, i2, gt, valid = step_inputs()
+    with torch.no_grad():
+        gt_b = po.flo_rotate(gt, po.sample_grid(128, 256, po.rotation_x(math.pi / 2)), po.sample_grid(128, 256, po.rotation_x(-math.pi / 2)))
+        valid_b = ((gt_b[:, 0].abs() < 1000) & (gt_b[:, 1].abs() < 1000)).float()
+    uni = po.spherical_mask(128, 256)[None]
+
+    def loss_fn(preds, tgt, v, gamma=0.8):
+        ok = (v >= 0.5) & (torch.sum(tgt ** 2, dim=1).sqrt() < 400)
+        n = len(preds)
+        return sum(gamma ** (n - i - 1) * torch.sum(ok * uni * torch.sum((preds[i] - tgt).abs(), dim=1)) for i in range(n))
+
+    pa, pb = po.forward_with_grad(p, i1, i2, iters=3)
+    loss = loss_fn(pa, gt, valid) + loss_fn(pb, gt_b, valid_b)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    total = math.sqrt(sum(float((p[k].grad.double() ** 2).sum()) for k in leaf if p[k].grad is not None))
+    assert abs(total - float(g["grad_norm"])) < 1e-5 * float(g["grad_norm"])
+    for k, sl in SLICES.items():
+        want = T(g["g:" + k])
+        close(p[k].grad[sl], want, 2e-3 * float(want.abs().max()) + 1e-9, what="grad " + k)
