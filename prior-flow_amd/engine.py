@@ -144,6 +144,8 @@ class Conv:
         d.in_shift = in_shift.data_ptr() if in_shift is not None else None
         d.in_relu = int(in_relu)
         d.stats_out = stats.data_ptr() if stats is not None else None
+        # the C struct holds raw pointers only: keep every tensor alive for as long as the descriptor is
+        d._keep = (in0, in1, out, h, z, aux, in_scale, in_shift, stats, self.w, self.b)
         return d
 
 
