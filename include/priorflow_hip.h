@@ -237,6 +237,18 @@ int pf_sum_squares(const float* x, long n, double* partials, int nblk, void* str
 int pf_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, float beta1, float beta2,
                   float eps, double weight_decay, int step, float grad_scale, void* stream);
 
+/* Weight and bias gradient of a stride-1 convolution (what autograd computes for every nn.Conv2d of
+ * core/update.py / core/extractor.py in `loss.backward()`, train_flow.py:135):
+ *   dw[o][tap][c] += sum_p dy[p][o] * x[p + off(tap)][c],  db[o] += sum_p dy[p][o]
+ * x: channel-last, two-segment virtual concat like pf_conv_desc (in0 | in1); dy: channel-last gradient of the
+ * conv's pre-activation output; dw: fp32 in the packed weight layout [Cout_pad128][KH*KW][Cin_pad32], db
+ * [Cout_pad128] or NULL -- both ACCUMULATED into (zero them first).  3x3, 1x5, 5x1, 1x1; 3-pass bf16 split.
+ * The data gradient needs no entry of its own: dx = pf_conv2d(dy, W') with
+ * W'[c][o][ky][kx] = W[o][c][KH-1-ky][KW-1-kx]. */
+int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const float* x1, int ld1, int off1, int c1,
+                    const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
+                    int kh, int kw, int B, int H8, int W8, void* stream);
+
 /* channel-last slice -> NCHW. */
 int pf_to_nchw(const float* in, int ld_in, int off_in, int c, float* out, int B, int N,
                void* stream);

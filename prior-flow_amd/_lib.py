@@ -65,6 +65,7 @@ _SIGNATURES = {
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
     "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
+    "pf_conv2d_wgrad": [_fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_seq_loss": [_fp, _fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, _i, _i, _i, _fp],
     "pf_sum_squares": [_fp, C.c_long, _fp, _i, _fp],
     "pf_adamw_step": [_fp, _fp, _fp, _fp, C.c_long, C.c_double, C.c_float, C.c_float, C.c_float, C.c_double, _i,
@@ -301,6 +302,16 @@ class PfLib:
         return out
 
     # ---- training-step pieces ---------------------------------------------------------------
+    def conv2d_wgrad(self, x0, off0, c0, dy, off_dy, cout, dw, db, kh, kw, B, H8, W8, x1=None, off1=0, c1=0):
+        """dw [Cout_pad128, kh*kw, Cin_pad32] and db [Cout_pad128] (or None) are accumulated into."""
+        self._chk(x0, x1, dy, dw, db)
+        cin_pad = (c0 + c1 + 31) // 32 * 32
+        if dw.shape[-1] != cin_pad or dw.shape[-2] != kh * kw or dw.shape[0] < cout:
+            raise PfError(f"conv2d_wgrad: dw must be [>= {cout}, {kh * kw}, {cin_pad}], got {tuple(dw.shape)}")
+        self._rc(self._dll.pf_conv2d_wgrad(_ptr(x0), x0.shape[-1], off0, c0, _ptr(x1), 0 if x1 is None else x1.shape[-1],
+                                           off1, c1, _ptr(dy), dy.shape[-1], off_dy, cout, _ptr(dw), _ptr(db),
+                                           kh, kw, B, H8, W8, self._stream(x0)), "pf_conv2d_wgrad")
+
     def seq_loss(self, pred, gt, valid, weight, i_weight, max_flow, grad, partials):
         """pred, gt [B,2,H,W]; valid [B,H,W]; weight [H*W]; grad [B,2,H,W] or None; partials float64 [B,nblk,6]."""
         self._chk(pred, gt, valid, weight, grad)

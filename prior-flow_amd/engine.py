@@ -114,6 +114,19 @@ class Conv:
                     mod.weight.shape[0], precision)
 
     @staticmethod
+    def dgrad_of(weight: torch.Tensor, precision=PREC_F32) -> "Conv":
+        """The convolution that maps dY to dX for a stride-1 conv with `weight` [Cout,Cin,KH,KW] (odd kernel):
+        dX = conv(dY, W'), W'[c][o][ky][kx] = W[o][c][KH-1-ky][KW-1-kx], no bias -- runs on pf_conv2d."""
+        wt = weight.detach().float().flip(2, 3).transpose(0, 1).contiguous()
+        wp, bp = pack_mfma(wt, torch.zeros(wt.shape[0], device=wt.device))
+        return Conv(wp, bp, wt.shape[2], wt.shape[3], wt.shape[1], wt.shape[0], precision)
+
+    @staticmethod
+    def unpack_wgrad(dw: torch.Tensor, cout: int, cin: int, kh: int, kw: int) -> torch.Tensor:
+        """Packed weight gradient [Cout_pad128][KH*KW][Cin_pad32] -> [Cout,Cin,KH,KW]."""
+        return dw[:cout, :, :cin].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
     def fused(mod_z, mod_r, precision=PREC_F32) -> "Conv":
         """convz|convr share their input (core/update.py:48-49): one 384->256 GEMM."""
         w = torch.cat([mod_z.weight, mod_r.weight], 0)
