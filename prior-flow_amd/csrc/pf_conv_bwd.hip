@@ -15,11 +15,13 @@
 // transposed reads (addressing validated on hardware by profiles/scratch/tr_read_check.hip).  64-byte rows
 // make every transposed read conflict-free: a 32-lane half covers 4 consecutive rows = 256 contiguous bytes.
 //
-// Work decomposition: workgroup = (64 output channels) x (one 32-input-channel chunk) x (a share of the
-// 4 x 32 pixel tiles, split-K); per tile it stages the dY tile and the X HALO once (like the forward halo
-// kernel: the taps read shifted rows of the same LDS image) and accumulates every tap; 4 waves =
-// 2 (32-channel halves of the 64 outputs) x 2 (tap parity), up to 5 taps x one 32x32 accumulator per wave.
-// Partial sums of the splits are added to dW with fp32 atomics (dW must be zeroed by the caller).
+// Work decomposition: workgroup (8 waves) = 128 output channels x 64 input channels x a share of the
+// 4 x 32 pixel tiles (split-K); per tile it stages the dY tile and the X HALO once (like the forward halo
+// kernel: the taps read shifted rows of the same LDS image); wave (mb, cb) owns one 32 x 32 (output, input)
+// channel block and accumulates EVERY tap (<= 9 accumulators).  Partial sums of the splits are added to dW
+// with fp32 atomics (dW must be zeroed by the caller).  The kernel is bound by re-staging: every pixel
+// tile is read by (Cout/128) x (Cin/64) workgroups; the first version's 64 x 32 tiles doubled that traffic
+// (~700 MB of L2 reads per GRU-gate launch, 14-68 TFLOP/s).
 #include <type_traits>
 #include "pf_common.h"
 #include "../../include/priorflow_hip.h"
@@ -33,7 +35,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 4, TW = 32, TPX = TH * TW;     // pixel tile
-constexpr int MAX_TAPS_PER_WAVE = 5;
+constexpr int WG_O = 128, WG_C = 64;              // output / input channels per workgroup
 
 struct WgradArgs {
     const float* x0; int ld0, off0, c0;
@@ -64,128 +66,173 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int lane
 }
 
 template <int KH, int KW>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(512, 2)
 pf_wgrad_kernel(const WgradArgs a) {
     constexpr int TAPS = KH * KW, HH = TH + KH - 1, HW = TW + KW - 1, HPX = HH * HW;
     constexpr int ph = KH / 2, pw = KW / 2;
-    static_assert(TAPS <= 2 * MAX_TAPS_PER_WAVE, "tap parity groups of at most 5 taps");
-    // LDS: dY tile [2 planes][2 halves of 32 channels][128 px][32]  and X halo [2 planes][HPX + pad][32], bf16
+    static_assert(TAPS <= 9, "one 32x32 accumulator per tap and wave");
+    // LDS (bf16): dY tile [2 planes][4 blocks of 32 out-channels][128 px][32], X halo [2 planes][2 blocks][XROWS][32]
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-    __bf16* const dyt = lds;                                   // index ((plane*2 + mb)*TPX + px)*32 + c
-    constexpr int XROWS = (HPX + 15) / 16 * 16 + 16;           // transposed reads touch up to 15 rows past a fragment's 8
-    __bf16* const xt = lds + 2 * 2 * TPX * 32;                 // index (plane*XROWS + hp)*32 + c
+    constexpr int XROWS = (HPX + 15) / 16 * 16;
+    __bf16* const dyt = lds;                                   // ((plane*4 + mb)*TPX + px)*32 + c
+    __bf16* const xt = lds + 2 * 4 * TPX * 32;                 // ((plane*2 + cb)*XROWS + hp)*32 + c
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mb = wave & 1, tpar = wave >> 1;                 // 32-channel half of the 64 outputs, tap parity
-    const int o0 = blockIdx.x * 64, cchunk = blockIdx.y, split = blockIdx.z;
+    const int mb = wave & 3, cb = wave >> 2;                   // this wave's 32 x 32 (output, input) channel block
+    const int o0 = blockIdx.x * WG_O, c00 = blockIdx.y * WG_C, split = blockIdx.z;
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int tiles_img = tiles_x * tiles_y, ntiles = a.B * tiles_img;
     const long N = (long)a.H * a.W;
     const int ctot = a.c0 + a.c1;
 
-    f32x16 acc[MAX_TAPS_PER_WAVE];
+    f32x16 acc[TAPS];
 #pragma unroll
-    for (int t = 0; t < MAX_TAPS_PER_WAVE; ++t)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int tile = split; tile < ntiles; tile += a.nsplit) {
+    // Software pipeline over this split's tiles: the operands of tile i+1 are fetched into registers while
+    // tile i is multiplied out of LDS (the first version loaded, waited, converted and computed serially and
+    // was latency bound: ~180 us even for a 1x1 conv).
+    constexpr int NX = (XROWS * 16 + 511) / 512;               // X-halo float4 per thread
+    f32x4 ry[8], rx[NX];
+    auto load_y = [&](int tile) __attribute__((always_inline)) {
         const int img = tile / tiles_img, tin = tile % tiles_img;
         const int y0 = (tin / tiles_x) * TH, x0 = (tin % tiles_x) * TW;
-        __syncthreads();                                       // previous tile's fragment reads are done
-        // ---- stage dY: 128 px x 64 channels, 8 float4 per thread ---------------------------------------
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                          // dY: 128 px x 128 channels
+            const int e = tid + 512 * q;                       // float4 index: px = e / 32, channel group = e % 32
+            const int px = e >> 5, cg = (e & 31) * 4;
+            const int yy = y0 + (px >> 5), xx = x0 + (px & 31), o = o0 + cg;
+            ry[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (tile < ntiles && yy < a.H && xx < a.W && o < a.cout)      // cout % 4 == 0 is checked by the launcher
+                ry[q] = *reinterpret_cast<const f32x4*>(a.dy + ((long)img * N + (long)yy * a.W + xx) * a.ld_dy + a.off_dy + o);
+        }
+    };
+    auto load_x = [&](int tile) __attribute__((always_inline)) {
+        const int img = tile / tiles_img, tin = tile % tiles_img;
+        const int y0 = (tin / tiles_x) * TH, x0 = (tin % tiles_x) * TW;
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {                         // X halo: XROWS px x 64 channels
+            const int e = tid + 512 * q;
+            const int hp = e >> 4, cg = (e & 15) * 4;
+            const int yy = y0 + hp / HW - ph, xx = x0 + hp % HW - pw, c = c00 + cg;
+            rx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (tile < ntiles && hp < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c < ctot) {
+                const long p = (long)img * N + (long)yy * a.W + xx;
+                rx[q] = c < a.c0 ? *reinterpret_cast<const f32x4*>(a.x0 + p * a.ld0 + a.off0 + c)
+                                 : *reinterpret_cast<const f32x4*>(a.x1 + p * a.ld1 + a.off1 + (c - a.c0));
+            }
+        }
+    };
+    auto store_y = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int e = tid + 256 * q;                       // float4 index: px = e / 16, channel group = e % 16
-            const int px = e >> 4, cg = (e & 15) * 4;
-            const int yy = y0 + (px >> 5), xx = x0 + (px & 31), o = o0 + cg;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (yy < a.H && xx < a.W && o < a.cout)            // cout % 4 == 0 is checked by the launcher
-                v = *reinterpret_cast<const f32x4*>(a.dy + ((long)img * N + (long)yy * a.W + xx) * a.ld_dy + a.off_dy + o);
-            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-            const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
-            const int half = cg >> 5, c = cg & 31;
-            *reinterpret_cast<bf16x4*>(dyt + ((0 * 2 + half) * TPX + px) * 32 + c) = hi;
-            *reinterpret_cast<bf16x4*>(dyt + ((1 * 2 + half) * TPX + px) * 32 + c) = lo;
+            const int e = tid + 512 * q, px = e >> 5, cg = (e & 31) * 4;
+            const bf16x4 hi = __builtin_convertvector(ry[q], bf16x4);
+            const bf16x4 lo = __builtin_convertvector(ry[q] - __builtin_convertvector(hi, f32x4), bf16x4);
+            const int blk = cg >> 5, c = cg & 31;
+            *reinterpret_cast<bf16x4*>(dyt + ((0 * 4 + blk) * TPX + px) * 32 + c) = hi;
+            *reinterpret_cast<bf16x4*>(dyt + ((1 * 4 + blk) * TPX + px) * 32 + c) = lo;
         }
-        // ---- stage the X halo: HPX px x 32 channels ------------------------------------------------------
-        for (int e = tid; e < XROWS * 8; e += 256) {
-            const int hp = e >> 3, cg = (e & 7) * 4;
-            const int yy = y0 + hp / HW - ph, xx = x0 + hp % HW - pw, c = cchunk * 32 + cg;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (hp < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c < ctot) {
-                const long p = (long)img * N + (long)yy * a.W + xx;
-                v = c < a.c0 ? *reinterpret_cast<const f32x4*>(a.x0 + p * a.ld0 + a.off0 + c)
-                             : *reinterpret_cast<const f32x4*>(a.x1 + p * a.ld1 + a.off1 + (c - a.c0));
+    };
+    auto store_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int e = tid + 512 * q, hp = e >> 4, cg = (e & 15) * 4;
+            if (hp < XROWS) {
+                const bf16x4 hi = __builtin_convertvector(rx[q], bf16x4);
+                const bf16x4 lo = __builtin_convertvector(rx[q] - __builtin_convertvector(hi, f32x4), bf16x4);
+                const int blk = cg >> 5, cc = cg & 31;
+                *reinterpret_cast<bf16x4*>(xt + ((0 * 2 + blk) * XROWS + hp) * 32 + cc) = hi;
+                *reinterpret_cast<bf16x4*>(xt + ((1 * 2 + blk) * XROWS + hp) * 32 + cc) = lo;
             }
-            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-            const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
-            *reinterpret_cast<bf16x4*>(xt + (0 * XROWS + hp) * 32 + cg) = hi;
-            *reinterpret_cast<bf16x4*>(xt + (1 * XROWS + hp) * 32 + cg) = lo;
+        }
+    };
+
+    constexpr bool PREFETCH = TAPS <= 5;                       // 9 accumulators (3x3) + 60 staging registers spill
+    if constexpr (PREFETCH) { load_y(split); load_x(split); }
+    for (int tile = split; tile < ntiles; tile += a.nsplit) {
+        __syncthreads();                                       // previous tile's fragment reads are done
+        if constexpr (PREFETCH) {
+            store_y(); store_x();
+        } else {                                               // one operand after the other: they share registers
+            load_y(tile); store_y();
+            asm volatile("" ::: "memory");
+            load_x(tile); store_x();
         }
         __syncthreads();
-        // ---- 8 K-steps of 16 pixels (tile row y, half row xh); every tap of this wave's parity ----------
-#pragma unroll 2
+        if constexpr (PREFETCH) {
+            load_y(tile + a.nsplit); load_x(tile + a.nsplit);  // zeros past the end
+            asm volatile("" ::: "memory");                     // keep the loads above the MFMA block
+        }
+        // ---- 8 K-steps of 16 pixels (tile row y, half row xh); every tap -------------------------------
         for (int ks = 0; ks < 8; ++ks) {
             const int y = ks >> 1, xh = (ks & 1) * 16;
-            const bf16x8 a_hi = tr_frag(dyt + (0 * 2 + mb) * TPX * 32, y * 32 + xh, lane);
-            const bf16x8 a_lo = tr_frag(dyt + (1 * 2 + mb) * TPX * 32, y * 32 + xh, lane);
+            const bf16x8 a_hi = tr_frag(dyt + (0 * 4 + mb) * TPX * 32, y * 32 + xh, lane);
+            const bf16x8 a_lo = tr_frag(dyt + (1 * 4 + mb) * TPX * 32, y * 32 + xh, lane);
 #pragma unroll
-            for (int t = 0; t < MAX_TAPS_PER_WAVE; ++t) {
-                const int tap = 2 * t + tpar;                  // compile-time bound below keeps acc[] in registers
-                if (tap < TAPS) {
-                    const int ky = tap / KW, kx = tap % KW;
-                    const int hrow = (y + ky) * HW + xh + kx;  // halo pixel of this K-step's first pixel under the tap
-                    const bf16x8 b_hi = tr_frag(xt + 0 * XROWS * 32, hrow, lane);
-                    const bf16x8 b_lo = tr_frag(xt + 1 * XROWS * 32, hrow, lane);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < TAPS; ++t) {
+                const int ky = t / KW, kx = t % KW;
+                const int hrow = (y + ky) * HW + xh + kx;      // halo pixel of this K-step's first pixel under the tap
+                const bf16x8 b_hi = tr_frag(xt + (0 * 2 + cb) * XROWS * 32, hrow, lane);
+                const bf16x8 b_lo = tr_frag(xt + (1 * 2 + cb) * XROWS * 32, hrow, lane);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
             }
         }
     }
     // ---- epilogue: D[row = output channel][col = input channel]; lane = column ---------------------------
     const int li = lane & 31, lh = lane >> 5;
-    const int c = cchunk * 32 + li;
+    const int c = c00 + 32 * cb + li;
 #pragma unroll
-    for (int t = 0; t < MAX_TAPS_PER_WAVE; ++t) {
-        const int tap = 2 * t + tpar;
-        if (tap < TAPS) {
+    for (int t = 0; t < TAPS; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = o0 + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (o < a.cout && c < ctot)
-                    atomicAdd(a.dw + ((long)o * TAPS + tap) * a.cin_pad + c, acc[t][r]);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (o < a.cout && c < ctot)
+                atomicAdd(a.dw + ((long)o * TAPS + t) * a.cin_pad + c, acc[t][r]);
         }
     }
 }
 
 template <int KH, int KW>
 int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
-    constexpr int HPX = (TH + KH - 1) * (TW + KW - 1), XROWS = (HPX + 15) / 16 * 16 + 16;
-    constexpr size_t lds = (size_t)(2 * 2 * TPX * 32 + 2 * XROWS * 32) * 2;
-    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    constexpr int HPX = (TH + KH - 1) * (TW + KW - 1), XROWS = (HPX + 15) / 16 * 16;
+    constexpr size_t lds = (size_t)(2 * 4 * TPX * 32 + 2 * 2 * XROWS * 32) * 2;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_wgrad_kernel<KH, KW>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return (int)attr;
-    dim3 grid((unsigned)((a.cout + 63) / 64), (unsigned)(a.cin_pad / 32), (unsigned)a.nsplit);
-    hipLaunchKernelGGL((pf_wgrad_kernel<KH, KW>), grid, dim3(256), lds, stream, a);
+    dim3 grid((unsigned)((a.cout + WG_O - 1) / WG_O), (unsigned)((a.cin_pad + WG_C - 1) / WG_C), (unsigned)a.nsplit);
+    hipLaunchKernelGGL((pf_wgrad_kernel<KH, KW>), grid, dim3(512), lds, stream, a);
     return (int)hipGetLastError();
 }
 
-// db[o] = sum over pixels of dY[p][o]; block = 64 channels x 4 pixel lanes, grid.y pixel chunks, fp32 atomics
+// db[o] += sum over pixels of dY[p][o]: block = 64 channels x 4 row lanes over a 256-row chunk (8 independent
+// loads in flight per thread), fp32 atomics across chunks.  (A first version with 2048-row chunks and one
+// dependent load per iteration took ~150 us -- longer than the weight gradient itself.)
 __global__ void __launch_bounds__(256) pf_col_sum_kernel(const float* __restrict__ dy, int ld, int off, int cout,
                                                         long rows, float* __restrict__ db) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    const long chunk = (rows + gridDim.y - 1) / gridDim.y;
-    const long lo = blockIdx.y * chunk, hi = lo + chunk < rows ? lo + chunk : rows;
+    const long lo = (long)blockIdx.y * 256 + part * 64;
     float s = 0.f;
-    if (c < cout)
-        for (long p = lo + part; p < hi; p += 4) s += dy[p * ld + off + c];
+    if (c < cout) {
+#pragma unroll
+        for (int j0 = 0; j0 < 64; j0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long p = lo + j0 + j;
+                v[j] = p < rows ? dy[p * ld + off + c] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+    }
     red[part][threadIdx.x & 63] = s;
     __syncthreads();
     if (part == 0 && c < cout)
@@ -210,8 +257,8 @@ extern "C" int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const
     a.cin_pad = (c0 + c1 + 31) / 32 * 32;
     // split-K: enough workgroups for ~4 per CU, at most one per pixel tile
     const long ntiles = (long)B * ((H8 + TH - 1) / TH) * ((W8 + TW - 1) / TW);
-    const long wg_base = (long)((cout + 63) / 64) * (a.cin_pad / 32);
-    long ns = (1024 + wg_base - 1) / wg_base;
+    const long wg_base = (long)((cout + WG_O - 1) / WG_O) * ((a.cin_pad + WG_C - 1) / WG_C);
+    long ns = (512 + wg_base - 1) / wg_base;          // one 123-135 KB workgroup per CU: about two rounds
     if (ns > ntiles) ns = ntiles;
     if (ns < 1) ns = 1;
     a.nsplit = (int)ns;
@@ -225,8 +272,8 @@ extern "C" int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const
     if (rc) return rc;
     if (db) {
         const long rows = (long)B * H8 * W8;
-        int chunks = (int)((rows + 2047) / 2048);
-        if (chunks > 256) chunks = 256;
+        const long chunks = (rows + 255) / 256;
+        if (chunks > 65535) return PF_ERR_BAD_SHAPE;
         hipLaunchKernelGGL(pf_col_sum_kernel, dim3((unsigned)((cout + 63) / 64), (unsigned)chunks), dim3(256), 0, s,
                            dy, ld_dy, off_dy, cout, rows, db);
         rc = (int)hipGetLastError();
