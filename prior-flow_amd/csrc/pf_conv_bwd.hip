@@ -70,32 +70,38 @@ __global__ void __launch_bounds__(512, 2)
 pf_wgrad_kernel(const WgradArgs a) {
     constexpr int TAPS = KH * KW, HH = TH + KH - 1, HW = TW + KW - 1, HPX = HH * HW;
     constexpr int ph = KH / 2, pw = KW / 2;
-    static_assert(TAPS <= 9, "one 32x32 accumulator per tap and wave");
+    static_assert(TAPS <= 10, "at most 5 accumulators per wave");
+    // TAPS <= 5: the two wave groups take the two 32-channel input blocks (workgroup = 128 x 64 channels);
+    // 6..10 taps: they take the even / odd taps of ONE input block (128 x 32 channels, <= 5 accumulators).
+    constexpr bool SPLIT_T = TAPS > 5;
+    constexpr int NCB = SPLIT_T ? 1 : 2, NACC = SPLIT_T ? (TAPS + 1) / 2 : TAPS;
     // LDS (bf16): dY tile [2 planes][4 blocks of 32 out-channels][128 px][32], X halo [2 planes][2 blocks][XROWS][32]
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     constexpr int XROWS = (HPX + 15) / 16 * 16;
     __bf16* const dyt = lds;                                   // ((plane*4 + mb)*TPX + px)*32 + c
-    __bf16* const xt = lds + 2 * 4 * TPX * 32;                 // ((plane*2 + cb)*XROWS + hp)*32 + c
+    __bf16* const xt = lds + 2 * 4 * TPX * 32;                 // ((plane*NCB + cb)*XROWS + hp)*32 + c
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mb = wave & 3, cb = wave >> 2;                   // this wave's 32 x 32 (output, input) channel block
-    const int o0 = blockIdx.x * WG_O, c00 = blockIdx.y * WG_C, split = blockIdx.z;
+    const int mb = wave & 3;                                   // this wave's 32 output channels
+    const int cb = SPLIT_T ? 0 : wave >> 2, tpar = SPLIT_T ? wave >> 2 : 0;       // input block / tap parity
+    const int o0 = blockIdx.x * WG_O, c00 = blockIdx.y * (32 * NCB), split = blockIdx.z;
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int tiles_img = tiles_x * tiles_y, ntiles = a.B * tiles_img;
     const long N = (long)a.H * a.W;
     const int ctot = a.c0 + a.c1;
 
-    f32x16 acc[TAPS];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // Software pipeline over this split's tiles: the operands of tile i+1 are fetched into registers while
     // tile i is multiplied out of LDS (the first version loaded, waited, converted and computed serially and
     // was latency bound: ~180 us even for a 1x1 conv).
-    constexpr int NX = (XROWS * 16 + 511) / 512;               // X-halo float4 per thread
+    constexpr int XV = 8 * NCB;                                // float4 per halo pixel
+    constexpr int NX = (XROWS * XV + 511) / 512;               // X-halo float4 per thread
     f32x4 ry[8], rx[NX];
     auto load_y = [&](int tile) __attribute__((always_inline)) {
         const int img = tile / tiles_img, tin = tile % tiles_img;
@@ -114,9 +120,9 @@ pf_wgrad_kernel(const WgradArgs a) {
         const int img = tile / tiles_img, tin = tile % tiles_img;
         const int y0 = (tin / tiles_x) * TH, x0 = (tin % tiles_x) * TW;
 #pragma unroll
-        for (int q = 0; q < NX; ++q) {                         // X halo: XROWS px x 64 channels
+        for (int q = 0; q < NX; ++q) {                         // X halo: XROWS px x 32*NCB channels
             const int e = tid + 512 * q;
-            const int hp = e >> 4, cg = (e & 15) * 4;
+            const int hp = e / XV, cg = (e % XV) * 4;
             const int yy = y0 + hp / HW - ph, xx = x0 + hp % HW - pw, c = c00 + cg;
             rx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (tile < ntiles && hp < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c < ctot) {
@@ -140,18 +146,18 @@ pf_wgrad_kernel(const WgradArgs a) {
     auto store_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
-            const int e = tid + 512 * q, hp = e >> 4, cg = (e & 15) * 4;
+            const int e = tid + 512 * q, hp = e / XV, cg = (e % XV) * 4;
             if (hp < XROWS) {
                 const bf16x4 hi = __builtin_convertvector(rx[q], bf16x4);
                 const bf16x4 lo = __builtin_convertvector(rx[q] - __builtin_convertvector(hi, f32x4), bf16x4);
                 const int blk = cg >> 5, cc = cg & 31;
-                *reinterpret_cast<bf16x4*>(xt + ((0 * 2 + blk) * XROWS + hp) * 32 + cc) = hi;
-                *reinterpret_cast<bf16x4*>(xt + ((1 * 2 + blk) * XROWS + hp) * 32 + cc) = lo;
+                *reinterpret_cast<bf16x4*>(xt + ((0 * NCB + blk) * XROWS + hp) * 32 + cc) = hi;
+                *reinterpret_cast<bf16x4*>(xt + ((1 * NCB + blk) * XROWS + hp) * 32 + cc) = lo;
             }
         }
     };
 
-    constexpr bool PREFETCH = TAPS <= 5;                       // 9 accumulators (3x3) + 60 staging registers spill
+    constexpr bool PREFETCH = true;
     if constexpr (PREFETCH) { load_y(split); load_x(split); }
     for (int tile = split; tile < ntiles; tile += a.nsplit) {
         __syncthreads();                                       // previous tile's fragment reads are done
@@ -173,14 +179,17 @@ pf_wgrad_kernel(const WgradArgs a) {
             const bf16x8 a_hi = tr_frag(dyt + (0 * 4 + mb) * TPX * 32, y * 32 + xh, lane);
             const bf16x8 a_lo = tr_frag(dyt + (1 * 4 + mb) * TPX * 32, y * 32 + xh, lane);
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int ky = t / KW, kx = t % KW;
-                const int hrow = (y + ky) * HW + xh + kx;      // halo pixel of this K-step's first pixel under the tap
-                const bf16x8 b_hi = tr_frag(xt + (0 * 2 + cb) * XROWS * 32, hrow, lane);
-                const bf16x8 b_lo = tr_frag(xt + (1 * 2 + cb) * XROWS * 32, hrow, lane);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
+            for (int t = 0; t < NACC; ++t) {
+                const int tap = SPLIT_T ? 2 * t + tpar : t;    // wave-uniform
+                if (tap < TAPS) {
+                    const int ky = tap / KW, kx = tap % KW;
+                    const int hrow = (y + ky) * HW + xh + kx;  // halo pixel of this K-step's first pixel under the tap
+                    const bf16x8 b_hi = tr_frag(xt + (0 * NCB + cb) * XROWS * 32, hrow, lane);
+                    const bf16x8 b_lo = tr_frag(xt + (1 * NCB + cb) * XROWS * 32, hrow, lane);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -188,12 +197,15 @@ pf_wgrad_kernel(const WgradArgs a) {
     const int li = lane & 31, lh = lane >> 5;
     const int c = c00 + 32 * cb + li;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
+    for (int t = 0; t < NACC; ++t) {
+        const int tap = SPLIT_T ? 2 * t + tpar : t;
+        if (tap < TAPS) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = o0 + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (o < a.cout && c < ctot)
-                atomicAdd(a.dw + ((long)o * TAPS + t) * a.cin_pad + c, acc[t][r]);
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o < a.cout && c < ctot)
+                    atomicAdd(a.dw + ((long)o * TAPS + tap) * a.cin_pad + c, acc[t][r]);
+            }
         }
     }
 }
@@ -201,12 +213,13 @@ pf_wgrad_kernel(const WgradArgs a) {
 template <int KH, int KW>
 int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     constexpr int HPX = (TH + KH - 1) * (TW + KW - 1), XROWS = (HPX + 15) / 16 * 16;
-    constexpr size_t lds = (size_t)(2 * 4 * TPX * 32 + 2 * 2 * XROWS * 32) * 2;
+    constexpr int NCB = KH * KW > 5 ? 1 : 2;
+    constexpr size_t lds = (size_t)(2 * 4 * TPX * 32 + 2 * NCB * XROWS * 32) * 2;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_wgrad_kernel<KH, KW>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return (int)attr;
-    dim3 grid((unsigned)((a.cout + WG_O - 1) / WG_O), (unsigned)((a.cin_pad + WG_C - 1) / WG_C), (unsigned)a.nsplit);
+    dim3 grid((unsigned)((a.cout + WG_O - 1) / WG_O), (unsigned)((a.cin_pad + 32 * NCB - 1) / (32 * NCB)), (unsigned)a.nsplit);
     hipLaunchKernelGGL((pf_wgrad_kernel<KH, KW>), grid, dim3(512), lds, stream, a);
     return (int)hipGetLastError();
 }
@@ -257,7 +270,8 @@ extern "C" int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const
     a.cin_pad = (c0 + c1 + 31) / 32 * 32;
     // split-K: enough workgroups for ~4 per CU, at most one per pixel tile
     const long ntiles = (long)B * ((H8 + TH - 1) / TH) * ((W8 + TW - 1) / TW);
-    const long wg_base = (long)((cout + WG_O - 1) / WG_O) * ((a.cin_pad + WG_C - 1) / WG_C);
+    const int wg_c = kh * kw > 5 ? 32 : WG_C;
+    const long wg_base = (long)((cout + WG_O - 1) / WG_O) * ((a.cin_pad + wg_c - 1) / wg_c);
     long ns = (512 + wg_base - 1) / wg_base;          // one 123-135 KB workgroup per CU: about two rounds
     if (ns > ntiles) ns = ntiles;
     if (ns < 1) ns = 1;
