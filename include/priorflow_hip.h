@@ -237,6 +237,16 @@ int pf_sum_squares(const float* x, long n, double* partials, int nblk, void* str
 int pf_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, float beta1, float beta2,
                   float eps, double weight_decay, int step, float grad_scale, void* stream);
 
+/* Backward of pf_dccl_combine / pf_dccl_lookup (autograd through DCCL.__call__, core/corr.py:113-144; coords
+ * are detached, core/prior_raft.py:171,176): d_corr -> d_raw (rotate-back transposed; d_own = d_corr), then
+ * d_own / d_raw -> gradients of the own and the other pyramid (level i: [B*N][H_i*W_i]).  All outputs are
+ * ACCUMULATED with fp32 atomics: zero them once per step. */
+int pf_dccl_combine_bwd(const float* d_corr, int ld_in, const float* g_back, float* d_raw, int ld,
+                        int B, int H8, int W8, void* stream);
+int pf_dccl_lookup_bwd(const float* coords, const float* g_w2c, const float* d_own, const float* d_raw, int ld,
+                       float* own0, float* own1, float* own2, float* own3,
+                       float* oth0, float* oth1, float* oth2, float* oth3, int B, int H8, int W8, void* stream);
+
 /* Weight and bias gradient of a stride-1 convolution (what autograd computes for every nn.Conv2d of
  * core/update.py / core/extractor.py in `loss.backward()`, train_flow.py:135):
  *   dw[o][tap][c] += sum_p dy[p][o] * x[p + off(tap)][c],  db[o] += sum_p dy[p][o]

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
     "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
+    "pf_dccl_combine_bwd": [_fp, _i, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_dccl_lookup_bwd": [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pf_conv2d_wgrad": [_fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_seq_loss": [_fp, _fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, _i, _i, _i, _fp],
     "pf_sum_squares": [_fp, C.c_long, _fp, _i, _fp],
@@ -302,6 +304,19 @@ class PfLib:
         return out
 
     # ---- training-step pieces ---------------------------------------------------------------
+    def dccl_combine_bwd(self, d_corr, g_back, d_raw, B, H8, W8):
+        self._chk(d_corr, g_back, d_raw)
+        self._rc(self._dll.pf_dccl_combine_bwd(_ptr(d_corr), d_corr.shape[-1], _ptr(g_back), _ptr(d_raw), d_raw.shape[-1],
+                                               B, H8, W8, self._stream(d_corr)), "pf_dccl_combine_bwd")
+
+    def dccl_lookup_bwd(self, coords, g_w2c, d_own, d_raw, g_own, g_other):
+        """g_own / g_other: lists of 4 level gradients [B*N, H_i*W_i], accumulated into."""
+        self._chk(coords, g_w2c, d_own, d_raw, *g_own, *g_other)
+        B, _, H, W = coords.shape
+        self._rc(self._dll.pf_dccl_lookup_bwd(_ptr(coords), _ptr(g_w2c), _ptr(d_own), _ptr(d_raw), d_own.shape[-1],
+                                              *[_ptr(t) for t in g_own], *[_ptr(t) for t in g_other], B, H, W,
+                                              self._stream(coords)), "pf_dccl_lookup_bwd")
+
     def conv2d_wgrad(self, x0, off0, c0, dy, off_dy, cout, dw, db, kh, kw, B, H8, W8, x1=None, off1=0, c1=0):
         """dw [Cout_pad128, kh*kw, Cin_pad32] and db [Cout_pad128] (or None) are accumulated into."""
         self._chk(x0, x1, dy, dw, db)

@@ -355,6 +355,71 @@ PF_HD void pf_combine_elem(long idx, const PfCombineArgs& a) {  // idx over B*N*
 }
 
 // ----------------------------------------------------------------------------------------------
+// Backward of K3 + K4 (SURVEY.md 8f-3 groundwork).  coords are detached every iteration
+// (core/prior_raft.py:171,176) and the sample grids are constants, so the only gradients are those of the
+// sampled VALUES: the bilinear weights of the forward, scattered.
+//   combine:  corr = own + rotate_back(raw)  =>  d_own = d_corr (no kernel), d_raw[idx_k(p)] += w_k(p) d_corr[p]
+//   lookup:   own[n][k] = sum_j w_j pyr_own[lvl][n][idx_j]   =>  g_own[lvl][n][idx_j]   += w_j d_own[n][k]
+//             raw[n][k] = sum_j w_j pyr_oth[lvl][n][idx_j'] =>  g_other[lvl][n][idx_j'] += w_j d_raw[n][k]
+// Gradients are ACCUMULATED (fp32 atomics; callers zero the buffers once per step).
+// ----------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PF_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
+#else
+#define PF_ATOMIC_ADD(ptr, v) do { float* pf_p_ = (ptr); const float pf_v_ = (v); _Pragma("omp atomic") *pf_p_ += pf_v_; } while (0)
+#endif
+struct PfCombineBwdArgs {
+    const float* d_corr;                  // channel-last [B*N][ld_in]
+    const float* g_back;                  // [2,N]
+    float* d_raw;                         // channel-last [B*N][ld]  (accumulated)
+    int B, H, W, ld_in, ld;
+};
+PF_HD void pf_combine_bwd_elem(long idx, const PfCombineBwdArgs& a) {   // idx over B*N*324
+    const long N = (long)a.H * a.W;
+    const int k = (int)(idx % PF_CORR_CH);
+    const long row = idx / PF_CORR_CH;
+    const long b = row / N, n = row % N;
+    const PfTaps t = pf_taps0(pf_pymod(a.g_back[n], (float)a.W), a.g_back[N + n], a.H, a.W);
+    const float g = a.d_corr[row * a.ld_in + k];
+    float* base = a.d_raw + b * N * a.ld + k;
+    for (int j = 0; j < 4; ++j)
+        if (t.w[j] != 0.f) PF_ATOMIC_ADD(base + (long)t.idx[j] * a.ld, g * t.w[j]);
+}
+struct PfLookupBwdArgs {
+    const float* coords;                  // planar [B,2,N]
+    const float* g_w2c;                   // [2,N]
+    const float* d_own; const float* d_raw;      // channel-last [B*N][ld]
+    float* g_own[PF_CORR_LEVELS];         // level i: [B*N][H_i*W_i]  (accumulated)
+    float* g_other[PF_CORR_LEVELS];
+    int B, H, W, ld;
+};
+PF_HD void pf_lookup_bwd_elem(long idx, const PfLookupBwdArgs& a) {     // idx over B*N*324
+    const long N = (long)a.H * a.W;
+    const int k = (int)(idx % PF_CORR_CH);
+    const long row = idx / PF_CORR_CH;
+    const long b = row / N, n = row % N;
+    const int lvl = k / PF_TAPS, tap = k % PF_TAPS;
+    const int ta = tap / 9, tb = tap % 9;             // slow axis a offsets x (core/corr.py:120-126)
+    const int Hl = a.H >> lvl, Wl = a.W >> lvl;
+    const float inv = 1.f / (float)(1 << lvl);
+    const float cx = a.coords[(b * 2 + 0) * N + n] * inv + (float)(ta - PF_CORR_RADIUS);
+    const float cy = a.coords[(b * 2 + 1) * N + n] * inv + (float)(tb - PF_CORR_RADIUS);
+    const long lsz = (long)Hl * Wl;
+    const float go = a.d_own[row * a.ld + k], gr = a.d_raw[row * a.ld + k];
+    const PfTaps t = pf_taps0(pf_pymod(cx, (float)Wl), cy, Hl, Wl);
+    float* own = a.g_own[lvl] + row * lsz;
+    for (int j = 0; j < 4; ++j)
+        if (t.w[j] != 0.f) PF_ATOMIC_ADD(own + t.idx[j], go * t.w[j]);
+    // cross view: the level-i coordinates index the LEVEL-0 grid (core/corr.py:132-133)
+    const PfTaps tg = pf_taps0(pf_pymod(cx, (float)a.W), cy, a.H, a.W);
+    const float gx = pf_apply(tg, a.g_w2c), gy = pf_apply(tg, a.g_w2c + N);
+    const PfTaps to = pf_taps0(pf_pymod(gx, (float)Wl), gy, Hl, Wl);
+    float* oth = a.g_other[lvl] + row * lsz;
+    for (int j = 0; j < 4; ++j)
+        if (to.w[j] != 0.f) PF_ATOMIC_ADD(oth + to.idx[j], gr * to.w[j]);
+}
+
+// ----------------------------------------------------------------------------------------------
 // K12: convex 8x upsampling (core/prior_raft.py:58-67); flow = coords1 - coords0
 // ----------------------------------------------------------------------------------------------
 struct PfUpsampleArgs {

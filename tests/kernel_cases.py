@@ -390,6 +390,32 @@ def case_flow_metrics(lib, dev):
         assert float((got[:, r] - want).abs().max()) < 1e-9, ("region_sums", r)
 
 
+def case_dccl_backward(lib, dev):
+    """pf_dccl_combine_bwd + pf_dccl_lookup_bwd vs autograd through the oracle's dccl_lookup."""
+    import math
+    h, w = H8, W8
+    n = h * w
+    f1, f2 = gc.fmaps("dbw/a", 1, h, w)
+    f3, f4 = gc.fmaps("dbw/b", 1, h, w)
+    pyr_a = [p.clone().requires_grad_(True) for p in po.build_pyramid(po.corr_volume(f1, f2))]
+    pyr_b = [p.clone().requires_grad_(True) for p in po.build_pyramid(po.corr_volume(f3, f4))]
+    coords = gc.nasty_coords("dbw/co", 1, h, w)
+    g_w2c = po.sample_grid(h, w, po.rotation_x(math.pi / 2))
+    g_back = po.sample_grid(h, w, po.rotation_x(-math.pi / 2))
+    own, cross = po.dccl_lookup(coords, pyr_a, pyr_b, g_w2c, g_back)
+    G = gc.uni("dbw/G", (1, 324, h, w), -1, 1)
+    ((own + cross) * G).sum().backward()
+    d_corr = cl(G).to(dev).contiguous()
+    d_raw = torch.zeros(n, 324, device=dev)
+    lib.dccl_combine_bwd(d_corr, g_back.to(dev).contiguous(), d_raw, 1, h, w)
+    g_own = [torch.zeros(n, (h >> i) * (w >> i), device=dev) for i in range(4)]
+    g_oth = [torch.zeros(n, (h >> i) * (w >> i), device=dev) for i in range(4)]
+    lib.dccl_lookup_bwd(coords.to(dev), g_w2c.to(dev).contiguous(), d_corr, d_raw, g_own, g_oth)
+    for i in range(4):
+        check(g_own[i], pyr_a[i].grad.reshape(n, -1), 2e-5, f"own pyramid gradient level {i}")
+        check(g_oth[i], pyr_b[i].grad.reshape(n, -1), 5e-5, f"other pyramid gradient level {i}")
+
+
 def case_training_pieces(lib, dev):
     """pf_seq_loss / pf_sum_squares / pf_adamw_step vs the oracle's restatement of train_flow.py."""
     from gen_golden_train import adam_case, loss_case
@@ -429,4 +455,4 @@ def case_training_pieces(lib, dev):
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
-                     case_flow_metrics, case_training_pieces, case_bad_args]
+                     case_flow_metrics, case_training_pieces, case_dccl_backward, case_bad_args]
