@@ -241,6 +241,9 @@ int pf_adamw_step(float* p, const float* g, float* m, float* v, long n, double l
  * are detached, core/prior_raft.py:171,176): d_corr -> d_raw (rotate-back transposed; d_own = d_corr), then
  * d_own / d_raw -> gradients of the own and the other pyramid (level i: [B*N][H_i*W_i]).  All outputs are
  * ACCUMULATED with fp32 atomics: zero them once per step. */
+/* Backward of build_pyramid (core/corr.py:99-111): level gradients g0..g3 ([B*N][H_i*W_i]) -> the dense volume
+ * gradient, written in place into g0 (avg_pool2d backward with floor semantics for odd sizes). */
+int pf_pyramid_bwd(float* g0, const float* g1, const float* g2, const float* g3, int B, int H8, int W8, void* stream);
 int pf_dccl_combine_bwd(const float* d_corr, int ld_in, const float* g_back, float* d_raw, int ld,
                         int B, int H8, int W8, void* stream);
 int pf_dccl_lookup_bwd(const float* coords, const float* g_w2c, const float* d_own, const float* d_raw, int ld,

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
     "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
+    "pf_pyramid_bwd": [_fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pf_dccl_combine_bwd": [_fp, _i, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_dccl_lookup_bwd": [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pf_conv2d_wgrad": [_fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp],
@@ -304,6 +305,13 @@ class PfLib:
         return out
 
     # ---- training-step pieces ---------------------------------------------------------------
+    def pyramid_bwd(self, g_levels, B, H8, W8):
+        """g_levels: 4 level gradients [B*N, H_i*W_i]; level 0 becomes the dense volume gradient (in place)."""
+        self._chk(*g_levels)
+        self._rc(self._dll.pf_pyramid_bwd(*[_ptr(t) for t in g_levels], B, H8, W8, self._stream(g_levels[0])),
+                 "pf_pyramid_bwd")
+        return g_levels[0]
+
     def dccl_combine_bwd(self, d_corr, g_back, d_raw, B, H8, W8):
         self._chk(d_corr, g_back, d_raw)
         self._rc(self._dll.pf_dccl_combine_bwd(_ptr(d_corr), d_corr.shape[-1], _ptr(g_back), _ptr(d_raw), d_raw.shape[-1],

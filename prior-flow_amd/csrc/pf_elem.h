@@ -419,6 +419,28 @@ PF_HD void pf_lookup_bwd_elem(long idx, const PfLookupBwdArgs& a) {     // idx o
         if (to.w[j] != 0.f) PF_ATOMIC_ADD(oth + to.idx[j], gr * to.w[j]);
 }
 
+// Backward of build_pyramid (core/corr.py:99-111: three F.avg_pool2d(2, stride 2), odd sizes floor): the dense
+// volume gradient  dV[row][y][x] = g0 + g1[y/2][x/2]/4 + g2[y/4][x/4]/16 + g3[y/8][x/8]/64, a parent
+// contributing only where it exists (y>>i < H>>i and the whole chain of windows was complete).  Written in
+// place into the level-0 gradient; one pass.  (The feature gradients are then two plain GEMMs, dV f2 and dV^T f1.)
+struct PfPyramidBwdArgs { float* g0; const float* g1; const float* g2; const float* g3; long rows; int H, W; };
+PF_HD void pf_pyramid_bwd_elem(long idx, const PfPyramidBwdArgs& a) {    // idx over rows*H*W
+    const int N = a.H * a.W;
+    const long row = idx / N;
+    const int n = (int)(idx % N), y = n / a.W, x = n % a.W;
+    float v = a.g0[idx];
+    int hy = a.H, hx = a.W, py = y, px = x;
+    const float* lv[3] = {a.g1, a.g2, a.g3};
+    float scale = 1.f;
+    for (int i = 0; i < 3; ++i) {
+        hy >>= 1; hx >>= 1; py >>= 1; px >>= 1;
+        if (py >= hy || px >= hx) break;           // odd size: the last row / column has no parent (nor grand-parents)
+        scale *= 0.25f;
+        v = v + lv[i][row * ((long)hy * hx) + (long)py * hx + px] * scale;
+    }
+    a.g0[idx] = v;
+}
+
 // ----------------------------------------------------------------------------------------------
 // K12: convex 8x upsampling (core/prior_raft.py:58-67); flow = coords1 - coords0
 // ----------------------------------------------------------------------------------------------

@@ -414,6 +414,21 @@ def case_dccl_backward(lib, dev):
     for i in range(4):
         check(g_own[i], pyr_a[i].grad.reshape(n, -1), 2e-5, f"own pyramid gradient level {i}")
         check(g_oth[i], pyr_b[i].grad.reshape(n, -1), 5e-5, f"other pyramid gradient level {i}")
+    # pyramid -> dense volume gradient -> feature gradients (odd map: floor pooling), vs autograd
+    for hh, ww in ((16, 32), (17, 27)):
+        nn_ = hh * ww
+        a1, a2 = gc.fmaps(f"dbw/p{hh}", 1, hh, ww)
+        a1 = a1[:, :32].clone().requires_grad_(True)
+        a2 = a2[:, :32].clone().requires_grad_(True)
+        pyr = po.build_pyramid(po.corr_volume(a1, a2))
+        gl = [gc.uni(f"dbw/g{hh}/{i}", tuple(p.shape), -1, 1) for i, p in enumerate(pyr)]
+        sum((p * g).sum() for p, g in zip(pyr, gl)).backward()
+        dv = [g.reshape(nn_, -1).contiguous().to(dev) for g in gl]
+        lib.pyramid_bwd(dv, 1, hh, ww)
+        r1, r2 = cl(a1.detach()).to(dev), cl(a2.detach()).to(dev)          # [N, C]
+        scale = 1.0 / math.sqrt(32.0)
+        check(cl(a1.grad), (dv[0] @ r2) * scale, 2e-4, f"f1 gradient {hh}x{ww}")
+        check(cl(a2.grad), (dv[0].t() @ r1) * scale, 2e-4, f"f2 gradient {hh}x{ww}")
 
 
 def case_training_pieces(lib, dev):
