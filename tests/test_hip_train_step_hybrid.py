@@ -3,7 +3,9 @@
 The reference's training step (tests/golden/train_step.npz: B=2, 128x256, iters=3, loss + backward) is re-run
 on the GPU with the ORACLE's graph (test infrastructure: every sampler / norm / activation stays a torch op) but
 with every supported convolution -- forward, data gradient and weight / bias gradient -- executed by the HIP
-kernels through one autograd.Function (pf_conv2d, Conv.dgrad_of + pf_conv2d, pf_conv2d_wgrad).  Loss, total
+kernels through one autograd.Function (pf_conv2d, Conv.dgrad_of + pf_conv2d, pf_conv2d_wgrad), and likewise the
+correlation path: corr + pyramid (pf_corr_pyramid_bf16x3 / pf_pyramid_bwd + GEMMs) and the DCCL lookups
+(pf_dccl_lookup + pf_dccl_combine / pf_dccl_combine_bwd + pf_dccl_lookup_bwd).  Loss, total
 gradient norm and gradient slices must match the reference's.  This is NOT a product training path."""
 import math
 import types
@@ -70,6 +72,79 @@ class HipConv(torch.autograd.Function):
         return _nchw(dx, B, H, W), Conv.unpack_wgrad(dw, cout, C, kh, kw), db[:cout].clone()
 
 
+class HipCorrPyramid(torch.autograd.Function):
+    """corr + build_pyramid (core/prior_raft.py:69-75, core/corr.py:99-111): forward = the fused bf16x3 kernel,
+    backward = pf_pyramid_bwd (dense volume gradient) + the two feature GEMMs."""
+
+    @staticmethod
+    def forward(ctx, f1, f2):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        B, C, H, W = f1.shape
+        n = H * W
+        r1, r2 = _rows(f1.detach()), _rows(f2.detach())
+        sp = [lib.split_bf16(r, torch.empty(B * n, C // 32, 2, 32, dtype=torch.bfloat16, device=f1.device)) for r in (r1, r2)]
+        lv = [torch.empty(B * n, (H >> i) * (W >> i), device=f1.device) for i in range(4)]
+        lib.corr_pyramid_bf16x3(sp[0], sp[1], lv, B, H, W, C)
+        ctx.save_for_backward(r1, r2)
+        ctx.shape = (B, C, H, W)
+        STATS["hip"] += 1
+        return tuple(l.view(B * n, 1, H >> i, W >> i) for i, l in enumerate(lv))
+
+    @staticmethod
+    def backward(ctx, *g):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        r1, r2 = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        n = H * W
+        gl = [x.reshape(B * n, -1).contiguous().clone() for x in g]
+        dv = lib.pyramid_bwd(gl, B, H, W).view(B, n, n)
+        s = 1.0 / math.sqrt(C)
+        d1 = torch.bmm(dv, r2.view(B, n, C)) * s                      # plain GEMMs
+        d2 = torch.bmm(dv.transpose(1, 2), r1.view(B, n, C)) * s
+        return _nchw(d1.reshape(B * n, C), B, H, W), _nchw(d2.reshape(B * n, C), B, H, W)
+
+
+class HipDccl(torch.autograd.Function):
+    """DCCL.__call__ (core/corr.py:113-144), own + cross summed: forward pf_dccl_lookup + pf_dccl_combine,
+    backward pf_dccl_combine_bwd + pf_dccl_lookup_bwd."""
+
+    @staticmethod
+    def forward(ctx, coords, g_w2c, g_back, *pyr):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        B, _, H, W = coords.shape
+        n = H * W
+        own_p = [p.detach().reshape(B * n, -1).contiguous() for p in pyr[:4]]
+        oth_p = [p.detach().reshape(B * n, -1).contiguous() for p in pyr[4:]]
+        own, raw, out = (torch.empty(B * n, 324, device=coords.device) for _ in range(3))
+        co = coords.detach().contiguous()
+        lib.dccl_lookup(co, own_p, oth_p, g_w2c.contiguous(), own, raw)
+        lib.dccl_combine(own, raw, g_back.contiguous(), out, B, H, W)
+        ctx.save_for_backward(co, g_w2c.contiguous(), g_back.contiguous())
+        ctx.shapes = [tuple(p.shape) for p in pyr]
+        ctx.dims = (B, H, W)
+        STATS["hip"] += 1
+        return _nchw(out, B, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        co, g_w2c, g_back = ctx.saved_tensors
+        B, H, W = ctx.dims
+        n = H * W
+        d_corr = _rows(g)
+        d_raw = torch.zeros(B * n, 324, device=g.device)
+        lib.dccl_combine_bwd(d_corr, g_back, d_raw, B, H, W)
+        g_own = [torch.zeros(B * n, (H >> i) * (W >> i), device=g.device) for i in range(4)]
+        g_oth = [torch.zeros(B * n, (H >> i) * (W >> i), device=g.device) for i in range(4)]
+        lib.dccl_lookup_bwd(co, g_w2c, d_corr, d_raw, g_own, g_oth)
+        grads = [x.view(s) for x, s in zip(g_own + g_oth, ctx.shapes)]
+        return (None, None, None, *grads)
+
+
 def hip_conv2d(x, w, b=None, stride=1, padding=0, **kw):
     kh, kwid = w.shape[2], w.shape[3]
     pad = (padding, padding) if isinstance(padding, int) else tuple(padding)
@@ -97,6 +172,14 @@ def test_training_step_with_hip_conv_forward_and_backward(monkeypatch):
     shim.conv2d = hip_conv2d
     monkeypatch.setattr(po, "F", shim)
     monkeypatch.setattr(po, "_conv", lambda p, name, x, pad: hip_conv2d(x, p[name + ".weight"], p[name + ".bias"], padding=pad))
+    # corr + pyramid and the DCCL lookups on the HIP kernels too (forward and backward)
+    monkeypatch.setattr(po, "corr_volume", lambda f1, f2: (f1, f2))
+    monkeypatch.setattr(po, "build_pyramid", lambda pair: list(HipCorrPyramid.apply(*pair)))
+
+    def hip_dccl(coords, pyr_own, pyr_other, g_w2c, g_back):
+        out = HipDccl.apply(coords, g_w2c, g_back, *pyr_own, *pyr_other)
+        return out, torch.zeros_like(out)
+    monkeypatch.setattr(po, "dccl_lookup", hip_dccl)
     STATS["hip"] = STATS["torch"] = 0
     torch.set_default_device(dev)
     try:
