@@ -241,6 +241,16 @@ int pf_adamw_step(float* p, const float* g, float* m, float* v, long n, double l
  * are detached, core/prior_raft.py:171,176): d_corr -> d_raw (rotate-back transposed; d_own = d_corr), then
  * d_own / d_raw -> gradients of the own and the other pyramid (level i: [B*N][H_i*W_i]).  All outputs are
  * ACCUMULATED with fp32 atomics: zero them once per step. */
+/* Backward of pf_warp_gcorr (autograd through cycle_bilinear_sampler + groupwise_corr, core/prior_raft.py:173-174,
+ * :77-83; coords detached): d_flaw (4 channels at off_d of [B*N][ld_d]) -> d_f1, d_f2 [B*N][C], both ACCUMULATED. */
+int pf_warp_gcorr_bwd(const float* f1, const float* f2, const float* coords, int add_grid, const float* d_flaw,
+                      int ld_d, int off_d, float* d_f1, float* d_f2, int B, int H8, int W8, int C, void* stream);
+
+/* Backward of pf_upsample_flow (autograd through upsample_flow, core/prior_raft.py:58-67): g [B,2,8*H8,8*W8] ->
+ * d_mask [B*N][ld_d] (all 576 logits written; softmax backward) and d_flow [B,2,H8,W8] (= d coords1, ACCUMULATED). */
+int pf_upsample_flow_bwd(const float* coords1, const float* mask, int ld, const float* g, float* d_mask, int ld_d,
+                         float* d_flow, int B, int H8, int W8, void* stream);
+
 /* Backward of build_pyramid (core/corr.py:99-111): level gradients g0..g3 ([B*N][H_i*W_i]) -> the dense volume
  * gradient, written in place into g0 (avg_pool2d backward with floor semantics for odd sizes). */
 int pf_pyramid_bwd(float* g0, const float* g1, const float* g2, const float* g3, int B, int H8, int W8, void* stream);

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
     "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
+    "pf_warp_gcorr_bwd": [_fp, _fp, _fp, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_upsample_flow_bwd": [_fp, _fp, _i, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_pyramid_bwd": [_fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pf_dccl_combine_bwd": [_fp, _i, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_dccl_lookup_bwd": [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
@@ -305,6 +307,22 @@ class PfLib:
         return out
 
     # ---- training-step pieces ---------------------------------------------------------------
+    def warp_gcorr_bwd(self, f1, f2, coords, add_grid, d_flaw, off_d, d_f1, d_f2):
+        """d_flaw: channel-last rows with the 4 group gradients at column off_d; d_f1 / d_f2 accumulated."""
+        self._chk(f1, f2, coords, d_flaw, d_f1, d_f2)
+        B, _, H, W = coords.shape
+        self._rc(self._dll.pf_warp_gcorr_bwd(_ptr(f1), _ptr(f2), _ptr(coords), int(add_grid), _ptr(d_flaw),
+                                             d_flaw.shape[-1], off_d, _ptr(d_f1), _ptr(d_f2), B, H, W, f1.shape[-1],
+                                             self._stream(f1)), "pf_warp_gcorr_bwd")
+
+    def upsample_flow_bwd(self, coords1, mask, g, d_mask, d_flow):
+        """g [B,2,8H,8W] -> d_mask [B*N, >=576] (written), d_flow [B,2,H,W] (accumulated)."""
+        self._chk(coords1, mask, g, d_mask, d_flow)
+        B, _, H, W = coords1.shape
+        self._rc(self._dll.pf_upsample_flow_bwd(_ptr(coords1), _ptr(mask), mask.shape[-1], _ptr(g), _ptr(d_mask),
+                                                d_mask.shape[-1], _ptr(d_flow), B, H, W, self._stream(g)),
+                 "pf_upsample_flow_bwd")
+
     def pyramid_bwd(self, g_levels, B, H8, W8):
         """g_levels: 4 level gradients [B*N, H_i*W_i]; level 0 becomes the dense volume gradient (in place)."""
         self._chk(*g_levels)

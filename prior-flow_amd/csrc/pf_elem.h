@@ -11,6 +11,12 @@
 #include "pf_common.h"
 
 // ----------------------------------------------------------------------------------------------
+// accumulation into gradient buffers: device atomics / omp atomic in the host emulation
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PF_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
+#else
+#define PF_ATOMIC_ADD(ptr, v) do { float* pf_p_ = (ptr); const float pf_v_ = (v); _Pragma("omp atomic") *pf_p_ += pf_v_; } while (0)
+#endif
 // scalar helpers
 // ----------------------------------------------------------------------------------------------
 // Python-style float remainder for b > 0 (`xgrid % W`, core/utils/utils.py:83; ATen: fmod, then +b when
@@ -363,11 +369,6 @@ PF_HD void pf_combine_elem(long idx, const PfCombineArgs& a) {  // idx over B*N*
 //             raw[n][k] = sum_j w_j pyr_oth[lvl][n][idx_j'] =>  g_other[lvl][n][idx_j'] += w_j d_raw[n][k]
 // Gradients are ACCUMULATED (fp32 atomics; callers zero the buffers once per step).
 // ----------------------------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PF_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
-#else
-#define PF_ATOMIC_ADD(ptr, v) do { float* pf_p_ = (ptr); const float pf_v_ = (v); _Pragma("omp atomic") *pf_p_ += pf_v_; } while (0)
-#endif
 struct PfCombineBwdArgs {
     const float* d_corr;                  // channel-last [B*N][ld_in]
     const float* g_back;                  // [2,N]
@@ -479,6 +480,54 @@ PF_HD void pf_upsample_elem(long idx, const PfUpsampleArgs& a) {  // idx over B*
     const long plane = (long)W8 * H8;
     a.out[(b * 2 + 0) * plane + (long)Y * W8 + X] = su;
     a.out[(b * 2 + 1) * plane + (long)Y * W8 + X] = sv;
+}
+
+// Backward of K12 (autograd through upsample_flow, core/prior_raft.py:58-67), one fine pixel per call:
+// with w = softmax_k(mask[64k + 8i + j]) and nb_k = 8 * flow at the k-th 3x3 neighbour (zero outside),
+//   d_mask[64k + 8i + j] = w_k (s_k - sum_k' w_k' s_k'),  s_k = <g, nb_k>        (written; the caller's mask is
+//                                                                                  0.25 * conv: scale upstream)
+//   d_flow[neighbour k]  += 8 w_k g                                              (fp32 atomics; = d coords1)
+struct PfUpsampleBwdArgs {
+    const float* coords1;   // planar [B,2,N]
+    const float* mask;      // channel-last [B*N][ld]
+    const float* g;         // NCHW [B,2,8H,8W]: gradient of the upsampled flow
+    float* d_mask;          // channel-last [B*N][ld_d]  (every one of the 576 columns is written)
+    float* d_flow;          // planar [B,2,N]  (accumulated)
+    int B, H, W, ld, ld_d;
+};
+PF_HD void pf_upsample_bwd_elem(long idx, const PfUpsampleBwdArgs& a) {  // idx over B*8H*8W
+    const int W8 = 8 * a.W, H8 = 8 * a.H;
+    const long N = (long)a.H * a.W;
+    const int X = (int)(idx % W8);
+    const int Y = (int)((idx / W8) % H8);
+    const long b = idx / ((long)W8 * H8);
+    const int x = X >> 3, j = X & 7, y = Y >> 3, i = Y & 7;
+    const long prow = b * N + (long)y * a.W + x;
+    const float* mrow = a.mask + prow * a.ld + 8 * i + j;
+    const long plane = (long)W8 * H8;
+    const float gu = a.g[(b * 2 + 0) * plane + (long)Y * W8 + X], gv = a.g[(b * 2 + 1) * plane + (long)Y * W8 + X];
+    float w[9], sk[9];
+    float mx = -INFINITY;
+    for (int k = 0; k < 9; ++k) { w[k] = mrow[64 * k]; mx = fmaxf(mx, w[k]); }
+    float den = 0.f;
+    for (int k = 0; k < 9; ++k) { w[k] = expf(w[k] - mx); den = den + w[k]; }
+    float dot = 0.f;
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        w[k] = w[k] / den;
+        sk[k] = 0.f;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+            const long p = (long)yy * a.W + xx;
+            const float fu = 8.f * (a.coords1[(b * 2 + 0) * N + p] - (float)xx);
+            const float fv = 8.f * (a.coords1[(b * 2 + 1) * N + p] - (float)yy);
+            sk[k] = gu * fu + gv * fv;
+            PF_ATOMIC_ADD(a.d_flow + (b * 2 + 0) * N + p, 8.f * w[k] * gu);
+            PF_ATOMIC_ADD(a.d_flow + (b * 2 + 1) * N + p, 8.f * w[k] * gv);
+        }
+        dot = dot + w[k] * sk[k];
+    }
+    float* drow = a.d_mask + prow * a.ld_d + 8 * i + j;
+    for (int k = 0; k < 9; ++k) drow[64 * k] = w[k] * (sk[k] - dot);
 }
 
 // coords1 += delta  (core/prior_raft.py:193,196); delta is channel-last [B*N][ld]
@@ -781,3 +830,33 @@ PF_HD void pf_warp_gcorr_elem(long idx, const PfWarpGcorrArgs& a) {   // idx ove
         acc = acc + a.f1[row * a.C + c] * pf_apply_ld(t, f2b + c, a.C);
     a.dst.ptr[row * a.dst.ld + a.dst.c_off + g] = acc / (float)cg;
 }
+
+// Backward of K5 (autograd through cycle_bilinear_sampler + groupwise_corr, core/prior_raft.py:173-174,
+// :77-83; coords detached): with gs = d_flaw[group(c)] / (C/4),
+//   d_f1[p][c]        += gs * warped_f2[p][c]
+//   d_f2[corner_k][c] += gs * f1[p][c] * w_k          (fp32 atomics: several pixels sample the same corner)
+// One call = one (pixel, channel); both outputs are ACCUMULATED.
+struct PfWarpGcorrBwdArgs {
+    const float* f1; const float* f2;   // channel-last [B*N][C]
+    const float* coords;                // planar [B,2,N]
+    const float* d_flaw; int ld_d, off_d;   // channel-last gradient of the 4 group means
+    float* d_f1; float* d_f2;           // channel-last [B*N][C]
+    int B, H, W, C, add_grid;
+};
+PF_HD void pf_warp_gcorr_bwd_elem(long idx, const PfWarpGcorrBwdArgs& a) {   // idx over B*N*C
+    const long N = (long)a.H * a.W;
+    const int c = (int)(idx % a.C);
+    const long row = idx / a.C;
+    const long b = row / N, n = row % N;
+    PfWarpGcorrArgs fa; fa.coords = a.coords; fa.H = a.H; fa.W = a.W; fa.add_grid = a.add_grid;
+    const PfTaps t = pf_warp_taps(fa, b, n);
+    const int cg = a.C / 4;
+    const float gs = a.d_flaw[row * a.ld_d + a.off_d + c / cg] / (float)cg;
+    const float* f2b = a.f2 + b * N * a.C + c;
+    PF_ATOMIC_ADD(a.d_f1 + row * a.C + c, gs * pf_apply_ld(t, f2b, a.C));
+    const float v = gs * a.f1[row * a.C + c];
+    float* d2 = a.d_f2 + b * N * a.C + c;
+    for (int j = 0; j < 4; ++j)
+        if (t.w[j] != 0.f) PF_ATOMIC_ADD(d2 + (long)t.idx[j] * a.C, v * t.w[j]);
+}
+

@@ -193,6 +193,37 @@ def case_upsample(lib, dev):
     check(out, gc.load("upsample")["out"], 3e-5, "upsample vs reference")
 
 
+def case_warp_gcorr_backward(lib, dev):
+    """pf_warp_gcorr_bwd vs autograd through the oracle's warp + groupwise correlation."""
+    f1, f2 = gc.fmaps("wgb", 2)
+    f1, f2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    co = gc.nasty_coords("wgb", 2)
+    G = gc.uni("wgb/G", (2, 4, H8, W8), -1, 1)
+    (po.warp_groupwise_corr(f1, f2, co) * G).sum().backward()
+    d_flaw = torch.zeros(2 * N, 8, device=dev)
+    d_flaw[:, 2:6] = cl(G).to(dev)
+    d1, d2 = torch.zeros(2 * N, 256, device=dev), torch.zeros(2 * N, 256, device=dev)
+    lib.warp_gcorr_bwd(cl(f1.detach()).to(dev).contiguous(), cl(f2.detach()).to(dev).contiguous(), co.to(dev), False,
+                       d_flaw, 2, d1, d2)
+    check(d1, cl(f1.grad), 2e-6, "d f1")
+    check(d2, cl(f2.grad), 5e-6, "d f2 (scatter)")
+
+
+def case_upsample_backward(lib, dev):
+    """pf_upsample_flow_bwd vs autograd through the oracle's convex upsampling."""
+    fl = gc.uni("upb/flow", (2, 2, H8, W8), -6, 6).requires_grad_(True)
+    mk = gc.uni("upb/mask", (2, 576, H8, W8), -2, 2).requires_grad_(True)
+    G = gc.uni("upb/G", (2, 2, 8 * H8, 8 * W8), -1, 1)
+    (po.upsample_flow(fl, mk) * G).sum().backward()
+    coords1 = (po.coords_grid(2, H8, W8) + fl.detach()).contiguous().to(dev)
+    d_mask = torch.full((2 * N, 580), 7.0, device=dev)
+    d_flow = torch.zeros(2, 2, H8, W8, device=dev)
+    lib.upsample_flow_bwd(coords1, cl(mk.detach()).to(dev).contiguous(), G.to(dev), d_mask, d_flow)
+    check(d_mask[:, :576], cl(mk.grad), 2e-5, "d mask logits")
+    check(d_flow, fl.grad, 1e-5 * float(fl.grad.abs().max()), "d coarse flow")      # 576 fp32 atomic contributions per pixel
+    assert float((d_mask[:, 576:] - 7.0).abs().max()) == 0.0
+
+
 def case_coords_add(lib, dev):
     co = gc.nasty_coords("cadd", B=2)
     delta = gc.uni("cadd/delta", (2 * N, 4), -1, 1)
@@ -470,4 +501,6 @@ def case_training_pieces(lib, dev):
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
-                     case_flow_metrics, case_training_pieces, case_dccl_backward, case_bad_args]
+                     case_flow_metrics, case_training_pieces, case_dccl_backward, case_upsample_backward,
+                     case_warp_gcorr_backward,
+                     case_bad_args]
