@@ -5,7 +5,8 @@ on the GPU with the ORACLE's graph (test infrastructure: every sampler / norm / 
 with every supported convolution -- forward, data gradient and weight / bias gradient -- executed by the HIP
 kernels through one autograd.Function (pf_conv2d, Conv.dgrad_of + pf_conv2d, pf_conv2d_wgrad), and likewise the
 correlation path: corr + pyramid (pf_corr_pyramid_bf16x3 / pf_pyramid_bwd + GEMMs) and the DCCL lookups
-(pf_dccl_lookup + pf_dccl_combine / pf_dccl_combine_bwd + pf_dccl_lookup_bwd).  Loss, total
+(pf_dccl_lookup + pf_dccl_combine / pf_dccl_combine_bwd + pf_dccl_lookup_bwd), the convex upsampling and the
+feature warp + groupwise correlation.  Loss, total
 gradient norm and gradient slices must match the reference's.  This is NOT a product training path."""
 import math
 import types
@@ -145,6 +146,60 @@ class HipDccl(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+class HipUpsample(torch.autograd.Function):
+    """upsample_flow (core/prior_raft.py:58-67): pf_upsample_flow / pf_upsample_flow_bwd."""
+
+    @staticmethod
+    def forward(ctx, flow, mask):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        B, _, H, W = flow.shape
+        coords1 = (po.coords_grid(B, H, W).to(flow.device) + flow.detach()).contiguous()
+        mrows = _rows(mask.detach())
+        out = torch.empty(B, 2, 8 * H, 8 * W, device=flow.device)
+        lib.upsample_flow(coords1, mrows, out)
+        ctx.save_for_backward(coords1, mrows)
+        STATS["hip"] += 1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        coords1, mrows = ctx.saved_tensors
+        B, _, H, W = coords1.shape
+        d_mask = torch.empty(B * H * W, 576, device=g.device)
+        d_flow = torch.zeros(B, 2, H, W, device=g.device)
+        lib.upsample_flow_bwd(coords1, mrows, g.contiguous(), d_mask, d_flow)
+        return d_flow, _nchw(d_mask, B, H, W)
+
+
+class HipWarpGcorr(torch.autograd.Function):
+    """cycle_bilinear_sampler + groupwise_corr (core/prior_raft.py:173-174, :77-83): pf_warp_gcorr / pf_warp_gcorr_bwd."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, coords):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        B, C, H, W = f1.shape
+        r1, r2, co = _rows(f1.detach()), _rows(f2.detach()), coords.detach().contiguous()
+        out = torch.empty(B * H * W, 4, device=f1.device)
+        lib.warp_gcorr(r1, r2, co, False, out, 0)
+        ctx.save_for_backward(r1, r2, co)
+        STATS["hip"] += 1
+        return _nchw(out, B, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        r1, r2, co = ctx.saved_tensors
+        B, _, H, W = co.shape
+        d1, d2 = torch.zeros_like(r1), torch.zeros_like(r2)
+        lib.warp_gcorr_bwd(r1, r2, co, False, _rows(g), 0, d1, d2)
+        return _nchw(d1, B, H, W), _nchw(d2, B, H, W), None
+
+
 def hip_conv2d(x, w, b=None, stride=1, padding=0, **kw):
     kh, kwid = w.shape[2], w.shape[3]
     pad = (padding, padding) if isinstance(padding, int) else tuple(padding)
@@ -180,6 +235,8 @@ def test_training_step_with_hip_conv_forward_and_backward(monkeypatch):
         out = HipDccl.apply(coords, g_w2c, g_back, *pyr_own, *pyr_other)
         return out, torch.zeros_like(out)
     monkeypatch.setattr(po, "dccl_lookup", hip_dccl)
+    monkeypatch.setattr(po, "upsample_flow", lambda flow, mask: HipUpsample.apply(flow, mask))
+    monkeypatch.setattr(po, "warp_groupwise_corr", lambda f1, f2, coords, groups=4: HipWarpGcorr.apply(f1, f2, coords))
     STATS["hip"] = STATS["torch"] = 0
     torch.set_default_device(dev)
     try:
