@@ -384,12 +384,151 @@ __global__ void __launch_bounds__(256) pf_flow_out_wave(const PfFlowOutArgs a, c
         }
     }
 }
+#if defined(PF_FLOW_OUT_STRIP)
+// EXPERIMENTAL, NOT SHIPPED (-DPF_FLOW_OUT_STRIP): one wave per 4 consecutive pixels of a row.  The 3 x 6 input neighbourhood and the 18
+// weight vectors are loaded once per strip (36 16-byte loads instead of 108), and the eight partial
+// sums are reduced with a halving exchange (10 cross-lane steps instead of 48).  ~2x faster than the pixel-wave
+// kernel, but NOT reproducible inside the captured multi-stream graph at small sizes (128x256, 256x512): a single
+// accumulator comes out wrong in lanes 48..63 of a wave that shares its SIMD with the mask head's conv waves, only
+// when the dot products are compiled to packed v_pk_*_f32 (a -fno-slp-vectorize build is stable).  Root cause
+// open; DESIGN.md section 8 has the evidence, profiles/scratch/det_*.py the reproducers (-DPF_FO_DEBUG dumps).
+#if !defined(PF_FO_LB)
+#define PF_FO_LB 1
+#endif
+#if defined(PF_FO_DEBUG)
+__device__ float* g_fo_dbg = nullptr;
+#endif
+__global__ void __launch_bounds__(256, PF_FO_LB) pf_flow_out_strip(const PfFlowOutArgs a, const long strips, const int spr) {
+    const int lane = threadIdx.x & 63;
+    const long N = (long)a.H * a.W;
+    long strip = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 4;
+    for (; strip < strips; strip += stride) {
+        const long b = strip / ((long)a.H * spr);
+        const int rem = (int)(strip % ((long)a.H * spr));
+        const int y = rem / spr, x0 = (rem % spr) * 4;
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+        for (int c = lane * 4; c < a.C; c += 256) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = y + ky - 1;
+                if (yy < 0 || yy >= a.H) continue;                           // wave-uniform
+                const float* xrow = a.x + (b * N + (long)yy * a.W) * a.ld + c;
+                float4 v[6], w0[3], w1[3];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int xx = x0 + i - 1;
+#if defined(PF_FO_NOBRANCH)
+                    const bool ok = xx >= 0 && xx < a.W;
+                    const float4 t = *reinterpret_cast<const float4*>(xrow + (long)(ok ? xx : x0) * a.ld);
+                    const float m = ok ? 1.f : 0.f;
+                    v[i] = make_float4(t.x * m, t.y * m, t.z * m, t.w * m);
+#else
+                    v[i] = (xx >= 0 && xx < a.W) ? *reinterpret_cast<const float4*>(xrow + (long)xx * a.ld)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    w0[kx] = *reinterpret_cast<const float4*>(a.w + (long)(ky * 3 + kx) * a.C + c);
+                    w1[kx] = *reinterpret_cast<const float4*>(a.w + (long)(9 + ky * 3 + kx) * a.C + c);
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 q = v[p + kx];
+                        s[2 * p] += q.x * w0[kx].x + q.y * w0[kx].y + q.z * w0[kx].z + q.w * w0[kx].w;
+                        s[2 * p + 1] += q.x * w1[kx].x + q.y * w1[kx].y + q.z * w1[kx].z + q.w * w1[kx].w;
+                    }
+#if defined(PF_FO_DEBUG) && PF_FO_DEBUG > 1
+                if (g_fo_dbg && a.delta) {
+                    float* d = g_fo_dbg + ((strip * 64 + lane) * 3 + ky) * 56;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[j] = s[j];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) *reinterpret_cast<float4*>(d + 8 + 4 * i) = v[i];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        *reinterpret_cast<float4*>(d + 32 + 4 * kx) = w0[kx];
+                        *reinterpret_cast<float4*>(d + 44 + 4 * kx) = w1[kx];
+                    }
+                }
+#endif
+            }
+        }
+#if defined(PF_FO_DEBUG)
+        if (PF_FO_DEBUG == 1 && g_fo_dbg && a.delta) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g_fo_dbg[(strip * 64 + lane) * 8 + j] = s[j];
+            if (lane == 0) {
+                unsigned* ids = reinterpret_cast<unsigned*>(g_fo_dbg + strips * 64 * 8) + strip * 2;
+                ids[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+                ids[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+            }
+        }
+#endif
+#if defined(PF_FO_BUTTERFLY)
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += __shfl_xor(s[j], m);
+        {
+            const int j = lane >> 3;
+            float r = s[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) r = (j == q) ? s[q] : r;
+            s[0] = r;
+        }
+        float r = s[0];
+#else
+        // halving exchange: after the m = 32, 16, 8 steps a lane holds sum j = lane >> 3 over 8 lanes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool up = lane & 32;
+            const float keep = up ? s[i + 4] : s[i], send = up ? s[i] : s[i + 4];
+            s[i] = keep + __shfl_xor(send, 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool up = lane & 16;
+            const float keep = up ? s[i + 2] : s[i], send = up ? s[i] : s[i + 2];
+            s[i] = keep + __shfl_xor(send, 16);
+        }
+        {
+            const bool up = lane & 8;
+            const float keep = up ? s[1] : s[0], send = up ? s[0] : s[1];
+            s[0] = keep + __shfl_xor(send, 8);
+        }
+        float r = s[0];
+        r += __shfl_xor(r, 4); r += __shfl_xor(r, 2); r += __shfl_xor(r, 1);
+#endif
+        const int j = lane >> 3, x = x0 + (j >> 1), o = j & 1;
+        if ((lane & 7) == 0 && x < a.W) {
+            const long n = (long)y * a.W + x;
+            const float acc = r + a.bias[o];
+            if (a.delta) a.delta[(b * N + n) * a.ld_delta + o] = acc;
+            a.coords1[(b * 2 + o) * N + n] += acc;
+        }
+    }
+}
+#endif  // PF_FLOW_OUT_STRIP
 int launch_flow_out(const PfFlowOutArgs& a, long total, void* stream) {
     if (a.C % 4 == 0 && a.ld % 4 == 0) {
+#if defined(PF_FLOW_OUT_STRIP)
+        const int spr = (a.W + 3) / 4;
+        const long strips = (long)a.B * a.H * spr;
+        long blocks = (strips + 3) / 4;
+        if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+        hipLaunchKernelGGL(pf_flow_out_strip, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, strips, spr);
+#else
         const long rows = total / 2;
         long blocks = (rows + 3) / 4;
         if (blocks > kMaxBlocks) blocks = kMaxBlocks;
         hipLaunchKernelGGL(pf_flow_out_wave, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, rows);
+#endif
         return (int)hipGetLastError();
     }
     return pf_launch_elem<PfFlowOutArgs, pf_flow_out_elem>(a, total, stream);
@@ -477,6 +616,9 @@ int launch_region_sums(const PfRegionSumArgs& a, void* stream) {
 }
 
 }  // namespace
+#if defined(PF_FLOW_OUT_STRIP) && defined(PF_FO_DEBUG)
+extern "C" int pf_debug_set_flow_out(float* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fo_dbg), &p, sizeof(p)); }
+#endif
 
 #define PF_REGION_SUM_LAUNCH(a, stream) launch_region_sums(a, stream)
 #define PF_SEQ_LOSS_LAUNCH(a, stream) launch_seq_loss(a, stream)

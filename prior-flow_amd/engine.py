@@ -281,6 +281,9 @@ class Engine:
         capture they become parallel branches)."""
         self.lib = lib
         self.side = side_streams
+        # debugging aid: PRIORFLOW_FORKS is a bit mask of the forks to keep (2: the three chains of
+        # motion_inputs, 4: branch B's lookups, 8: the head tails; 1 is the encoders' fork in prior_raft.py)
+        self.forks = int(os.environ.get("PRIORFLOW_FORKS", "15")) if side_streams is not None else 0
 
     # ---- stage 0: view B images --------------------------------------------------------------
     def rotate_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
@@ -377,7 +380,7 @@ class Engine:
         """DCCL lookups (K3+K4; :185-188) + 1x1 + 3x3 of the motion encoders -> cat_a[0:128], cat_b[0:192].
         A looks into B through grid(R_A2B^T)==grid(R_B2A) and rotates back with grid(R_B2A); B the other way."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
-        if need_b and self.side is not None:
+        if need_b and self.forks & 4:
             # the two branches' lookups are independent gather chains: B's runs beside A's
             main, sb = torch.cuda.current_stream(), self.side[2]
             sb.wait_stream(main)
@@ -417,7 +420,7 @@ class Engine:
     def motion_inputs(self, ws: Workspace, P, need_b: bool):
         """Everything of an iteration up to (excluding) conv_A / conv: fills cat_a, cat_b and the flow
         tails of x_a, x_b from coords1 and the pyramids.  Three concurrent chains when side streams exist."""
-        if self.side is None:
+        if not self.forks & 2:
             self._flow_chain_head(ws)
             self._corr_chain(ws, P, need_b)
             self._flow_chain_tail(ws, P, need_b)
@@ -497,7 +500,7 @@ class Engine:
             d.append(P["a.m2"].desc(ws.mh_a, 0, 256, ws.mask_a, 0, EPI_LINEAR, scale=0.25))
         if mask_b and need_b:
             d.append(P["b.m2"].desc(ws.mh_b, 0, 256, ws.mask_b, 0, EPI_LINEAR, scale=0.25))
-        if self.side is not None and (need_b or d):
+        if self.forks & 8 and (need_b or d):
             # three independent tails of the heads: flow_out A | flow_out B | mask convs
             main = torch.cuda.current_stream()
             s1, s2 = self.side[0], self.side[1]

@@ -120,7 +120,7 @@ class PriOr_RAFT(nn.Module):
             ws.img_c[:B].copy_(image1); ws.img_c[B:].copy_(image1_b)
             ws.img_f[:B].copy_(image1); ws.img_f[B:2 * B].copy_(image2)
             ws.img_f[2 * B:3 * B].copy_(image1_b); ws.img_f[3 * B:].copy_(image2_b)
-            if self.use_streams:
+            if self.use_streams and int(os.environ.get("PRIORFLOW_FORKS", "15")) & 1:
                 # cnet and fnet are independent: fork them onto two side streams (the fork/join
                 # is captured into the HIP graph as parallel branches) so that the latency-bound
                 # kernels of one (stem, statistics) hide behind the other's convolutions

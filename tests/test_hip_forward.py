@@ -208,3 +208,27 @@ def test_streams_and_graph_are_bitwise_reproducible(params):
             m = build(True, graph)
             for _ in range(6):
                 assert torch.equal(m(i1, i2, iters=5, test_mode=True), ref), f"streams=True graph={graph}"
+
+
+@pytest.mark.parametrize("size", [(128, 256), (256, 512)])
+def test_graph_replays_are_bitwise_stable_at_small_sizes(params, size):
+    """Small maps leave most of the chip idle, so the parallel graph branches really do run side by side (at
+    512x1024 they mostly queue behind each other).  An experimental FlowHead kernel that was not reproducible
+    in exactly this setting differed in >90 % of replays here, so this is the sensitive
+    screen: every replay must equal the single-stream eager result bit for bit."""
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+
+    def build(streams, graph):
+        m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+        m.load_state_dict(params, strict=True)
+        m = m.cuda().eval()
+        m.use_streams, m.use_graph = streams, graph
+        return m
+
+    i1, i2 = gc.synthetic_pair(1, *size, seed=5)
+    i1, i2 = i1.cuda(), i2.cuda()
+    with torch.no_grad():
+        ref = build(False, False)(i1, i2, iters=12, test_mode=True).clone()
+        m = build(True, True)
+        bad = sum(int(not torch.equal(m(i1, i2, iters=12, test_mode=True), ref)) for _ in range(24))
+    assert bad == 0, f"{bad} of 24 graph replays differ from the single-stream result at {size}"
