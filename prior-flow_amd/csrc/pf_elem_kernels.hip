@@ -432,16 +432,26 @@ __global__ void __launch_bounds__(256, PF_FO_LB) pf_flow_out_strip(const PfFlowO
                 }
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
+#if defined(PF_FO_PAIRW)      // weights as [9][C][2]: (o=0, o=1) pairs per channel, no register shuffles for the packed ops
+                    w0[kx] = *reinterpret_cast<const float4*>(a.w + ((long)(ky * 3 + kx) * a.C + c) * 2);
+                    w1[kx] = *reinterpret_cast<const float4*>(a.w + ((long)(ky * 3 + kx) * a.C + c) * 2 + 4);
+#else
                     w0[kx] = *reinterpret_cast<const float4*>(a.w + (long)(ky * 3 + kx) * a.C + c);
                     w1[kx] = *reinterpret_cast<const float4*>(a.w + (long)(9 + ky * 3 + kx) * a.C + c);
+#endif
                 }
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const float4 q = v[p + kx];
+#if defined(PF_FO_PAIRW)
+                        s[2 * p] += q.x * w0[kx].x + q.y * w0[kx].z + q.z * w1[kx].x + q.w * w1[kx].z;
+                        s[2 * p + 1] += q.x * w0[kx].y + q.y * w0[kx].w + q.z * w1[kx].y + q.w * w1[kx].w;
+#else
                         s[2 * p] += q.x * w0[kx].x + q.y * w0[kx].y + q.z * w0[kx].z + q.w * w0[kx].w;
                         s[2 * p + 1] += q.x * w1[kx].x + q.y * w1[kx].y + q.z * w1[kx].z + q.w * w1[kx].w;
+#endif
                     }
 #if defined(PF_FO_DEBUG) && PF_FO_DEBUG > 1
                 if (g_fo_dbg && a.delta) {

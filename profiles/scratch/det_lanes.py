@@ -32,4 +32,5 @@ with torch.no_grad():
                 print(f"   strip {st}: xcc {x} se {(h >> 13) & 7} sh {(h >> 12) & 1} cu {(h >> 8) & 15} simd {(h >> 4) & 3} wave {h & 15} | lanes {lanes[0]}..{lanes[-1]} sums {js}")
             for st, lane, j in []:
                 print(f"   strip {st} (y {st // 8}, x0 {(st % 8) * 4}) lane {lane} sum j={j} (pixel +{j >> 1}, o={j & 1}): ref {float(ref_p[st, lane, j]):+.6f} now {float(dbg[st, lane, j]):+.6f}")
+print("wave slots of the strip waves in the last replay:", torch.bincount(ids[:, 0] & 15, minlength=8).tolist())
 print("done")

@@ -37,6 +37,8 @@ def body():
         lib.flow_prep(ws.c1a, None, ws.flow4_a, 0, ws.x_a, 252)
         main.wait_stream(s2)
     ws.c1a.zero_()
+    for _ in range(int(os.environ.get('PRELOAD', '0'))):      # keep the chip busy (clocks up) right before the pair
+        lib.conv2d([P['a.fh1'].desc(ws.net_a[0], 0, 128, ws.fh_b, 0, EPI_RELU), P['a.m0'].desc(ws.net_a[0], 0, 128, ws.mh_b, 0, EPI_RELU)], 1, ws.H8, ws.W8, ws.x_a)
     if os.environ.get('HEADS', '0') == '1':      # the 3x3 head stems that produce fh_a / mh_a, as in the model
         lib.conv2d([P['a.fh1'].desc(ws.net_a[0], 0, 128, ws.fh_a, 0, EPI_RELU), P['a.m0'].desc(ws.net_a[0], 0, 128, ws.mh_a, 0, EPI_RELU)], 1, ws.H8, ws.W8, ws.x_a)
     if co != "none":
@@ -56,6 +58,13 @@ with torch.cuda.stream(side):
 torch.cuda.current_stream().wait_stream(side)
 with torch.cuda.graph(graph):
     body()
+buf = None
+if hasattr(lib._dll, "pf_debug_set_flow_out"):
+    import ctypes
+    n = ws.H8 * ((ws.W8 + 3) // 4)
+    buf = torch.zeros(n * 64 * 8 + 2 * n, device="cuda")
+    lib._dll.pf_debug_set_flow_out.argtypes = [ctypes.c_void_p]
+    lib._dll.pf_debug_set_flow_out(buf.data_ptr())
 graph.replay(); torch.cuda.synchronize()
 ref = ws.delta_a.clone()
 bad = 0
@@ -63,4 +72,7 @@ runs = int(os.environ.get("RUNS", 400))
 for r in range(runs):
     graph.replay(); torch.cuda.synchronize()
     bad += int(not torch.equal(ws.delta_a, ref))
+if buf is not None:
+    ids = buf[n * 64 * 8:].view(torch.int32).view(n, 2)[:, 0]
+    print("wave slots of the strip waves in the last replay:", torch.bincount(ids & 15, minlength=8).tolist())
 print(f"co-runner {co} pre-fork {pre} {H}x{W}: {bad} of {runs} replays differ")
