@@ -153,6 +153,17 @@ int pf_conv2d_direct(const float* in, int ld_in, int off_in, int cin,
                      float* out, int ld_out, int off_out, int cout,
                      int kh, int kw, int relu, int B, int H8, int W8, void* stream);
 
+/* The same convolution for 1..4 independent problems of one shape in ONE launch (the motion encoders' 7x7
+ * stems of flow_A, flow_B_A and flow_B, core/update.py:187-188,:94, read three different 2-channel inputs).
+ * Outputs must not overlap. */
+typedef struct pf_direct_desc {
+    const float* in;  int ld_in, off_in;
+    const float* weight; const float* bias;
+    float* out;       int ld_out, off_out;
+} pf_direct_desc;
+int pf_conv2d_direct_group(const pf_direct_desc* descs, int n, int cin, int cout, int kh, int kw, int relu,
+                           int B, int H8, int W8, void* stream);
+
 /* Small-Cin convolution with stride 1|2 from channel-last or NCHW input (the encoders' 7x7/2 3->64
  * stem, core/extractor.py:112,144; same kernel family as pf_conv2d_direct).  Hout/Wout = OUTPUT map;
  * input map = stride x output.  nchw != 0: `in` is [B,cin,Hin,Win] planes (ld_in/off_in ignored). */

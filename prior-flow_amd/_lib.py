@@ -41,6 +41,12 @@ class ConvDesc(C.Structure):
     ]
 
 
+class DirectDesc(C.Structure):
+    """Mirror of ``pf_direct_desc`` (include/priorflow_hip.h)."""
+    _fields_ = [("in_", _fp), ("ld_in", _i), ("off_in", _i), ("weight", _fp), ("bias", _fp),
+                ("out", _fp), ("ld_out", _i), ("off_out", _i)]
+
+
 _SIGNATURES = {
     "pf_sample_grid": [_fp, _i, _i, C.POINTER(C.c_float), _fp],
     "pf_img_rotate": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
@@ -55,6 +61,7 @@ _SIGNATURES = {
     "pf_conv2d": [C.POINTER(ConvDesc), _i, _i, _i, _i, _fp],
     "pf_conv2d_tile": [C.POINTER(ConvDesc), _i, _i, _i, _i],
     "pf_conv2d_direct": [_fp, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
+    "pf_conv2d_direct_group": [C.POINTER(DirectDesc), _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_conv2d_small": [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_channel_stats": [_fp, _i, _i, _i, C.c_float, _fp, _fp, _fp, _i, _fp],
     "pf_channel_stats_final": [_fp, _i, _i, _i, _i, C.c_float, _fp, _fp, _fp],
@@ -237,6 +244,17 @@ class PfLib:
         self._rc(self._dll.pf_conv2d_direct(_ptr(x), x.shape[-1], off_in, cin, _ptr(weight), _ptr(bias),
                                             _ptr(out), out.shape[-1], off_out, cout, kh, kw, int(relu),
                                             B, H8, W8, self._stream(x)), "pf_conv2d_direct")
+
+    def conv2d_direct_group(self, problems, cin, cout, kh, kw, relu, B, H8, W8):
+        """problems: 1..4 tuples (x, off_in, weight, bias, out, off_out) of one shape -> one launch."""
+        arr = (DirectDesc * len(problems))()
+        for d, (x, off_in, weight, bias, out, off_out) in zip(arr, problems):
+            self._chk(x, weight, bias, out)
+            d.in_, d.ld_in, d.off_in = _ptr(x), x.shape[-1], off_in
+            d.weight, d.bias = _ptr(weight), _ptr(bias)
+            d.out, d.ld_out, d.off_out = _ptr(out), out.shape[-1], off_out
+        self._rc(self._dll.pf_conv2d_direct_group(arr, len(problems), cin, cout, kh, kw, int(relu), B, H8, W8,
+                                                  self._stream(problems[0][0])), "pf_conv2d_direct_group")
 
     def conv2d_small(self, x, nchw, off_in, cin, weight, bias, out, off_out, cout, kh, kw, stride, relu,
                      B, Hout, Wout):

@@ -84,8 +84,11 @@ struct PfSmallConvArgs {
 // segments), so the kernel is built to have one global round trip per phase: the patch is staged
 // by all 256 threads with 4 loads in flight each, and every wave prefetches ALL its weights
 // (one per lane per step, 128-byte coalesced rows) into registers before the first MFMA.
+// Up to 4 same-shape problems per launch (blockIdx.y): the motion encoders' three independent 7x7 flow stems.
+struct PfSmallConvMulti { PfSmallConvArgs p[4]; };
 template <int MAXS, int PMAX>
-__global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvArgs a) {
+__global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvMulti multi) {
+    const PfSmallConvArgs& a = multi.p[blockIdx.y];
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int K = a.KH * a.KW * a.Cin;
@@ -204,7 +207,8 @@ __global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvArgs 
     }
 }
 
-int launch_small_conv(const PfSmallConvArgs& a, void* stream) {
+int launch_small_conv(const PfSmallConvMulti& m, int n, void* stream) {
+    const PfSmallConvArgs& a = m.p[0];
     const int K = a.KH * a.KW * a.Cin, KS = (K + 1) / 2;
     const int PW = 31 * a.stride + a.KW;
     const int patch_elems = a.KH * PW * (a.Cin | 1);
@@ -215,16 +219,16 @@ int launch_small_conv(const PfSmallConvArgs& a, void* stream) {
     const long blocks = nitems < cap ? nitems : cap;
     const int spw = ((KS + 3) / 4);
     const int pmax = (a.KH * PW * a.Cin + 255) / 256;     // patch elements per thread
-    dim3 grid((unsigned)blocks), blk(256);
+    dim3 grid((unsigned)blocks, (unsigned)n), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (spw <= 16 && pmax <= 4)
-        hipLaunchKernelGGL((pf_small_conv_mfma<16, 4>), grid, blk, lds, st, a);
+        hipLaunchKernelGGL((pf_small_conv_mfma<16, 4>), grid, blk, lds, st, m);
     else if (spw <= 20 && pmax <= 8)
-        hipLaunchKernelGGL((pf_small_conv_mfma<20, 8>), grid, blk, lds, st, a);
+        hipLaunchKernelGGL((pf_small_conv_mfma<20, 8>), grid, blk, lds, st, m);
     else if (spw <= 40 && pmax <= 8)
-        hipLaunchKernelGGL((pf_small_conv_mfma<40, 8>), grid, blk, lds, st, a);
+        hipLaunchKernelGGL((pf_small_conv_mfma<40, 8>), grid, blk, lds, st, m);
     else if (spw <= 40 && pmax <= 16)
-        hipLaunchKernelGGL((pf_small_conv_mfma<40, 16>), grid, blk, lds, st, a);
+        hipLaunchKernelGGL((pf_small_conv_mfma<40, 16>), grid, blk, lds, st, m);
     else
         return PF_ERR_BAD_SHAPE;
     return (int)hipGetLastError();
@@ -640,21 +644,36 @@ extern "C" int pf_debug_set_flow_out(float* p) { return (int)hipMemcpyToSymbol(H
 #define PF_LAUNCH(name, args, total, stream) \
     pf_launch_elem<decltype(args), pf_##name##_elem>(args, total, stream)
 
-// device build: route pf_conv2d_direct to the MFMA small-Cin kernel when the shape allows
-static int pf_direct_conv_dispatch(const PfDirectConvArgs& d, long total, void* stream) {
+// device build: route pf_conv2d_direct[_group] to the MFMA small-Cin kernel when the shape allows
+// (the n problems of a group share every shape parameter; checked by the entry point)
+static int pf_direct_conv_dispatch_n(const PfDirectConvArgs* ds, int n, long total, void* stream) {
+    const PfDirectConvArgs& d = ds[0];
     const int K = d.KH * d.KW * d.Cin;
     const size_t lds = ((size_t)d.KH * (31 * d.stride + d.KW) * (d.Cin | 1) + 4 + 3 * 16 * 64) * 4;
     if (lds <= 60 * 1024 && (K + 1) / 2 <= 160 &&
         d.KH * (31 * d.stride + d.KW) * d.Cin <= 16 * 256 && d.Cin <= 255) {
-        PfSmallConvArgs a;
-        a.in = d.in; a.ld_in = d.ld_in; a.c_in_off = d.c_in_off; a.Cin = d.Cin; a.nchw = d.nchw;
-        a.w = d.w; a.bias = d.bias; a.out = d.out; a.ld_out = d.ld_out; a.c_out_off = d.c_out_off; a.Cout = d.Cout;
-        a.B = d.B; a.H = d.Hin; a.W = d.Win; a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.relu = d.relu;
-        a.Ho = d.H; a.Wo = d.W;
-        return launch_small_conv(a, stream);
+        PfSmallConvMulti m;
+        for (int i = 0; i < n; ++i) {
+            const PfDirectConvArgs& e = ds[i];
+            PfSmallConvArgs& a = m.p[i];
+            a.in = e.in; a.ld_in = e.ld_in; a.c_in_off = e.c_in_off; a.Cin = e.Cin; a.nchw = e.nchw;
+            a.w = e.w; a.bias = e.bias; a.out = e.out; a.ld_out = e.ld_out; a.c_out_off = e.c_out_off; a.Cout = e.Cout;
+            a.B = e.B; a.H = e.Hin; a.W = e.Win; a.KH = e.KH; a.KW = e.KW; a.stride = e.stride; a.relu = e.relu;
+            a.Ho = e.H; a.Wo = e.W;
+        }
+        for (int i = n; i < 4; ++i) m.p[i] = m.p[0];
+        return launch_small_conv(m, n, stream);
     }
-    return pf_launch_elem<PfDirectConvArgs, pf_direct_conv_elem>(d, total, stream);
+    for (int i = 0; i < n; ++i) {
+        const int rc = pf_launch_elem<PfDirectConvArgs, pf_direct_conv_elem>(ds[i], total, stream);
+        if (rc != PF_OK) return rc;
+    }
+    return PF_OK;
 }
+static int pf_direct_conv_dispatch(const PfDirectConvArgs& d, long total, void* stream) {
+    return pf_direct_conv_dispatch_n(&d, 1, total, stream);
+}
+#define PF_DIRECT_CONV_GROUP_LAUNCH(ds, n, total, stream) pf_direct_conv_dispatch_n(ds, n, total, stream)
 #define PF_DIRECT_CONV_LAUNCH(a, total, stream) pf_direct_conv_dispatch(a, total, stream)
 
 #include "pf_api_elem.inc"

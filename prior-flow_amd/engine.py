@@ -359,16 +359,17 @@ class Engine:
         """7x7 flow stems + 3x3 (core/update.py:187-191, :94-95) -> cat_a[128:256], cat_b[192:256]."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
 
-        def direct(dc: DirectConv, x, off_in, out, off_out):
-            lib.conv2d_direct(x, off_in, dc.cin, dc.w, dc.b, out, off_out, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
-
-        direct(P["a.f1a"], ws.flow4_a, 0, ws.t_a, 0)
-        direct(P["a.f1b"], ws.flow4_a, 2, ws.t_ba, 0)
+        # the 7x7 stems of flow_A, flow_B_A (and flow_B) are independent and of one shape: one launch
+        stems = [(P["a.f1a"], ws.flow4_a, 0, ws.t_a), (P["a.f1b"], ws.flow4_a, 2, ws.t_ba)]
         d = [P["a.f2a"].desc(ws.t_a, 0, 128, ws.cat_a, 128, EPI_RELU),
              P["a.f2b"].desc(ws.t_ba, 0, 128, ws.cat_a, 192, EPI_RELU)]
         if need_b:
-            direct(P["b.f1"], ws.flow2_b, 0, ws.t_b, 0)
+            stems.append((P["b.f1"], ws.flow2_b, 0, ws.t_b))
             d.append(P["b.f2"].desc(ws.t_b, 0, 128, ws.cat_b, 192, EPI_RELU))
+        dc = stems[0][0]
+        assert all((s[0].cin, s[0].cout, s[0].kh, s[0].kw) == (dc.cin, dc.cout, dc.kh, dc.kw) for s in stems)
+        lib.conv2d_direct_group([(x, off_in, c.w, c.b, out, 0) for c, x, off_in, out in stems],
+                                dc.cin, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
         lib.conv2d(d, B, H8, W8, ws.x_a)
 
     def _conf_chain(self, ws: Workspace, P):

@@ -13,6 +13,11 @@ static int pf_loop(const Args& a, long total) {
 }
 #define PF_LAUNCH(name, args, total, stream) pf_loop<decltype(args), pf_##name##_elem>(args, total)
 #define PF_DIRECT_CONV_LAUNCH(a, total, stream) pf_loop<PfDirectConvArgs, pf_direct_conv_elem>(a, total)
+static int pf_direct_group_loop(const PfDirectConvArgs* ds, int n, long total) {
+    for (int i = 0; i < n; ++i) pf_loop<PfDirectConvArgs, pf_direct_conv_elem>(ds[i], total);
+    return 0;
+}
+#define PF_DIRECT_CONV_GROUP_LAUNCH(ds, n, total, stream) pf_direct_group_loop(ds, n, total)
 
 // host statements of pf_seq_loss / pf_sum_squares (same chunk partition, sequential sums inside a chunk)
 static int emu_seq_loss(const PfSeqLossArgs& a, void*) {

@@ -245,6 +245,25 @@ def case_direct_conv(lib, dev, params):
     lib.conv2d_direct(x, 1, 2, wp.to(dev), b.to(dev), out, 2, 128, 7, 7, True, 1, H8, W8)
     check(uncl(out[:, 2:].cpu(), 1, H8, W8), want, 2e-5, "direct 7x7")
     assert float(out[:, :2].abs().max()) == 0.0
+    # the same stem for three inputs in ONE launch (pf_conv2d_direct_group): bit-identical to single launches
+    x4 = torch.zeros(N, 4, device=dev)
+    x4[:, :2] = cl(ui["flow_a"]).to(dev)
+    x4[:, 2:] = cl(ui["flow_a"].flip(1) * 0.5).to(dev)
+    x2 = cl(-ui["flow_a"]).to(dev).contiguous()
+    wts = [(wp * s).to(dev) for s in (1.0, 0.5, -1.0)]
+    outs = [torch.zeros(N, 128, device=dev) for _ in range(3)]
+    probs = [(x4, 0, wts[0], b.to(dev), outs[0], 0), (x4, 2, wts[1], b.to(dev), outs[1], 0),
+             (x2, 0, wts[2], b.to(dev), outs[2], 0)]
+    lib.conv2d_direct_group(probs, 2, 128, 7, 7, True, 1, H8, W8)
+    for i, (xi, off, wi, bi, _, _) in enumerate(probs):
+        single = torch.zeros(N, 128, device=dev)
+        lib.conv2d_direct(xi, off, 2, wi, bi, single, 0, 128, 7, 7, True, 1, H8, W8)
+        assert torch.equal(single, outs[i]), f"direct group problem {i}"
+    check(uncl(outs[0].cpu(), 1, H8, W8), want, 2e-5, "direct 7x7 group[0]")
+    import pytest
+    from prior_flow_amd._lib import PfError
+    with pytest.raises(PfError):                          # overlapping outputs in one group are refused
+        lib.conv2d_direct_group([probs[0], (x2, 0, wts[2], b.to(dev), outs[0], 0)], 2, 128, 7, 7, True, 1, H8, W8)
     # 3x3 8->32 relu -> 3x3 32->16 relu (confidence stem)
     w1, b1 = params["ODDC.encoder.conv_conf1.weight"], params["ODDC.encoder.conv_conf1.bias"]
     w2, b2 = params["ODDC.encoder.conv_conf2.weight"], params["ODDC.encoder.conv_conf2.bias"]
