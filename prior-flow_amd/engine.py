@@ -193,10 +193,7 @@ def pack_update_blocks(oddc, upd, precision: Optional[int] = None) -> Dict[str, 
         P[f"{tag}.fh1"] = C(blk.flow_head.conv1)
         P[f"{tag}.fh2"] = C(blk.flow_head.conv2)
         w2 = blk.flow_head.conv2.weight.detach().float()          # [2,256,3,3] -> [2][9][256]
-        if os.environ.get("PRIORFLOW_FO_PAIRW") == "1":      # experiment: layout of the -DPF_FO_PAIRW diag build
-            P[f"{tag}.fh2w"] = w2.permute(2, 3, 1, 0).reshape(9, w2.shape[1], 2).contiguous()
-        else:
-            P[f"{tag}.fh2w"] = w2.permute(0, 2, 3, 1).reshape(2, 9, w2.shape[1]).contiguous()
+        P[f"{tag}.fh2w"] = w2.permute(0, 2, 3, 1).reshape(2, 9, w2.shape[1]).contiguous()
         P[f"{tag}.fh2b"] = blk.flow_head.conv2.bias.detach().float().contiguous()
         P[f"{tag}.m0"] = C(blk.mask[0])
         P[f"{tag}.m2"] = C(blk.mask[2])

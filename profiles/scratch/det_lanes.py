@@ -1,4 +1,4 @@
-"""Per-lane partial sums of pf_flow_out_strip inside the captured graph: which lanes deviate in a bad replay?"""
+"""[needs the -DPF_FO_DEBUG hooks of pf_flow_out_strip as of commit 6e5c0fe; the shipped kernel has none] Per-lane partial sums of pf_flow_out_strip inside the captured graph: which lanes deviate in a bad replay?"""
 import argparse, ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -1,4 +1,4 @@
-"""Per-lane, per-kernel-row state of pf_flow_out_strip inside the captured graph (diag build -DPF_FO_DEBUG=2)."""
+"""[needs the -DPF_FO_DEBUG hooks of pf_flow_out_strip as of commit 6e5c0fe; the shipped kernel has none] Per-lane, per-kernel-row state of pf_flow_out_strip inside the captured graph (diag build -DPF_FO_DEBUG=2)."""
 import argparse, ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
