@@ -8,6 +8,7 @@ $B -DPK_KIND=1 -o /tmp/pkm/bcast &
 $B -DPK_KIND=2 -o /tmp/pkm/plain &
 $B -DPK_KIND=3 -fno-slp-vectorize -o /tmp/pkm/scalar &
 $B -DPK_KIND=4 -fno-slp-vectorize -o /tmp/pkm/dpp &
+$B -DPK_KIND=5 -fno-slp-vectorize -o /tmp/pkm/wide &
 $B -DPK_KIND=0 -DMFMA_KIND=1 -o /tmp/pkm/swap_f32mfma &
 $B -DPK_KIND=0 -DMFMA_KIND=2 -o /tmp/pkm/swap_valu &
 $B -DPK_KIND=0 -DBURST=0 -o /tmp/pkm/swap_continuous &
@@ -15,6 +16,6 @@ $B -DPK_KIND=0 -DBURST=1 -o /tmp/pkm/swap_burst1 &
 $B -DPK_KIND=0 -DBURST=40 -o /tmp/pkm/swap_burst40 &
 wait
 rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id"
-for v in swap bcast plain scalar dpp swap_f32mfma swap_valu swap_continuous swap_burst1 swap_burst40; do
+for v in swap bcast plain scalar dpp wide swap_f32mfma swap_valu swap_continuous swap_burst1 swap_burst40; do
   timeout 300 /tmp/pkm/$v 2048 200 50 | tail -2
 done
