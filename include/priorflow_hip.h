@@ -262,6 +262,17 @@ int pf_warp_gcorr_bwd(const float* f1, const float* f2, const float* coords, int
 int pf_upsample_flow_bwd(const float* coords1, const float* mask, int ld, const float* g, float* d_mask, int ld_d,
                          float* d_flow, int B, int H8, int W8, void* stream);
 
+/* SepConvGRU gate backward of one half-step (core/update.py:46-60), channel-last rows with leading dimensions.
+ * Stage Q, before the data gradient of convq:  dq_pre = dh'*z*(1-q^2), dz = dh'*q - dh'*h, dh = dh'*(1-z).
+ * Stage ZR, after it (d_rh = gradient of r*h, the first C input channels of convq):
+ * dzr_pre[:, :C] = dz*(1-z)*z, dzr_pre[:, C:2C] = d_rh*h*(1-r)*r (the [z|r] gradient of the fused conv), dh += d_rh*r. */
+int pf_gru_q_bwd(const float* dh_new, int ld_dhn, const float* z, int ld_z, const float* q, int ld_q,
+                 const float* h, int ld_h, float* dq_pre, int ld_dq, float* dz, int ld_dz,
+                 float* dh, int ld_dh, long rows, int C, void* stream);
+int pf_gru_zr_bwd(const float* dz, int ld_dz, const float* d_rh, int ld_drh, const float* z, int ld_z,
+                  const float* r, int ld_r, const float* h, int ld_h, float* dzr_pre, int ld_dzr,
+                  float* dh, int ld_dh, long rows, int C, void* stream);
+
 /* Backward of build_pyramid (core/corr.py:99-111): level gradients g0..g3 ([B*N][H_i*W_i]) -> the dense volume
  * gradient, written in place into g0 (avg_pool2d backward with floor semantics for odd sizes). */
 int pf_pyramid_bwd(float* g0, const float* g1, const float* g2, const float* g3, int B, int H8, int W8, void* stream);

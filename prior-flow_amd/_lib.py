@@ -75,6 +75,8 @@ _SIGNATURES = {
     "pf_warp_gcorr_bwd": [_fp, _fp, _fp, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow_bwd": [_fp, _fp, _i, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_pyramid_bwd": [_fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pf_gru_q_bwd": [_fp, _i] * 7 + [C.c_long, _i, _fp],
+    "pf_gru_zr_bwd": [_fp, _i] * 7 + [C.c_long, _i, _fp],
     "pf_dccl_combine_bwd": [_fp, _i, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_dccl_lookup_bwd": [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pf_conv2d_wgrad": [_fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp],
@@ -136,6 +138,14 @@ class PfLib:
                 continue
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise PfError(f"expected contiguous fp32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+            if self.require_cuda and not t.is_cuda:
+                raise PfError("the HIP path needs tensors on a cuda (ROCm) device; there is no CPU fallback")
+
+    def _chk_rows(self, *tensors: torch.Tensor):
+        """2-D fp32 row views: unit stride along the channels, any leading dimension (column slices are fine)."""
+        for t in tensors:
+            if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+                raise PfError(f"expected a 2-D fp32 view with unit channel stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
             if self.require_cuda and not t.is_cuda:
                 raise PfError("the HIP path needs tensors on a cuda (ROCm) device; there is no CPU fallback")
 
@@ -347,6 +357,24 @@ class PfLib:
         self._rc(self._dll.pf_pyramid_bwd(*[_ptr(t) for t in g_levels], B, H8, W8, self._stream(g_levels[0])),
                  "pf_pyramid_bwd")
         return g_levels[0]
+
+    def gru_q_bwd(self, dh_new, z, q, h, dq_pre, dz, dh):
+        """Stage Q of the GRU gate backward; every argument a channel-last [rows, >=C] view (C = dh_new.shape[-1])."""
+        self._chk_rows(dh_new, z, q, h, dq_pre, dz, dh)
+        rows, Cc = dh_new.shape
+        args = []
+        for t in (dh_new, z, q, h, dq_pre, dz, dh):
+            args += [_ptr(t), t.stride(0)]
+        self._rc(self._dll.pf_gru_q_bwd(*args, rows, Cc, self._stream(dh_new)), "pf_gru_q_bwd")
+
+    def gru_zr_bwd(self, dz, d_rh, z, r, h, dzr_pre, dh):
+        """Stage ZR; dzr_pre is [rows, >=2C] (z half | r half), dh is accumulated."""
+        self._chk_rows(dz, d_rh, z, r, h, dzr_pre, dh)
+        rows, Cc = dz.shape
+        args = []
+        for t in (dz, d_rh, z, r, h, dzr_pre, dh):
+            args += [_ptr(t), t.stride(0)]
+        self._rc(self._dll.pf_gru_zr_bwd(*args, rows, Cc, self._stream(dz)), "pf_gru_zr_bwd")
 
     def dccl_combine_bwd(self, d_corr, g_back, d_raw, B, H8, W8):
         self._chk(d_corr, g_back, d_raw)

@@ -386,6 +386,40 @@ PF_HD void pf_combine_bwd_elem(long idx, const PfCombineBwdArgs& a) {   // idx o
     for (int j = 0; j < 4; ++j)
         if (t.w[j] != 0.f) PF_ATOMIC_ADD(base + (long)t.idx[j] * a.ld, g * t.w[j]);
 }
+// ----------------------------------------------------------------------------------------------
+// SepConvGRU gate backward (core/update.py:46-60; one half-step):
+//   z = sigmoid(az), r = sigmoid(ar), q = tanh(aq(cat[r*h, x])), h' = (1 - z) * h + z * q
+// stage Q  (before the dgrad of convq):  dq_pre = dh' * z * (1 - q^2),  dz = dh' * q - dh' * h,  dh = dh' * (1 - z)
+// stage ZR (after it, d_rh = gradient of r*h): dz_pre = dz * (1 - z) * z,  dr_pre = (d_rh * h) * (1 - r) * r,
+//                                              dh += d_rh * r
+// (the products are written in the order of torch's sigmoid_backward / tanh_backward / mul backward).
+// dzr_pre is the [z | r] gradient of the fused z|r convolution (columns 0..C-1 and C..2C-1).
+// ----------------------------------------------------------------------------------------------
+struct PfGruQBwdArgs {
+    const float* dhn; const float* z; const float* q; const float* h;
+    float* dq_pre; float* dz; float* dh;
+    int ld_dhn, ld_z, ld_q, ld_h, ld_dq, ld_dz, ld_dh, C;
+};
+PF_HD void pf_gru_q_bwd_elem(long idx, const PfGruQBwdArgs& a) {          // idx over rows*C
+    const long row = idx / a.C; const int c = (int)(idx % a.C);
+    const float g = a.dhn[row * a.ld_dhn + c], z = a.z[row * a.ld_z + c], q = a.q[row * a.ld_q + c], h = a.h[row * a.ld_h + c];
+    a.dq_pre[row * a.ld_dq + c] = (g * z) * (1.f - q * q);
+    a.dz[row * a.ld_dz + c] = g * q - g * h;
+    a.dh[row * a.ld_dh + c] = g * (1.f - z);
+}
+struct PfGruZrBwdArgs {
+    const float* dz; const float* d_rh; const float* z; const float* r; const float* h;
+    float* dzr_pre; float* dh;
+    int ld_dz, ld_drh, ld_z, ld_r, ld_h, ld_dzr, ld_dh, C;
+};
+PF_HD void pf_gru_zr_bwd_elem(long idx, const PfGruZrBwdArgs& a) {        // idx over rows*C
+    const long row = idx / a.C; const int c = (int)(idx % a.C);
+    const float dz = a.dz[row * a.ld_dz + c], drh = a.d_rh[row * a.ld_drh + c];
+    const float z = a.z[row * a.ld_z + c], r = a.r[row * a.ld_r + c], h = a.h[row * a.ld_h + c];
+    a.dzr_pre[row * a.ld_dzr + c] = (dz * (1.f - z)) * z;
+    a.dzr_pre[row * a.ld_dzr + a.C + c] = ((drh * h) * (1.f - r)) * r;
+    a.dh[row * a.ld_dh + c] = a.dh[row * a.ld_dh + c] + drh * r;
+}
 struct PfLookupBwdArgs {
     const float* coords;                  // planar [B,2,N]
     const float* g_w2c;                   // [2,N]

@@ -517,9 +517,39 @@ def case_training_pieces(lib, dev):
     check(v, wv, 1e-7, "adamw exp_avg_sq")
 
 
+def case_gru_gate_backward(lib, dev):
+    """pf_gru_q_bwd / pf_gru_zr_bwd against torch autograd of the SepConvGRU gate math (core/update.py:46-60);
+    the convolutions are replaced by free tensors, so only the gate arithmetic is differentiated."""
+    rows, Cc = 200, 128
+    g = lambda name, lo=-2.0, hi=2.0: gc.uni(f"grubwd/{name}", (rows, Cc), lo, hi)    # noqa: E731
+    az, ar, aq_lin, h, dhn = g("az"), g("ar"), g("aq"), g("h", -1, 1), g("dhn", -1, 1)
+    az, ar, aq_lin, h = (t.clone().requires_grad_(True) for t in (az, ar, aq_lin, h))
+    z, r = torch.sigmoid(az), torch.sigmoid(ar)
+    rh = r * h
+    rh.retain_grad()
+    q = torch.tanh(aq_lin + 0.5 * rh)                      # stand-in for convq(cat[r*h, x]): d_rh = 0.5 * dq_pre
+    hn = (1 - z) * h + z * q
+    hn.backward(dhn)
+    # HIP / emu: stage Q, the "data gradient of convq" (here 0.5 * dq_pre), stage ZR
+    d = lambda t: t.detach().to(dev).contiguous()          # noqa: E731
+    zz, rr, qq, hh = d(z), d(r), d(q), d(h)
+    wide = torch.zeros(rows, 3 * Cc, device=dev)           # column slices exercise the leading dimensions
+    dq_pre, dz, dh = wide[:, :Cc], wide[:, Cc:2 * Cc], wide[:, 2 * Cc:]
+    lib.gru_q_bwd(d(dhn), zz, qq, hh, dq_pre, dz, dh)
+    check(dq_pre.cpu(), aq_lin.grad, 2e-6, "gru dq_pre")
+    d_rh = (0.5 * dq_pre).contiguous()
+    check(d_rh.cpu(), rh.grad, 2e-6, "gru d_rh (stand-in conv)")
+    dzr = torch.zeros(rows, 2 * Cc + 8, device=dev)
+    lib.gru_zr_bwd(dz, d_rh, zz, rr, hh, dzr, dh)
+    check(dzr[:, :Cc].cpu(), az.grad, 2e-6, "gru dz_pre")
+    check(dzr[:, Cc:2 * Cc].cpu(), ar.grad, 2e-6, "gru dr_pre")
+    check(dh.cpu(), h.grad, 2e-6, "gru dh")
+    assert float(dzr[:, 2 * Cc:].abs().max()) == 0.0
+
+
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
                      case_flow_metrics, case_training_pieces, case_dccl_backward, case_upsample_backward,
-                     case_warp_gcorr_backward,
+                     case_warp_gcorr_backward, case_gru_gate_backward,
                      case_bad_args]

@@ -200,6 +200,60 @@ class HipWarpGcorr(torch.autograd.Function):
         return _nchw(d1, B, H, W), _nchw(d2, B, H, W), None
 
 
+class HipGruGates(torch.autograd.Function):
+    """z = sigmoid(az), r = sigmoid(ar), rh = r * h (core/update.py:49-51, :56-58); backward = pf_gru_zr_bwd."""
+
+    @staticmethod
+    def forward(ctx, az, ar, h):
+        z, r = torch.sigmoid(az), torch.sigmoid(ar)
+        ctx.save_for_backward(_rows(z), _rows(r), _rows(h))
+        ctx.shape = az.shape
+        return z, r * h
+
+    @staticmethod
+    def backward(ctx, dz, d_rh):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        z, r, h = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        dzr = torch.empty(B * H * W, 2 * Cc, device=dz.device)
+        dh = torch.zeros(B * H * W, Cc, device=dz.device)
+        lib.gru_zr_bwd(_rows(dz), _rows(d_rh), z, r, h, dzr, dh)
+        STATS["hip"] += 1
+        return _nchw(dzr[:, :Cc].contiguous(), B, H, W), _nchw(dzr[:, Cc:].contiguous(), B, H, W), _nchw(dh, B, H, W)
+
+
+class HipGruBlend(torch.autograd.Function):
+    """q = tanh(aq), h' = (1 - z) * h + z * q (core/update.py:52-53, :59-60); backward = pf_gru_q_bwd."""
+
+    @staticmethod
+    def forward(ctx, z, aq, h):
+        q = torch.tanh(aq)
+        ctx.save_for_backward(_rows(z), _rows(q), _rows(h))
+        ctx.shape = z.shape
+        return (1 - z) * h + z * q
+
+    @staticmethod
+    def backward(ctx, g):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        z, q, h = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        dq_pre, dz, dh = (torch.empty(B * H * W, Cc, device=g.device) for _ in range(3))
+        lib.gru_q_bwd(_rows(g), z, q, h, dq_pre, dz, dh)
+        STATS["hip"] += 1
+        return _nchw(dz, B, H, W), _nchw(dq_pre, B, H, W), _nchw(dh, B, H, W)
+
+
+def hip_sepconv_gru(p, pre, h, x):
+    """oracle sepconv_gru with the gate arithmetic's backward on the HIP kernels (the convs go through po._conv)."""
+    for tag, pad in (("1", (0, 2)), ("2", (2, 0))):
+        hx = torch.cat([h, x], 1)
+        z, rh = HipGruGates.apply(po._conv(p, pre + "convz" + tag, hx, pad), po._conv(p, pre + "convr" + tag, hx, pad), h)
+        h = HipGruBlend.apply(z, po._conv(p, pre + "convq" + tag, torch.cat([rh, x], 1), pad), h)
+    return h
+
+
 def hip_conv2d(x, w, b=None, stride=1, padding=0, **kw):
     kh, kwid = w.shape[2], w.shape[3]
     pad = (padding, padding) if isinstance(padding, int) else tuple(padding)
@@ -235,6 +289,7 @@ def test_training_step_with_hip_conv_forward_and_backward(monkeypatch):
         out = HipDccl.apply(coords, g_w2c, g_back, *pyr_own, *pyr_other)
         return out, torch.zeros_like(out)
     monkeypatch.setattr(po, "dccl_lookup", hip_dccl)
+    monkeypatch.setattr(po, "sepconv_gru", hip_sepconv_gru)
     monkeypatch.setattr(po, "upsample_flow", lambda flow, mask: HipUpsample.apply(flow, mask))
     monkeypatch.setattr(po, "warp_groupwise_corr", lambda f1, f2, coords, groups=4: HipWarpGcorr.apply(f1, f2, coords))
     STATS["hip"] = STATS["torch"] = 0
