@@ -262,6 +262,14 @@ int pf_warp_gcorr_bwd(const float* f1, const float* f2, const float* coords, int
 int pf_upsample_flow_bwd(const float* coords1, const float* mask, int ld, const float* g, float* d_mask, int ld_d,
                          float* d_flow, int B, int H8, int W8, void* stream);
 
+/* Backward of y = act(x * scale[b,c] + shift[b,c]) on channel-last rows [B*Np][C] (the encoders' norm + ReLU,
+ * core/extractor.py:112-147; scale / shift as produced by pf_channel_stats or the folded BatchNorm affine).
+ * relu != 0: dy is masked where x*scale+shift <= 0.  instance != 0: InstanceNorm backward,
+ * dx = scale * (g - mean(g) - xh * mean(g*xh)) with deterministic fp64 sums through `partials` ([B][nblk][C][2]
+ * doubles) and `coef` ([B][C][2] floats); instance == 0: fixed statistics (BatchNorm eval), dx = scale * g. */
+int pf_norm_bwd(const float* dy, const float* x, const float* scale, const float* shift, int relu, int instance,
+                double* partials, int nblk, float* coef, float* dx, int B, int Np, int C, void* stream);
+
 /* SepConvGRU gate backward of one half-step (core/update.py:46-60), channel-last rows with leading dimensions.
  * Stage Q, before the data gradient of convq:  dq_pre = dh'*z*(1-q^2), dz = dh'*q - dh'*h, dh = dh'*(1-z).
  * Stage ZR, after it (d_rh = gradient of r*h, the first C input channels of convq):

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "pf_warp_gcorr_bwd": [_fp, _fp, _fp, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow_bwd": [_fp, _fp, _i, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_pyramid_bwd": [_fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pf_norm_bwd": [_fp, _fp, _fp, _fp, _i, _i, _fp, _i, _fp, _fp, _i, _i, _i, _fp],
     "pf_gru_q_bwd": [_fp, _i] * 7 + [C.c_long, _i, _fp],
     "pf_gru_zr_bwd": [_fp, _i] * 7 + [C.c_long, _i, _fp],
     "pf_dccl_combine_bwd": [_fp, _i, _fp, _fp, _i, _i, _i, _i, _fp],
@@ -357,6 +358,18 @@ class PfLib:
         self._rc(self._dll.pf_pyramid_bwd(*[_ptr(t) for t in g_levels], B, H8, W8, self._stream(g_levels[0])),
                  "pf_pyramid_bwd")
         return g_levels[0]
+
+    def norm_bwd(self, dy, x, scale, shift, relu, instance, dx, B, Np, Cc, nblk=None):
+        """Backward of act(x*scale+shift) (InstanceNorm when `instance`, else fixed statistics); rows [B*Np, C]."""
+        self._chk(dy, x, scale, shift, dx)
+        part = coef = None
+        if instance:
+            nblk = nblk or max(1, min(Np, Np // 64))
+            part = torch.empty(B * nblk * Cc * 2, dtype=torch.float64, device=dy.device)
+            coef = torch.empty(B * Cc * 2, dtype=torch.float32, device=dy.device)
+        self._rc(self._dll.pf_norm_bwd(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), int(relu), int(instance),
+                                       _ptr(part), nblk or 0, _ptr(coef), _ptr(dx), B, Np, Cc, self._stream(dy)),
+                 "pf_norm_bwd")
 
     def gru_q_bwd(self, dh_new, z, q, h, dq_pre, dz, dh):
         """Stage Q of the GRU gate backward; every argument a channel-last [rows, >=C] view (C = dh_new.shape[-1])."""

@@ -420,6 +420,60 @@ PF_HD void pf_gru_zr_bwd_elem(long idx, const PfGruZrBwdArgs& a) {        // idx
     a.dzr_pre[row * a.ld_dzr + a.C + c] = ((drh * h) * (1.f - r)) * r;
     a.dh[row * a.ld_dh + c] = a.dh[row * a.ld_dh + c] + drh * r;
 }
+// ----------------------------------------------------------------------------------------------
+// Backward of  y = act(x * s[b,c] + t[b,c])  over channel-last rows [B*Np][C] (core/extractor.py:112-147):
+// s, t are the scale / shift of pf_channel_stats (InstanceNorm: s = rstd, t = -mean * rstd) or the folded
+// BatchNorm(eval) affine.  With xh = x*s + t and g = dy masked by the ReLU (xh > 0):
+//   InstanceNorm:     dx = s * (g - mean_p(g) - xh * mean_p(g * xh))      (mean over the Np pixels of (b, c))
+//   BatchNorm (eval): dx = s * g
+// Three elementwise passes for InstanceNorm: partial sums over pixel chunks (fp64, fixed order), their
+// reduction to the two means, the apply pass.
+// ----------------------------------------------------------------------------------------------
+struct PfNormBwdArgs {
+    const float* dy; const float* x; const float* s; const float* t;
+    double* part;          // [B][nblk][C][2]
+    float* coef;           // [B][C][2]: mean(g), mean(g*xh)
+    float* dx;
+    int B, Np, C, nblk, relu, instance;
+};
+PF_HD void pf_norm_bwd_partial_elem(long idx, const PfNormBwdArgs& a) {     // idx over B*nblk*C
+    const int c = (int)(idx % a.C);
+    const long r = idx / a.C;
+    const int blk = (int)(r % a.nblk); const long b = r / a.nblk;
+    const int chunk = (a.Np + a.nblk - 1) / a.nblk;
+    const int p0 = blk * chunk, p1 = (p0 + chunk < a.Np) ? p0 + chunk : a.Np;
+    const float s = a.s[b * a.C + c], t = a.t[b * a.C + c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = p0; p < p1; ++p) {
+        const long e = (b * a.Np + p) * a.C + c;
+        const float xh = a.x[e] * s + t;
+        const float g = (a.relu && !(xh > 0.f)) ? 0.f : a.dy[e];
+        s1 += (double)g; s2 += (double)g * (double)xh;
+    }
+    a.part[idx * 2] = s1; a.part[idx * 2 + 1] = s2;
+}
+PF_HD void pf_norm_bwd_final_elem(long idx, const PfNormBwdArgs& a) {       // idx over B*C
+    const int c = (int)(idx % a.C); const long b = idx / a.C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < a.nblk; ++k) {
+        const double* q = a.part + ((b * a.nblk + k) * a.C + c) * 2;
+        s1 += q[0]; s2 += q[1];
+    }
+    a.coef[idx * 2] = (float)(s1 / (double)a.Np); a.coef[idx * 2 + 1] = (float)(s2 / (double)a.Np);
+}
+PF_HD void pf_norm_bwd_apply_elem(long idx, const PfNormBwdArgs& a) {       // idx over B*Np*C
+    const int c = (int)(idx % a.C);
+    const long b = idx / ((long)a.Np * a.C);
+    const float s = a.s[b * a.C + c], t = a.t[b * a.C + c];
+    const float xh = a.x[idx] * s + t;
+    const float g = (a.relu && !(xh > 0.f)) ? 0.f : a.dy[idx];
+    if (a.instance) {
+        const float m1 = a.coef[(b * a.C + c) * 2], m2 = a.coef[(b * a.C + c) * 2 + 1];
+        a.dx[idx] = s * ((g - m1) - xh * m2);
+    } else {
+        a.dx[idx] = s * g;
+    }
+}
 struct PfLookupBwdArgs {
     const float* coords;                  // planar [B,2,N]
     const float* g_w2c;                   // [2,N]

@@ -547,9 +547,33 @@ def case_gru_gate_backward(lib, dev):
     assert float(dzr[:, 2 * Cc:].abs().max()) == 0.0
 
 
+def case_norm_backward(lib, dev):
+    """pf_norm_bwd against autograd of relu(instance_norm(x)) (fnet, core/extractor.py:112-113) and of the folded
+    BatchNorm(eval) affine + relu (cnet)."""
+    B, Cc, H, W = 2, 64, 12, 20
+    Np = H * W
+    x = gc.uni("normbwd/x", (B, Cc, H, W), -2, 2).requires_grad_(True)
+    dy = gc.uni("normbwd/dy", (B, Cc, H, W), -1, 1)
+    torch.relu(torch.nn.functional.instance_norm(x, eps=1e-5)).backward(dy)
+    xr = cl(x.detach()).to(dev).contiguous()
+    scale = torch.empty(B, Cc, device=dev); shift = torch.empty(B, Cc, device=dev)
+    part = torch.empty(B * 4 * Cc * 2, dtype=torch.float64, device=dev)
+    lib.channel_stats(xr, B, Np, Cc, scale, shift, part, 4)
+    dx = torch.empty_like(xr)
+    lib.norm_bwd(cl(dy).to(dev).contiguous(), xr, scale, shift, True, True, dx, B, Np, Cc, nblk=7)
+    check(uncl(dx.cpu(), B, H, W), x.grad, 2e-5, "instance norm + relu backward")
+    # fixed statistics
+    s = gc.uni("normbwd/s", (Cc,), 0.5, 1.5); t = gc.uni("normbwd/t", (Cc,), -0.5, 0.5)
+    x2 = x.detach().clone().requires_grad_(True)
+    torch.relu(x2 * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)).backward(dy)
+    sc = s.view(1, -1).expand(B, Cc).contiguous().to(dev); sh = t.view(1, -1).expand(B, Cc).contiguous().to(dev)
+    lib.norm_bwd(cl(dy).to(dev).contiguous(), xr, sc, sh, True, False, dx, B, Np, Cc)
+    check(uncl(dx.cpu(), B, H, W), x2.grad, 1e-6, "affine + relu backward")
+
+
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
                      case_flow_metrics, case_training_pieces, case_dccl_backward, case_upsample_backward,
-                     case_warp_gcorr_backward, case_gru_gate_backward,
+                     case_warp_gcorr_backward, case_gru_gate_backward, case_norm_backward,
                      case_bad_args]

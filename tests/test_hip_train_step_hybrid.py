@@ -245,6 +245,30 @@ class HipGruBlend(torch.autograd.Function):
         return _nchw(dz, B, H, W), _nchw(dq_pre, B, H, W), _nchw(dh, B, H, W)
 
 
+class HipInstanceNorm(torch.autograd.Function):
+    """nn.InstanceNorm2d of fnet (core/extractor.py:112-113): forward as the oracle writes it, backward = pf_norm_bwd."""
+
+    @staticmethod
+    def forward(ctx, x):
+        mu = x.mean(dim=(2, 3), keepdim=True)
+        rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3), unbiased=False, keepdim=True) + 1e-5)
+        B, Cc = x.shape[:2]
+        ctx.save_for_backward(_rows(x), rstd.reshape(B, Cc).contiguous(), (-mu * rstd).reshape(B, Cc).contiguous())
+        ctx.shape = x.shape
+        return (x - mu) * rstd
+
+    @staticmethod
+    def backward(ctx, g):
+        from prior_flow_amd import _lib
+        lib = _lib.load()
+        xr, scale, shift = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        dx = torch.empty_like(xr)
+        lib.norm_bwd(_rows(g), xr, scale, shift, False, True, dx, B, H * W, Cc)
+        STATS["hip"] += 1
+        return _nchw(dx, B, H, W)
+
+
 def hip_sepconv_gru(p, pre, h, x):
     """oracle sepconv_gru with the gate arithmetic's backward on the HIP kernels (the convs go through po._conv)."""
     for tag, pad in (("1", (0, 2)), ("2", (2, 0))):
@@ -290,6 +314,8 @@ def test_training_step_with_hip_conv_forward_and_backward(monkeypatch):
         return out, torch.zeros_like(out)
     monkeypatch.setattr(po, "dccl_lookup", hip_dccl)
     monkeypatch.setattr(po, "sepconv_gru", hip_sepconv_gru)
+    oracle_norm = po._norm
+    monkeypatch.setattr(po, "_norm", lambda p, name, x, kind: HipInstanceNorm.apply(x) if kind == "instance" else oracle_norm(p, name, x, kind))
     monkeypatch.setattr(po, "upsample_flow", lambda flow, mask: HipUpsample.apply(flow, mask))
     monkeypatch.setattr(po, "warp_groupwise_corr", lambda f1, f2, coords, groups=4: HipWarpGcorr.apply(f1, f2, coords))
     STATS["hip"] = STATS["torch"] = 0
