@@ -284,6 +284,7 @@ class Engine:
         # debugging aid: PRIORFLOW_FORKS is a bit mask of the forks to keep (2: the three chains of
         # motion_inputs, 4: branch B's lookups, 8: the head tails; 1 is the encoders' fork in prior_raft.py)
         self.forks = int(os.environ.get("PRIORFLOW_FORKS", "15")) if side_streams is not None else 0
+        self._b_pending = None      # event after branch B's deferred FlowHead tail (see iteration())
 
     # ---- stage 0: view B images --------------------------------------------------------------
     def rotate_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
@@ -336,12 +337,23 @@ class Engine:
 
     # ---- one refinement iteration (core/prior_raft.py:170-211) --------------------------------
     def iteration(self, ws: Workspace, P: Dict[str, object], cur: int, need_b: bool, mask_a: bool,
-                  mask_b: bool) -> int:
+                  mask_b: bool, defer_b_join: bool = False) -> int:
         """Runs one iteration; hidden states are read from net_x[cur] and end in net_x[cur]
         (two GRU half-steps ping-pong).  need_b=False skips branch B's update (its result is
-        dead in the last test_mode iteration); mask_x selects the mask heads."""
+        dead in the last test_mode iteration); mask_x selects the mask heads.
+        defer_b_join: another iteration follows and nothing on the calling stream reads branch B's coords
+        before it: branch B's FlowHead tail is then not joined here but awaited by its consumers in the next
+        motion_inputs() (saves one cross-queue dependency hop, ~8 us, at every iteration boundary)."""
         self.motion_inputs(ws, P, need_b)
-        return self.update_blocks(ws, P, cur, need_b, mask_a, mask_b, inputs_ready=True)   # incl. coords1 += delta
+        return self.update_blocks(ws, P, cur, need_b, mask_a, mask_b, inputs_ready=True,
+                                  defer_b_join=defer_b_join)   # incl. coords1 += delta
+
+    def _await_b(self, stream, keep: bool = False):
+        """Make `stream` wait for branch B's deferred FlowHead tail of the previous iteration, if any."""
+        if self._b_pending is not None:
+            stream.wait_event(self._b_pending)
+            if not keep:
+                self._b_pending = None
 
     # -- the three independent chains of an iteration ---------------------------------------------
     def _flow_chain_head(self, ws: Workspace):
@@ -385,6 +397,7 @@ class Engine:
             # the two branches' lookups are independent gather chains: B's runs beside A's
             main, sb = torch.cuda.current_stream(), self.side[2]
             sb.wait_stream(main)
+            self._await_b(sb, keep=True)
             with torch.cuda.stream(sb):
                 lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b)
                 lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
@@ -395,6 +408,7 @@ class Engine:
             lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
             lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
             if need_b:
+                self._await_b(torch.cuda.current_stream(), keep=True)
                 lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b)
                 lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
         d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
@@ -422,6 +436,7 @@ class Engine:
         """Everything of an iteration up to (excluding) conv_A / conv: fills cat_a, cat_b and the flow
         tails of x_a, x_b from coords1 and the pyramids.  Three concurrent chains when side streams exist."""
         if not self.forks & 2:
+            self._await_b(torch.cuda.current_stream())
             self._flow_chain_head(ws)
             self._corr_chain(ws, P, need_b)
             self._flow_chain_tail(ws, P, need_b)
@@ -441,9 +456,10 @@ class Engine:
         self._corr_chain(ws, P, need_b)
         main.wait_stream(s1)
         main.wait_stream(s2)
+        self._b_pending = None      # s1 (which ran the deferred tail) has been joined
 
     def update_blocks(self, ws: Workspace, P: Dict[str, object], cur: int, need_b: bool, mask_a: bool,
-                      mask_b: bool, inputs_ready: bool = False) -> int:
+                      mask_b: bool, inputs_ready: bool = False, defer_b_join: bool = False) -> int:
         """ODDC (branch A) and update_block (branch B) (core/update.py:152-159, :129-136).
         Inputs: corr_x, flow4_a / flow2_b, conf_in, x_x (inp + flow tail), net_x[cur], c1x.
         Outputs: net_x[cur], delta_x, mask_x, and c1x += delta_x (core/prior_raft.py:193,196).
@@ -509,12 +525,15 @@ class Engine:
                 s1.wait_stream(main)
                 with torch.cuda.stream(s1):
                     lib.flow_head_out(ws.fh_b, 256, P["b.fh2w"], P["b.fh2b"], ws.c1b, ws.delta_b)
+                    if defer_b_join:
+                        self._b_pending = torch.cuda.Event()
+                        self._b_pending.record(s1)
             if d:
                 s2.wait_stream(main)
                 with torch.cuda.stream(s2):
                     lib.conv2d(d, B, H8, W8, like)
             lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
-            if need_b:
+            if need_b and not defer_b_join:
                 main.wait_stream(s1)
             if d:
                 main.wait_stream(s2)

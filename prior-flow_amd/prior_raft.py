@@ -163,7 +163,8 @@ class PriOr_RAFT(nn.Module):
                 # dead-work elimination: only the last prediction of branch A is returned
                 # (core/prior_raft.py:212-213), so 23 of 24 upsamples, every B mask head and
                 # branch B's last update are never observable.
-                cur = eng.iteration(ws, P, cur, need_b=not last, mask_a=last, mask_b=False)
+                cur = eng.iteration(ws, P, cur, need_b=not last, mask_a=last, mask_b=False,
+                                    defer_b_join=not last and os.environ.get("PRIORFLOW_DEFER_B", "1") != "0")
                 if last:
                     eng.upsample(ws, "a", out_a[0])
             else:
