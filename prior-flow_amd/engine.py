@@ -285,6 +285,8 @@ class Engine:
         # motion_inputs, 4: branch B's lookups, 8: the head tails; 1 is the encoders' fork in prior_raft.py)
         self.forks = int(os.environ.get("PRIORFLOW_FORKS", "15")) if side_streams is not None else 0
         self._b_pending = None      # event after branch B's deferred FlowHead tail (see iteration())
+        # capture-order switches (bit mask; see motion_inputs): 1 chains, 2 head tails, 4 lookups: calling stream first
+        self.order = int(os.environ.get("PRIORFLOW_ORDER", "15"))
 
     # ---- stage 0: view B images --------------------------------------------------------------
     def rotate_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
@@ -389,20 +391,33 @@ class Engine:
         for dc, x, out, off in ((P["a.cf1"], ws.conf_in, ws.conf_mid, 0), (P["a.cf2"], ws.conf_mid, ws.cat_a, 256)):
             lib.conv2d_direct(x, 0, dc.cin, dc.w, dc.b, out, off, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
 
-    def _corr_chain(self, ws: Workspace, P, need_b: bool):
+    def _corr_chain(self, ws: Workspace, P, need_b: bool, fork_from=None):
         """DCCL lookups (K3+K4; :185-188) + 1x1 + 3x3 of the motion encoders -> cat_a[0:128], cat_b[0:192].
         A looks into B through grid(R_A2B^T)==grid(R_B2A) and rotates back with grid(R_B2A); B the other way."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
         if need_b and self.forks & 4:
             # the two branches' lookups are independent gather chains: B's runs beside A's
             main, sb = torch.cuda.current_stream(), self.side[2]
-            sb.wait_stream(main)
+            a_first = bool(self.order & 4)
+            if a_first:
+                ev = fork_from
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+                lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+                sb.wait_event(ev)
+            elif fork_from is not None:
+                sb.wait_event(fork_from)
+            else:
+                sb.wait_stream(main)
             self._await_b(sb, keep=True)
             with torch.cuda.stream(sb):
                 lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b)
                 lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
-            lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
-            lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+            if not a_first:
+                lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+                lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
             main.wait_stream(sb)
         else:
             lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
@@ -444,7 +459,18 @@ class Engine:
             return
         main = torch.cuda.current_stream()
         s1, s2 = self.side[0], self.side[1]
-        s1.wait_stream(main)
+        # Enqueue order matters inside a captured graph: the runtime keeps a node's FIRST-captured successor on its
+        # queue and moves the others to other queues (a cross-queue dependency costs ~10 us).  The calling stream's
+        # own chain is therefore enqueued first and the side chains fork from an event recorded at its start
+        # (same dependencies as forking first; -330 us per forward in a same-box A/B).
+        order = "main-first" if self.order & 1 else "forks-first"
+        if order == "main-first":
+            start = torch.cuda.Event()
+            start.record(main)
+            self._corr_chain(ws, P, need_b, fork_from=start)
+            s1.wait_event(start)
+        else:
+            s1.wait_stream(main)
         with torch.cuda.stream(s1):
             self._flow_chain_head(ws)
             head_done = torch.cuda.Event()
@@ -453,7 +479,8 @@ class Engine:
         s2.wait_event(head_done)            # warp #2 needs flow_ba
         with torch.cuda.stream(s2):
             self._conf_chain(ws, P)
-        self._corr_chain(ws, P, need_b)
+        if order != "main-first":
+            self._corr_chain(ws, P, need_b)
         main.wait_stream(s1)
         main.wait_stream(s2)
         self._b_pending = None      # s1 (which ran the deferred tail) has been joined
@@ -521,18 +548,30 @@ class Engine:
             # three independent tails of the heads: flow_out A | flow_out B | mask convs
             main = torch.cuda.current_stream()
             s1, s2 = self.side[0], self.side[1]
+            tail_first = bool(self.order & 2)
+            if tail_first:              # branch A's tail stays on the calling stream's queue: enqueue it first
+                heads_done = torch.cuda.Event()
+                heads_done.record(main)
+                lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
             if need_b:
-                s1.wait_stream(main)
+                if tail_first:
+                    s1.wait_event(heads_done)
+                else:
+                    s1.wait_stream(main)
                 with torch.cuda.stream(s1):
                     lib.flow_head_out(ws.fh_b, 256, P["b.fh2w"], P["b.fh2b"], ws.c1b, ws.delta_b)
                     if defer_b_join:
                         self._b_pending = torch.cuda.Event()
                         self._b_pending.record(s1)
             if d:
-                s2.wait_stream(main)
+                if tail_first:
+                    s2.wait_event(heads_done)
+                else:
+                    s2.wait_stream(main)
                 with torch.cuda.stream(s2):
                     lib.conv2d(d, B, H8, W8, like)
-            lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
+            if not tail_first:
+                lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
             if need_b and not defer_b_join:
                 main.wait_stream(s1)
             if d:

@@ -126,14 +126,24 @@ class PriOr_RAFT(nn.Module):
                 # kernels of one (stem, statistics) hide behind the other's convolutions
                 cur = torch.cuda.current_stream()
                 s1, s2 = self._streams()[:2]
-                s1.wait_stream(cur)
-                s2.wait_stream(cur)
-                with torch.cuda.stream(s1):
-                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
-                with torch.cuda.stream(s2):
+                if int(os.environ.get("PRIORFLOW_ORDER", "15")) & 8:
+                    # fnet (the longer chain) stays on the calling stream and is enqueued first; cnet forks from an event
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
                     fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
-                cur.wait_stream(s1)
-                cur.wait_stream(s2)
+                    s1.wait_event(ev)
+                    with torch.cuda.stream(s1):
+                        cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+                    cur.wait_stream(s1)
+                else:
+                    s1.wait_stream(cur)
+                    s2.wait_stream(cur)
+                    with torch.cuda.stream(s1):
+                        cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+                    with torch.cuda.stream(s2):
+                        fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
+                    cur.wait_stream(s1)
+                    cur.wait_stream(s2)
             else:
                 cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
                 fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
