@@ -474,6 +474,19 @@ class PfLib:
 _cached: Optional[PfLib] = None
 
 
+_WEIGHTS_EPOCH = [0]
+
+
+def weights_epoch() -> int:
+    """Counter of in-place parameter updates made through raw pointers (pf_adamw_step): torch's per-tensor
+    version counters do not see those, so every cache of packed weights keys on this as well."""
+    return _WEIGHTS_EPOCH[0]
+
+
+def bump_weights_epoch() -> None:
+    _WEIGHTS_EPOCH[0] += 1
+
+
 def load() -> PfLib:
     """The product's library handle (built in-tree under prior-flow_amd/lib/)."""
     global _cached

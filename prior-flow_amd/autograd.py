@@ -1,0 +1,451 @@
+"""Differentiable (training-mode) forward of PriOr-RAFT on the HIP kernels.
+
+``train_forward(model, image1, image2, iters, init_flow)`` follows core/prior_raft.py:107-215 and
+core/update.py / core/extractor.py with torch autograd as the tape and the HIP library as the arithmetic,
+in BOTH directions, of every heavy operator:
+
+  operator (reference)                           forward                          backward
+  ---------------------------------------------  -------------------------------  ----------------------------------------
+  nn.Conv2d 3x3 / 1x5 / 5x1 / 1x1, stride 1      pf_conv2d (bf16x3 MFMA)          pf_conv2d on flipped weights (dgrad),
+                                                                                  pf_conv2d_wgrad (+ bias column sums)
+  corr + build_pyramid (prior_raft.py:69-75)     pf_corr_pyramid_bf16x3           pf_pyramid_bwd + two feature GEMMs
+  DCCL.__call__ own + cross (corr.py:113-144)    pf_dccl_lookup + pf_dccl_combine pf_dccl_combine_bwd + pf_dccl_lookup_bwd
+  warp + groupwise_corr (prior_raft.py:173-182)  pf_warp_gcorr                    pf_warp_gcorr_bwd
+  upsample_flow (prior_raft.py:58-67)            pf_upsample_flow                 pf_upsample_flow_bwd
+  SepConvGRU gates (update.py:49-60)             elementwise                      pf_gru_zr_bwd, pf_gru_q_bwd
+  InstanceNorm2d (extractor.py:112-113)          elementwise                      pf_norm_bwd
+  img_rotate / flo_rotate / sample grids         pf_img_rotate / pf_flo_rotate    (inputs are detached in the reference)
+
+Left on PyTorch-ROCm device ops (plumbing; no HIP backward kernel exists for them yet): the three stride-2
+convolutions and the 7x7/2 stem of each encoder, the 7x7 2->128 flow stems, BatchNorm2d of cnet, ReLU / tanh /
+sigmoid outside the GRU backward, torch.cat / slicing, and the feature GEMMs of the corr backward (torch.bmm).
+There is no CPU path: every tensor must live on a ROCm device and ``_lib.load()`` raises when the HIP library
+is missing.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import EPI_LINEAR, PREC_BF16X3
+from .engine import Conv, pack_mfma, rotation_x
+
+STATS = {"hip": 0, "torch": 0}          # launches routed to the HIP library / left to torch (tests read this)
+
+
+def _rows(x: torch.Tensor) -> torch.Tensor:
+    """NCHW -> channel-last rows [B*H*W, C]."""
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def _nchw(rows: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    return rows.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+# weight packs of one training step, keyed by (storage, version): a conv that runs 2 x iters times packs once
+_PACKS: Dict[tuple, object] = {}
+
+
+def _pack(w: torch.Tensor, b: Optional[torch.Tensor], kind: str):
+    key = (kind, w.data_ptr(), w._version, tuple(w.shape), _lib.weights_epoch())
+    hit = _PACKS.get(key)
+    if hit is not None:
+        return hit
+    if len(_PACKS) > 256:           # one training step needs ~140 entries; stale ones go with the next refill
+        _PACKS.clear()
+    cout, cin, kh, kw = w.shape
+    cp = (cout + 3) // 4 * 4
+    if kind == "fwd":
+        wp, bp = pack_mfma(w.detach(), b.detach())
+        val = Conv(wp, bp, kh, kw, cin, cout, PREC_BF16X3)
+    else:           # data gradient: the forward kernel on flipped / transposed weights (Cout padded to 4 with zero rows)
+        wpad = torch.zeros(cp, cin, kh, kw, device=w.device)
+        wpad[:cout] = w.detach()
+        val = Conv.dgrad_of(wpad, PREC_BF16X3)
+    _PACKS[key] = val
+    return val
+
+
+class HipConv(torch.autograd.Function):
+    """Stride-1 'same' convolution with bias: pf_conv2d forward, pf_conv2d (dgrad) + pf_conv2d_wgrad backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        cout, _, kh, kw = w.shape
+        xr = _rows(x.detach())
+        cv = _pack(w, b, "fwd")
+        cp = (cout + 3) // 4 * 4
+        out = torch.zeros(B * H * W, cp, device=x.device)
+        lib.conv2d([cv.desc(xr, 0, C, out, 0, EPI_LINEAR)], B, H, W, xr)
+        ctx.save_for_backward(xr, w)
+        ctx.shape = (B, C, H, W, cout, kh, kw, cp)
+        STATS["hip"] += 1
+        return _nchw(out[:, :cout], B, H, W)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xr, w = ctx.saved_tensors
+        B, C, H, W, cout, kh, kw, cp = ctx.shape
+        dy = torch.zeros(B * H * W, cp, device=gy.device)
+        dy[:, :cout] = _rows(gy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dg = _pack(w, None, "dgrad")
+            dxr = torch.empty(B * H * W, C, device=gy.device)
+            lib.conv2d([dg.desc(dy, 0, cp, dxr, 0, EPI_LINEAR)], B, H, W, dy)
+            dx = _nchw(dxr, B, H, W)
+        op = (cp + 127) // 128 * 128
+        dw = torch.zeros(op, kh * kw, (C + 31) // 32 * 32, device=gy.device)
+        db = torch.zeros(op, device=gy.device)
+        lib.conv2d_wgrad(xr, 0, C, dy, 0, cp, dw, db, kh, kw, B, H, W)
+        STATS["hip"] += 2
+        return dx, Conv.unpack_wgrad(dw, cout, C, kh, kw), db[:cout].clone()
+
+
+def conv2d(x: torch.Tensor, m: nn.Conv2d) -> torch.Tensor:
+    """nn.Conv2d.forward of module ``m``: the HIP pair when the geometry is covered, PyTorch-ROCm otherwise."""
+    kh, kw = m.kernel_size
+    hip = (m.stride == (1, 1) and (kh, kw) in ((3, 3), (1, 5), (5, 1), (1, 1)) and m.padding == (kh // 2, kw // 2)
+           and x.shape[1] % 4 == 0 and m.bias is not None and m.dilation == (1, 1) and m.groups == 1)
+    if hip:
+        return HipConv.apply(x, m.weight, m.bias)
+    STATS["torch"] += 1
+    return F.conv2d(x, m.weight, m.bias, stride=m.stride, padding=m.padding)
+
+
+class HipCorrPyramid(torch.autograd.Function):
+    """corr + build_pyramid (core/prior_raft.py:69-75, core/corr.py:99-111)."""
+
+    @staticmethod
+    def forward(ctx, f1, f2):
+        lib = _lib.load()
+        B, C, H, W = f1.shape
+        n = H * W
+        r1, r2 = _rows(f1.detach()), _rows(f2.detach())
+        sp = [lib.split_bf16(r, torch.empty(B * n, C // 32, 2, 32, dtype=torch.bfloat16, device=f1.device))
+              for r in (r1, r2)]
+        lv = [torch.empty(B * n, (H >> i) * (W >> i), device=f1.device) for i in range(4)]
+        lib.corr_pyramid_bf16x3(sp[0], sp[1], lv, B, H, W, C)
+        ctx.save_for_backward(r1, r2)
+        ctx.shape = (B, C, H, W)
+        STATS["hip"] += 1
+        return tuple(lv)
+
+    @staticmethod
+    def backward(ctx, *g):
+        lib = _lib.load()
+        r1, r2 = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        n = H * W
+        gl = [torch.zeros(B * n, (H >> i) * (W >> i), device=r1.device) if x is None
+              else x.reshape(B * n, -1).contiguous().clone() for i, x in enumerate(g)]
+        dv = lib.pyramid_bwd(gl, B, H, W).view(B, n, n)
+        s = 1.0 / math.sqrt(C)
+        d1 = torch.bmm(dv, r2.view(B, n, C)) * s
+        d2 = torch.bmm(dv.transpose(1, 2), r1.view(B, n, C)) * s
+        STATS["hip"] += 1
+        return _nchw(d1.reshape(B * n, C), B, H, W), _nchw(d2.reshape(B * n, C), B, H, W)
+
+
+class HipDccl(torch.autograd.Function):
+    """DCCL.__call__ (core/corr.py:113-144), own + rotated-back cross lookup summed (prior_raft.py:187-188).
+    Pyramid levels are [B*N, H_i*W_i] rows; the coordinates carry no gradient (detached, prior_raft.py:171,176)."""
+
+    @staticmethod
+    def forward(ctx, coords, g_w2c, g_back, *pyr):
+        lib = _lib.load()
+        B, _, H, W = coords.shape
+        n = H * W
+        own_p = [p.detach() for p in pyr[:4]]
+        oth_p = [p.detach() for p in pyr[4:]]
+        own, raw, out = (torch.empty(B * n, 324, device=coords.device) for _ in range(3))
+        co = coords.detach().contiguous()
+        lib.dccl_lookup(co, own_p, oth_p, g_w2c, own, raw)
+        lib.dccl_combine(own, raw, g_back, out, B, H, W)
+        ctx.save_for_backward(co, g_w2c, g_back)
+        ctx.dims = (B, H, W)
+        STATS["hip"] += 2
+        return _nchw(out, B, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        co, g_w2c, g_back = ctx.saved_tensors
+        B, H, W = ctx.dims
+        n = H * W
+        d_corr = _rows(g)
+        d_raw = torch.zeros(B * n, 324, device=g.device)
+        lib.dccl_combine_bwd(d_corr, g_back, d_raw, B, H, W)
+        g_own = [torch.zeros(B * n, (H >> i) * (W >> i), device=g.device) for i in range(4)]
+        g_oth = [torch.zeros(B * n, (H >> i) * (W >> i), device=g.device) for i in range(4)]
+        lib.dccl_lookup_bwd(co, g_w2c, d_corr, d_raw, g_own, g_oth)
+        STATS["hip"] += 2
+        return (None, None, None, *g_own, *g_oth)
+
+
+class HipUpsample(torch.autograd.Function):
+    """upsample_flow (core/prior_raft.py:58-67) of flow = coords1 - coords0 with the 0.25-scaled mask logits."""
+
+    @staticmethod
+    def forward(ctx, flow, mask, coords0):
+        lib = _lib.load()
+        B, _, H, W = flow.shape
+        coords1 = (coords0 + flow.detach()).contiguous()
+        mrows = _rows(mask.detach())
+        out = torch.empty(B, 2, 8 * H, 8 * W, device=flow.device)
+        lib.upsample_flow(coords1, mrows, out)
+        ctx.save_for_backward(coords1, mrows)
+        STATS["hip"] += 1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        coords1, mrows = ctx.saved_tensors
+        B, _, H, W = coords1.shape
+        d_mask = torch.empty(B * H * W, 576, device=g.device)
+        d_flow = torch.zeros(B, 2, H, W, device=g.device)
+        lib.upsample_flow_bwd(coords1, mrows, g.contiguous(), d_mask, d_flow)
+        STATS["hip"] += 1
+        return d_flow, _nchw(d_mask, B, H, W), None
+
+
+class HipWarpGcorr(torch.autograd.Function):
+    """cycle_bilinear_sampler + groupwise_corr (core/prior_raft.py:173-174, :77-83); coords carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, coords):
+        lib = _lib.load()
+        B, C, H, W = f1.shape
+        r1, r2, co = _rows(f1.detach()), _rows(f2.detach()), coords.detach().contiguous()
+        out = torch.empty(B * H * W, 4, device=f1.device)
+        lib.warp_gcorr(r1, r2, co, False, out, 0)
+        ctx.save_for_backward(r1, r2, co)
+        STATS["hip"] += 1
+        return _nchw(out, B, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        r1, r2, co = ctx.saved_tensors
+        B, _, H, W = co.shape
+        d1, d2 = torch.zeros_like(r1), torch.zeros_like(r2)
+        lib.warp_gcorr_bwd(r1, r2, co, False, _rows(g), 0, d1, d2)
+        STATS["hip"] += 1
+        return _nchw(d1, B, H, W), _nchw(d2, B, H, W), None
+
+
+class HipGruGates(torch.autograd.Function):
+    """z = sigmoid(az), r = sigmoid(ar), rh = r * h (core/update.py:49-51, :56-58); backward = pf_gru_zr_bwd."""
+
+    @staticmethod
+    def forward(ctx, az, ar, h):
+        z, r = torch.sigmoid(az), torch.sigmoid(ar)
+        ctx.save_for_backward(_rows(z), _rows(r), _rows(h))
+        ctx.shape = az.shape
+        return z, r * h
+
+    @staticmethod
+    def backward(ctx, dz, d_rh):
+        lib = _lib.load()
+        z, r, h = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        dzr = torch.empty(B * H * W, 2 * Cc, device=dz.device)
+        dh = torch.zeros(B * H * W, Cc, device=dz.device)
+        lib.gru_zr_bwd(_rows(dz), _rows(d_rh), z, r, h, dzr, dh)
+        STATS["hip"] += 1
+        return _nchw(dzr[:, :Cc].contiguous(), B, H, W), _nchw(dzr[:, Cc:].contiguous(), B, H, W), _nchw(dh, B, H, W)
+
+
+class HipGruBlend(torch.autograd.Function):
+    """q = tanh(aq), h' = (1 - z) * h + z * q (core/update.py:52-53, :59-60); backward = pf_gru_q_bwd."""
+
+    @staticmethod
+    def forward(ctx, z, aq, h):
+        q = torch.tanh(aq)
+        ctx.save_for_backward(_rows(z), _rows(q), _rows(h))
+        ctx.shape = z.shape
+        return (1 - z) * h + z * q
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        z, q, h = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        dq_pre, dz, dh = (torch.empty(B * H * W, Cc, device=g.device) for _ in range(3))
+        lib.gru_q_bwd(_rows(g), z, q, h, dq_pre, dz, dh)
+        STATS["hip"] += 1
+        return _nchw(dz, B, H, W), _nchw(dq_pre, B, H, W), _nchw(dh, B, H, W)
+
+
+class HipInstanceNorm(torch.autograd.Function):
+    """nn.InstanceNorm2d without affine / running statistics (core/extractor.py:112-113); backward = pf_norm_bwd."""
+
+    @staticmethod
+    def forward(ctx, x):
+        mu = x.mean(dim=(2, 3), keepdim=True)
+        rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3), unbiased=False, keepdim=True) + 1e-5)
+        B, Cc = x.shape[:2]
+        ctx.save_for_backward(_rows(x), rstd.reshape(B, Cc).contiguous(), (-mu * rstd).reshape(B, Cc).contiguous())
+        ctx.shape = x.shape
+        return (x - mu) * rstd
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        xr, scale, shift = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        dx = torch.empty_like(xr)
+        lib.norm_bwd(_rows(g), xr, scale, shift, False, True, dx, B, H * W, Cc)
+        STATS["hip"] += 1
+        return _nchw(dx, B, H, W)
+
+
+# ---- module forwards (the parameter containers of modules.py carry no arithmetic of their own) ---------------
+def _norm(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    if isinstance(m, nn.InstanceNorm2d):
+        return HipInstanceNorm.apply(x)
+    if isinstance(m, nn.BatchNorm2d):        # running statistics are updated unless frozen (freeze_bn -> eval)
+        return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, m.training, m.momentum, m.eps)
+    raise _lib.PfError(f"unsupported norm layer {type(m).__name__}")
+
+
+def encoder_forward(enc, x: torch.Tensor) -> torch.Tensor:
+    """BasicEncoder.forward (core/extractor.py:136-158) on one concatenated batch."""
+    x = torch.relu(_norm(enc.norm1, conv2d(x, enc.conv1)))
+    for layer in (enc.layer1, enc.layer2, enc.layer3):
+        for blk in layer:                                     # ResidualBlock.forward (core/extractor.py:39-47)
+            y = torch.relu(_norm(blk.norm1, conv2d(x, blk.conv1)))
+            y = torch.relu(_norm(blk.norm2, conv2d(y, blk.conv2)))
+            if blk.downsample is not None:
+                x = _norm(blk.norm3, conv2d(x, blk.downsample[0]))
+            x = torch.relu(x + y)
+    x = conv2d(x, enc.conv2)
+    if enc.training and enc.dropout is not None:
+        x = enc.dropout(x)
+    return x
+
+
+def sepconv_gru(gru, h: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """SepConvGRU.forward (core/update.py:45-60)."""
+    for tag in ("1", "2"):
+        hx = torch.cat([h, x], 1)
+        z, rh = HipGruGates.apply(conv2d(hx, getattr(gru, "convz" + tag)), conv2d(hx, getattr(gru, "convr" + tag)), h)
+        h = HipGruBlend.apply(z, conv2d(torch.cat([rh, x], 1), getattr(gru, "convq" + tag)), h)
+    return h
+
+
+def _heads(blk, net: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    delta = conv2d(torch.relu(conv2d(net, blk.flow_head.conv1)), blk.flow_head.conv2)        # update.py:13-14
+    mask = 0.25 * conv2d(torch.relu(conv2d(net, blk.mask[0])), blk.mask[2])                  # update.py:134,157
+    return mask, delta
+
+
+def update_block_b(blk, net, inp, corr, flow):
+    """BasicUpdateBlock.forward + BasicMotionEncoder.forward (core/update.py:91-99, :129-136)."""
+    e = blk.encoder
+    cor = torch.relu(conv2d(torch.relu(conv2d(corr, e.convc1)), e.convc2))
+    flo = torch.relu(conv2d(torch.relu(conv2d(flow, e.convf1)), e.convf2))
+    out = torch.relu(conv2d(torch.cat([cor, flo], 1), e.conv))
+    net = sepconv_gru(blk.gru, net, torch.cat([inp, out, flow], 1))
+    mask, delta = _heads(blk, net)
+    return net, mask, delta
+
+
+def update_block_a(blk, net, inp, flow_a, corr_a, flaw_a, flow_ba, flaw_ba):
+    """BasicMultiUpdateBlock.forward + BasicMultiMotionEncoder.forward (core/update.py:152-159, :183-201)."""
+    e = blk.encoder
+    cor = torch.relu(conv2d(torch.relu(conv2d(corr_a, e.convc1_A)), e.convc2_A))
+    flo_a = torch.relu(conv2d(torch.relu(conv2d(flow_a, e.convf1_A)), e.convf2_A))
+    flo_b = torch.relu(conv2d(torch.relu(conv2d(flow_ba, e.convf1_B)), e.convf2_B))
+    conf = torch.relu(conv2d(torch.relu(conv2d(torch.cat([flaw_a, flaw_ba], 1), e.conv_conf1)), e.conv_conf2))
+    out = torch.relu(conv2d(torch.cat([cor, flo_a, flo_b, conf], 1), e.conv_A))
+    net = sepconv_gru(blk.gru, net, torch.cat([inp, out, flow_a, flow_ba], 1))
+    mask, delta = _heads(blk, net)
+    return net, mask, delta
+
+
+_GRIDS: Dict[tuple, tuple] = {}
+
+
+def _grids(H: int, W: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """grid(R_A2B) at full size and grid(R_A2B), grid(R_B2A) at 1/8 (core/prior_raft.py:115-125; the W2C grids
+    are these same two: grid(R^T_A2B) == grid(R_B2A) bit for bit)."""
+    key = (H, W, str(device))
+    if key not in _GRIDS:
+        lib = _lib.load()
+        g_a2b = torch.empty(2, H, W, device=device)
+        g_a2b_8 = torch.empty(2, H // 8, W // 8, device=device)
+        g_b2a_8 = torch.empty(2, H // 8, W // 8, device=device)
+        lib.sample_grid(g_a2b, rotation_x(-math.pi / 2))
+        lib.sample_grid(g_a2b_8, rotation_x(-math.pi / 2))
+        lib.sample_grid(g_b2a_8, rotation_x(math.pi / 2))
+        _GRIDS[key] = (g_a2b, g_a2b_8, g_b2a_8)
+    return _GRIDS[key]
+
+
+def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int = 12,
+                  init_flow: Optional[torch.Tensor] = None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """PriOr_RAFT.forward(test_mode=False) with an autograd graph (core/prior_raft.py:107-215)."""
+    lib = _lib.load()
+    if not image1.is_cuda:
+        raise _lib.PfError("train_forward needs inputs on a cuda/ROCm device; there is no CPU path")
+    B, _, H, W = image1.shape
+    if H % 8 or W % 8 or H < 128 or W < 128:
+        raise _lib.PfError(f"image size {H}x{W}: H and W must be multiples of 8 and at least 128")
+    dev = image1.device
+    H8, W8 = H // 8, W // 8
+    g_a2b, g_a2b_8, g_b2a_8 = _grids(H, W, dev)
+    with torch.no_grad():
+        i1 = (2 * (image1.float() / 255.0) - 1.0).contiguous()
+        i2 = (2 * (image2.float() / 255.0) - 1.0).contiguous()
+        rot = torch.empty(B, 6, H, W, device=dev)
+        lib.img_rotate(torch.cat([i1, i2], 1).contiguous(), g_a2b, rot)                         # :127
+        i1b, i2b = rot[:, :3].contiguous(), rot[:, 3:].contiguous()
+        xs = torch.arange(W8, device=dev, dtype=torch.float32).view(1, 1, 1, W8).expand(B, 1, H8, W8)
+        ys = torch.arange(H8, device=dev, dtype=torch.float32).view(1, 1, H8, 1).expand(B, 1, H8, W8)
+        coords0 = torch.cat([xs, ys], 1).contiguous()                                           # :50-56
+
+    cnet = encoder_forward(model.cnet, torch.cat([i1, i1b], 0))                                 # :133-142
+    net_a, inp_a = torch.tanh(cnet[:B, :128]), torch.relu(cnet[:B, 128:])
+    net_b, inp_b = torch.tanh(cnet[B:, :128]), torch.relu(cnet[B:, 128:])
+    fm = encoder_forward(model.fnet, torch.cat([i1, i2, i1b, i2b], 0)).float()                  # :144-149
+    f1a, f2a, f1b, f2b = fm[:B], fm[B:2 * B], fm[2 * B:3 * B], fm[3 * B:]
+    pyr_a = HipCorrPyramid.apply(f1a, f2a)                                                      # :151-159
+    pyr_b = HipCorrPyramid.apply(f1b, f2b)
+
+    c1a, c1b = coords0.clone(), coords0.clone()
+    if init_flow is not None:                                                                   # :162-165
+        with torch.no_grad():
+            fl = init_flow.float().contiguous()
+            c1a = c1a + fl
+            c1b = c1b + lib.flo_rotate(fl, g_b2a_8, g_a2b_8, torch.empty_like(fl))
+    preds_a: List[torch.Tensor] = []
+    preds_b: List[torch.Tensor] = []
+    for _ in range(iters):
+        c1a, c1b = c1a.detach(), c1b.detach()                                                   # :171, :176
+        with torch.no_grad():
+            flow_a = (c1a - coords0).contiguous()
+            flow_b = (c1b - coords0).contiguous()
+            flow_ba = lib.flo_rotate(flow_b, g_a2b_8, g_b2a_8, torch.empty_like(flow_b))        # :179
+            c_ba = (coords0 + flow_ba).contiguous()
+        flaw_a = HipWarpGcorr.apply(f1a, f2a, c1a)                                              # :173-174
+        flaw_ba = HipWarpGcorr.apply(f1a, f2a, c_ba)                                            # :181-182
+        corr_a = HipDccl.apply(c1a, g_b2a_8, g_b2a_8, *pyr_a, *pyr_b)                           # :185, :187
+        corr_b = HipDccl.apply(c1b, g_a2b_8, g_a2b_8, *pyr_b, *pyr_a)                           # :186, :188
+        net_a, mask_a, delta_a = update_block_a(model.ODDC, net_a, inp_a, flow_a, corr_a, flaw_a, flow_ba, flaw_ba)
+        net_b, mask_b, delta_b = update_block_b(model.update_block, net_b, inp_b, corr_b, flow_b)
+        c1a = c1a + delta_a                                                                     # :193-197
+        c1b = c1b + delta_b
+        preds_a.append(HipUpsample.apply(c1a - coords0, mask_a, coords0))                       # :200-208
+        preds_b.append(HipUpsample.apply(c1b - coords0, mask_b, coords0))
+    return preds_a, preds_b

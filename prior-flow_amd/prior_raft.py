@@ -5,10 +5,10 @@ inner loop running in hand-written gfx950 kernels (``libpriorflow_hip.so``).
     model = PriOr_RAFT(args).cuda().eval()
     flow  = model(image1, image2, iters=12, test_mode=True)      # [B,2,H,W]
 
-Callers covered: demo.py:11-19, demo_image.py:30-39, evaluate.py:208,266,318,350,382 (all
-inference).  The training caller (train_flow.py:131) needs the backward kernels, which this
-round does not ship: a forward with autograd enabled in train() mode raises instead of
-silently returning non-differentiable tensors.
+Callers covered: demo.py:11-19, demo_image.py:30-39, evaluate.py:208,266,318,350,382 (inference:
+the workspace / HIP-graph engine) and the training caller train_flow.py:131: in ``train()`` mode with
+autograd enabled the forward runs ``autograd.train_forward`` -- torch autograd as the tape, the HIP
+kernels as the arithmetic in both directions (``autograd.py`` lists what is still a PyTorch-ROCm op).
 """
 from __future__ import annotations
 
@@ -75,7 +75,7 @@ class PriOr_RAFT(nn.Module):
 
     def _weights(self):
         params = list(self.ODDC.parameters()) + list(self.update_block.parameters())
-        sig = tuple((p.data_ptr(), p._version) for p in params) + (self.precision,)
+        sig = tuple((p.data_ptr(), p._version) for p in params) + (self.precision, _lib.weights_epoch())
         if self._packed is None or sig != self._packed_sig:
             with torch.no_grad():
                 self._packed = pack_update_blocks(self.ODDC, self.update_block, self.precision)
@@ -95,7 +95,7 @@ class PriOr_RAFT(nn.Module):
     def _encoder_plans(self):
         """HIP launch plans of cnet / fnet (bf16x3 mode), rebuilt when their weights change."""
         params = list(self.fnet.parameters()) + list(self.cnet.parameters()) + list(self.cnet.buffers())
-        sig = tuple((p.data_ptr(), p._version) for p in params)
+        sig = tuple((p.data_ptr(), p._version) for p in params) + (_lib.weights_epoch(),)
         if self._enc_plans is None or sig != self._enc_sig:
             from ._lib import PREC_BF16X3
             with torch.no_grad():
@@ -191,9 +191,11 @@ class PriOr_RAFT(nn.Module):
             raise _lib.PfError("PriOr_RAFT (MI355X build) needs inputs on a cuda/ROCm device; "
                                "there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only)")
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "training forward/backward through the HIP kernels is not implemented in this round "
-                "(SURVEY.md §8f rank 3); run inference under torch.no_grad() / model.eval()")
+            # training caller (train_flow.py:131): autograd tape over the HIP forward / backward kernels
+            from .autograd import train_forward
+            with torch.cuda.device(image1.device):
+                preds_a, preds_b = train_forward(self, image1, image2, iters, init_flow)
+            return preds_a[-1] if test_mode else (preds_a, preds_b)
         B, _, H, W = image1.shape
         device = image1.device
         with torch.no_grad(), torch.cuda.device(device):

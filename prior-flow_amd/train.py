@@ -1,6 +1,6 @@
-"""Training-step counterpart of the reference on the HIP kernels -- everything of
-``train_flow.py``'s step EXCEPT the network's backward, which is not built (``PriOr_RAFT.forward``
-raises in ``train()`` mode with autograd on).
+"""Training-step counterpart of the reference on the HIP kernels.  The network's
+forward / backward in ``train()`` mode is ``autograd.train_forward`` (reached through ``PriOr_RAFT.forward``);
+``train_step`` below is the loop body of ``train_flow.py:120-141`` built from the pieces of this module.
 
 Mirrors, with the reference's names and argument meaning:
   * ``uniform_loss(H, W)(flow_preds, flow_gt, valid, gamma, extro_info, max_flow)`` (train_flow.py:55-79)
@@ -166,6 +166,7 @@ class FlatAdamW:
         self.lib.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
                             g["eps"], g["weight_decay"], self.step_count, self.grad_scale)
         self.grad_scale = 1.0
+        _lib.bump_weights_epoch()       # the kernel wrote the parameters through raw pointers: drop packed copies
 
 
 def clip_grad_norm_(optimizer: FlatAdamW, max_norm: float) -> float:
@@ -181,3 +182,31 @@ def fetch_optimizer(args, model):
     optimizer = FlatAdamW(model.parameters(), lr=args.lr, weight_decay=args.wdecay, eps=args.epsilon)
     scheduler = OneCycleLinearLR(optimizer, args.lr, args.num_steps + 100, pct_start=0.05)
     return optimizer, scheduler
+
+
+def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criterion: uniform_loss,
+               image1: torch.Tensor, image2: torch.Tensor, flow_gt: torch.Tensor, valid: torch.Tensor,
+               iters: int = 12, gamma: float = 0.8, clip: float = 1.0, group=None):
+    """One optimisation step, the loop body of train_flow.py:120-141 (without GradScaler: fp32 / bf16x3 math
+    needs no loss scaling): zero_grad, GT rotation, forward of both branches, sequence loss of both, backward,
+    [one SUM all-reduce of the flat gradient buffer when torch.distributed runs with more than one rank --
+    RCCL over xGMI, replacing DataParallel's reduce_add (train_flow.py:96)], clip, AdamW, scheduler.
+    ``model`` may be the bare module or an ``nn.DataParallel``-style wrapper exposing ``.module``.
+    Returns ``(loss, metrics)``; ``metrics['grad_norm']`` is the pre-clip total norm."""
+    import torch.distributed as dist
+    net = getattr(model, "module", model)
+    optimizer.zero_grad()
+    flow_gt_b, valid_b = rotate_gt(flow_gt)
+    preds_a, preds_b = net(image1, image2, iters=iters)
+    loss_a, metrics_a = criterion(preds_a, flow_gt, valid, gamma, extro_info="A-")
+    seeds = list(criterion.grads)
+    loss_b, metrics_b = criterion(preds_b, flow_gt_b, valid_b, gamma, extro_info="B-")
+    seeds += list(criterion.grads)
+    # loss.backward(): the criterion has already produced d loss / d prediction for every prediction
+    torch.autograd.backward(list(preds_a) + list(preds_b), seeds)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(optimizer.grad, op=dist.ReduceOp.SUM, group=group)
+    norm = clip_grad_norm_(optimizer, clip)
+    optimizer.step()
+    scheduler.step()
+    return loss_a + loss_b, {**metrics_a, **metrics_b, "grad_norm": norm}

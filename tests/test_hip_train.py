@@ -1,4 +1,4 @@
-"""GPU tests of the training-step counterpart (everything except the network's backward):
+"""GPU tests of the training-step counterpart (the network's backward: test_hip_train_step.py):
 uniform_loss, rotate_gt, fetch_optimizer (FlatAdamW + OneCycleLinearLR), clip_grad_norm_ against the
 reference-generated goldens in tests/golden/train.npz."""
 import argparse
@@ -57,13 +57,14 @@ def test_fetch_optimizer_trajectory_vs_reference():
             s2.step()
 
 
-def test_train_mode_forward_still_raises():
-    """The backward kernels are not built: the drop-in module must fail loudly, not fall back."""
+def test_train_mode_forward_needs_a_device():
+    """No CPU path: the training forward fails loudly on CPU tensors instead of falling back."""
+    from prior_flow_amd import _lib
     from prior_flow_amd.modules import state_dict_shapes
     from prior_flow_amd.prior_raft import PriOr_RAFT
     m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
     m.load_state_dict(gc.det_state_dict(state_dict_shapes()), strict=True)
-    m = m.cuda().train()
+    m = m.train()
     i1, i2 = gc.synthetic_pair(1, 128, 256)
-    with pytest.raises(NotImplementedError):
-        m(i1.cuda(), i2.cuda(), iters=2)
+    with pytest.raises(_lib.PfError):
+        m(i1, i2, iters=2)
