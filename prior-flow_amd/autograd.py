@@ -39,13 +39,15 @@ STATS = {"hip": 0, "torch": 0}          # launches routed to the HIP library / l
 
 
 def _rows(x: torch.Tensor) -> torch.Tensor:
-    """NCHW -> channel-last rows [B*H*W, C]."""
+    """NCHW (logical) -> channel-last rows [B*H*W, C]; a view when x already has channels_last strides."""
     B, C, H, W = x.shape
     return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
 
 
 def _nchw(rows: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
-    return rows.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+    """Channel-last rows -> logical NCHW with channels_last strides (no copy): the kernels' layout IS the
+    tape's memory format, torch's elementwise ops / cat preserve it, and _rows() of the result is free."""
+    return rows.view(B, H, W, -1).permute(0, 3, 1, 2)
 
 
 # weight packs of one training step, keyed by (storage, version): a conv that runs 2 x iters times packs once
@@ -83,20 +85,23 @@ class HipConv(torch.autograd.Function):
         xr = _rows(x.detach())
         cv = _pack(w, b, "fwd")
         cp = (cout + 3) // 4 * 4
-        out = torch.zeros(B * H * W, cp, device=x.device)
+        out = (torch.empty if cp == cout else torch.zeros)(B * H * W, cp, device=x.device)
         lib.conv2d([cv.desc(xr, 0, C, out, 0, EPI_LINEAR)], B, H, W, xr)
         ctx.save_for_backward(xr, w)
         ctx.shape = (B, C, H, W, cout, kh, kw, cp)
         STATS["hip"] += 1
-        return _nchw(out[:, :cout], B, H, W)
+        return _nchw(out if cp == cout else out[:, :cout].contiguous(), B, H, W)
 
     @staticmethod
     def backward(ctx, gy):
         lib = _lib.load()
         xr, w = ctx.saved_tensors
         B, C, H, W, cout, kh, kw, cp = ctx.shape
-        dy = torch.zeros(B * H * W, cp, device=gy.device)
-        dy[:, :cout] = _rows(gy)
+        if cp == cout:
+            dy = _rows(gy)
+        else:
+            dy = torch.zeros(B * H * W, cp, device=gy.device)
+            dy[:, :cout] = _rows(gy)
         dx = None
         if ctx.needs_input_grad[0]:
             dg = _pack(w, None, "dgrad")
@@ -245,25 +250,29 @@ class HipWarpGcorr(torch.autograd.Function):
 
 
 class HipGruGates(torch.autograd.Function):
-    """z = sigmoid(az), r = sigmoid(ar), rh = r * h (core/update.py:49-51, :56-58); backward = pf_gru_zr_bwd."""
+    """z = sigmoid(az), r = sigmoid(ar), rh = r * h (core/update.py:49-51, :56-58) on the output [az | ar] of the
+    fused z|r convolution; backward = pf_gru_zr_bwd, which writes the gradient of [az | ar] in one piece."""
 
     @staticmethod
-    def forward(ctx, az, ar, h):
-        z, r = torch.sigmoid(az), torch.sigmoid(ar)
-        ctx.save_for_backward(_rows(z), _rows(r), _rows(h))
-        ctx.shape = az.shape
+    def forward(ctx, azr, h):
+        Cc = h.shape[1]
+        zr = torch.sigmoid(azr)
+        z, r = zr[:, :Cc], zr[:, Cc:]
+        zr_rows = _rows(zr)
+        ctx.save_for_backward(zr_rows, _rows(h))
+        ctx.shape = h.shape
         return z, r * h
 
     @staticmethod
     def backward(ctx, dz, d_rh):
         lib = _lib.load()
-        z, r, h = ctx.saved_tensors
+        zr, h = ctx.saved_tensors
         B, Cc, H, W = ctx.shape
         dzr = torch.empty(B * H * W, 2 * Cc, device=dz.device)
         dh = torch.zeros(B * H * W, Cc, device=dz.device)
-        lib.gru_zr_bwd(_rows(dz), _rows(d_rh), z, r, h, dzr, dh)
+        lib.gru_zr_bwd(_rows(dz), _rows(d_rh), zr[:, :Cc], zr[:, Cc:], h, dzr, dh)
         STATS["hip"] += 1
-        return _nchw(dzr[:, :Cc].contiguous(), B, H, W), _nchw(dzr[:, Cc:].contiguous(), B, H, W), _nchw(dh, B, H, W)
+        return _nchw(dzr, B, H, W), _nchw(dh, B, H, W)
 
 
 class HipGruBlend(torch.autograd.Function):
@@ -335,11 +344,22 @@ def encoder_forward(enc, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def sepconv_gru(gru, h: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def fuse_zr(gru) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
+    """convz | convr of a SepConvGRU half share their input (core/update.py:48-49, :55-56): one convolution with
+    the output channels concatenated.  Built once per forward; autograd splits the gradient back into the four
+    parameters through the cat nodes."""
+    out = {}
+    for tag in ("1", "2"):
+        cz, cr = getattr(gru, "convz" + tag), getattr(gru, "convr" + tag)
+        out[tag] = (torch.cat([cz.weight, cr.weight], 0), torch.cat([cz.bias, cr.bias], 0))
+    return out
+
+
+def sepconv_gru(gru, zr: Dict[str, Tuple[torch.Tensor, torch.Tensor]], h: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """SepConvGRU.forward (core/update.py:45-60)."""
     for tag in ("1", "2"):
         hx = torch.cat([h, x], 1)
-        z, rh = HipGruGates.apply(conv2d(hx, getattr(gru, "convz" + tag)), conv2d(hx, getattr(gru, "convr" + tag)), h)
+        z, rh = HipGruGates.apply(HipConv.apply(hx, *zr[tag]), h)
         h = HipGruBlend.apply(z, conv2d(torch.cat([rh, x], 1), getattr(gru, "convq" + tag)), h)
     return h
 
@@ -350,18 +370,18 @@ def _heads(blk, net: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return mask, delta
 
 
-def update_block_b(blk, net, inp, corr, flow):
+def update_block_b(blk, zr, net, inp, corr, flow):
     """BasicUpdateBlock.forward + BasicMotionEncoder.forward (core/update.py:91-99, :129-136)."""
     e = blk.encoder
     cor = torch.relu(conv2d(torch.relu(conv2d(corr, e.convc1)), e.convc2))
     flo = torch.relu(conv2d(torch.relu(conv2d(flow, e.convf1)), e.convf2))
     out = torch.relu(conv2d(torch.cat([cor, flo], 1), e.conv))
-    net = sepconv_gru(blk.gru, net, torch.cat([inp, out, flow], 1))
+    net = sepconv_gru(blk.gru, zr, net, torch.cat([inp, out, flow], 1))
     mask, delta = _heads(blk, net)
     return net, mask, delta
 
 
-def update_block_a(blk, net, inp, flow_a, corr_a, flaw_a, flow_ba, flaw_ba):
+def update_block_a(blk, zr, net, inp, flow_a, corr_a, flaw_a, flow_ba, flaw_ba):
     """BasicMultiUpdateBlock.forward + BasicMultiMotionEncoder.forward (core/update.py:152-159, :183-201)."""
     e = blk.encoder
     cor = torch.relu(conv2d(torch.relu(conv2d(corr_a, e.convc1_A)), e.convc2_A))
@@ -369,7 +389,7 @@ def update_block_a(blk, net, inp, flow_a, corr_a, flaw_a, flow_ba, flaw_ba):
     flo_b = torch.relu(conv2d(torch.relu(conv2d(flow_ba, e.convf1_B)), e.convf2_B))
     conf = torch.relu(conv2d(torch.relu(conv2d(torch.cat([flaw_a, flaw_ba], 1), e.conv_conf1)), e.conv_conf2))
     out = torch.relu(conv2d(torch.cat([cor, flo_a, flo_b, conf], 1), e.conv_A))
-    net = sepconv_gru(blk.gru, net, torch.cat([inp, out, flow_a, flow_ba], 1))
+    net = sepconv_gru(blk.gru, zr, net, torch.cat([inp, out, flow_a, flow_ba], 1))
     mask, delta = _heads(blk, net)
     return net, mask, delta
 
@@ -423,6 +443,7 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
     pyr_a = HipCorrPyramid.apply(f1a, f2a)                                                      # :151-159
     pyr_b = HipCorrPyramid.apply(f1b, f2b)
 
+    zr_a, zr_b = fuse_zr(model.ODDC.gru), fuse_zr(model.update_block.gru)
     c1a, c1b = coords0.clone(), coords0.clone()
     if init_flow is not None:                                                                   # :162-165
         with torch.no_grad():
@@ -442,8 +463,8 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
         flaw_ba = HipWarpGcorr.apply(f1a, f2a, c_ba)                                            # :181-182
         corr_a = HipDccl.apply(c1a, g_b2a_8, g_b2a_8, *pyr_a, *pyr_b)                           # :185, :187
         corr_b = HipDccl.apply(c1b, g_a2b_8, g_a2b_8, *pyr_b, *pyr_a)                           # :186, :188
-        net_a, mask_a, delta_a = update_block_a(model.ODDC, net_a, inp_a, flow_a, corr_a, flaw_a, flow_ba, flaw_ba)
-        net_b, mask_b, delta_b = update_block_b(model.update_block, net_b, inp_b, corr_b, flow_b)
+        net_a, mask_a, delta_a = update_block_a(model.ODDC, zr_a, net_a, inp_a, flow_a, corr_a, flaw_a, flow_ba, flaw_ba)
+        net_b, mask_b, delta_b = update_block_b(model.update_block, zr_b, net_b, inp_b, corr_b, flow_b)
         c1a = c1a + delta_a                                                                     # :193-197
         c1b = c1b + delta_b
         preds_a.append(HipUpsample.apply(c1a - coords0, mask_a, coords0))                       # :200-208

@@ -523,8 +523,72 @@ int launch_region_sums(const PfRegionSumArgs& a, void* stream) {
     return (int)hipGetLastError();
 }
 
+// Backward of the convex upsampling on a wavefront: one coarse pixel per wave, lane = sub-pixel 8i + j.
+// The 9 softmax logits of a lane are 9 coalesced 256-byte rows of the mask (the per-element version read them
+// at a 2.3 KB stride) and the 64 contributions to each of the 9 neighbours' coarse-flow gradients are summed
+// with a butterfly before ONE atomic per (neighbour, component) instead of 64 colliding ones.
+// Same arithmetic per lane as pf_upsample_bwd_elem (pf_elem.h), which stays the emulated / checked statement.
+__global__ void __launch_bounds__(kBlock) pf_upsample_bwd_wave(const PfUpsampleBwdArgs a, const long rows) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane >> 3, j = lane & 7;
+    const long N = (long)a.H * a.W;
+    const int W8 = 8 * a.W;
+    const long plane = (long)W8 * 8 * a.H;
+    long prow = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * (kBlock / 64);
+    for (; prow < rows; prow += stride) {
+        const long b = prow / N;
+        const int n = (int)(prow % N);
+        const int y = n / a.W, x = n % a.W;
+        const long fine = (long)(8 * y + i) * W8 + 8 * x + j;
+        const float gu = a.g[(b * 2 + 0) * plane + fine], gv = a.g[(b * 2 + 1) * plane + fine];
+        const float* mrow = a.mask + prow * a.ld + lane;
+        float w[9], sk[9];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { w[k] = mrow[64 * k]; mx = fmaxf(mx, w[k]); }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { w[k] = expf(w[k] - mx); den = den + w[k]; }
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+            w[k] = w[k] / den;
+            sk[k] = 0.f;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {      // wave-uniform
+                const long p = (long)yy * a.W + xx;
+                const float fu = 8.f * (a.coords1[(b * 2 + 0) * N + p] - (float)xx);
+                const float fv = 8.f * (a.coords1[(b * 2 + 1) * N + p] - (float)yy);
+                sk[k] = gu * fu + gv * fv;
+                float su = 8.f * w[k] * gu, sv = 8.f * w[k] * gv;
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) { su += __shfl_xor(su, m); sv += __shfl_xor(sv, m); }
+                if (lane == 0) {
+                    atomicAdd(a.d_flow + (b * 2 + 0) * N + p, su);
+                    atomicAdd(a.d_flow + (b * 2 + 1) * N + p, sv);
+                }
+            }
+            dot = dot + w[k] * sk[k];
+        }
+        float* drow = a.d_mask + prow * a.ld_d + lane;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) drow[64 * k] = w[k] * (sk[k] - dot);
+    }
+}
+
+int launch_upsample_bwd(const PfUpsampleBwdArgs& a, long total, void* stream) {
+    const long rows = total / 64;
+    if (rows <= 0) return PF_OK;
+    long blocks = (rows + 3) / 4;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(pf_upsample_bwd_wave, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, rows);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
+#define PF_UPSAMPLE_BWD_LAUNCH(a, total, stream) launch_upsample_bwd(a, total, stream)
 #define PF_REGION_SUM_LAUNCH(a, stream) launch_region_sums(a, stream)
 #define PF_SEQ_LOSS_LAUNCH(a, stream) launch_seq_loss(a, stream)
 #define PF_SUMSQ_LAUNCH(a, stream) launch_sumsq(a, stream)
