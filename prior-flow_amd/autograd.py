@@ -127,11 +127,31 @@ def conv2d(x: torch.Tensor, m: nn.Conv2d) -> torch.Tensor:
     return F.conv2d(x, m.weight, m.bias, stride=m.stride, padding=m.padding)
 
 
+class PyramidGrad:
+    """Gradient accumulator of one branch's pyramid for one backward pass.  Every DCCL lookup of every iteration
+    scatters straight into these four buffers (pf_dccl_lookup_bwd accumulates) instead of handing autograd a
+    pyramid-sized tensor per call to add up: at 384x512 that was 8 zero fills and 8 adds of up to 38 MB per lookup."""
+
+    def __init__(self):
+        self.g: Optional[List[torch.Tensor]] = None
+
+    def buffers(self, like: List[torch.Tensor]) -> List[torch.Tensor]:
+        if self.g is None:
+            self.g = [torch.zeros_like(t) for t in like]
+        return self.g
+
+    def take(self) -> Optional[List[torch.Tensor]]:
+        g, self.g = self.g, None
+        return g
+
+
 class HipCorrPyramid(torch.autograd.Function):
-    """corr + build_pyramid (core/prior_raft.py:69-75, core/corr.py:99-111)."""
+    """corr + build_pyramid (core/prior_raft.py:69-75, core/corr.py:99-111).  Returns the four levels
+    ([B*N, H_i*W_i] rows, not differentiable as tensors) and a one-element token: the lookups take the token as an
+    input, which orders this node's backward after all of theirs, and leave the levels' gradient in ``acc``."""
 
     @staticmethod
-    def forward(ctx, f1, f2):
+    def forward(ctx, f1, f2, acc):
         lib = _lib.load()
         B, C, H, W = f1.shape
         n = H * W
@@ -142,42 +162,45 @@ class HipCorrPyramid(torch.autograd.Function):
         lib.corr_pyramid_bf16x3(sp[0], sp[1], lv, B, H, W, C)
         ctx.save_for_backward(r1, r2)
         ctx.shape = (B, C, H, W)
+        ctx.acc = acc
+        ctx.mark_non_differentiable(*lv)
         STATS["hip"] += 1
-        return tuple(lv)
+        return (*lv, torch.zeros(1, device=f1.device))
 
     @staticmethod
-    def backward(ctx, *g):
+    def backward(ctx, *_):
         lib = _lib.load()
         r1, r2 = ctx.saved_tensors
         B, C, H, W = ctx.shape
         n = H * W
-        gl = [torch.zeros(B * n, (H >> i) * (W >> i), device=r1.device) if x is None
-              else x.reshape(B * n, -1).contiguous().clone() for i, x in enumerate(g)]
-        dv = lib.pyramid_bwd(gl, B, H, W).view(B, n, n)
+        gl = ctx.acc.take()
+        if gl is None:                       # no lookup contributed a gradient
+            return torch.zeros(B, C, H, W, device=r1.device), torch.zeros(B, C, H, W, device=r1.device), None
+        dv = lib.pyramid_bwd(gl, B, H, W).view(B, n, n)       # level 0 becomes the dense volume gradient, in place
         s = 1.0 / math.sqrt(C)
         d1 = torch.bmm(dv, r2.view(B, n, C)) * s
         d2 = torch.bmm(dv.transpose(1, 2), r1.view(B, n, C)) * s
         STATS["hip"] += 1
-        return _nchw(d1.reshape(B * n, C), B, H, W), _nchw(d2.reshape(B * n, C), B, H, W)
+        return _nchw(d1.reshape(B * n, C), B, H, W), _nchw(d2.reshape(B * n, C), B, H, W), None
 
 
 class HipDccl(torch.autograd.Function):
     """DCCL.__call__ (core/corr.py:113-144), own + rotated-back cross lookup summed (prior_raft.py:187-188).
-    Pyramid levels are [B*N, H_i*W_i] rows; the coordinates carry no gradient (detached, prior_raft.py:171,176)."""
+    Pyramid levels are [B*N, H_i*W_i] rows; the coordinates carry no gradient (detached, prior_raft.py:171,176).
+    ``own`` / ``other`` are (levels, token, PyramidGrad) triples of HipCorrPyramid."""
 
     @staticmethod
-    def forward(ctx, coords, g_w2c, g_back, *pyr):
+    def forward(ctx, coords, g_w2c, g_back, tok_own, tok_other, own, other):
         lib = _lib.load()
         B, _, H, W = coords.shape
         n = H * W
-        own_p = [p.detach() for p in pyr[:4]]
-        oth_p = [p.detach() for p in pyr[4:]]
-        own, raw, out = (torch.empty(B * n, 324, device=coords.device) for _ in range(3))
+        own_out, raw, out = (torch.empty(B * n, 324, device=coords.device) for _ in range(3))
         co = coords.detach().contiguous()
-        lib.dccl_lookup(co, own_p, oth_p, g_w2c, own, raw)
-        lib.dccl_combine(own, raw, g_back, out, B, H, W)
+        lib.dccl_lookup(co, own[0], other[0], g_w2c, own_out, raw)
+        lib.dccl_combine(own_out, raw, g_back, out, B, H, W)
         ctx.save_for_backward(co, g_w2c, g_back)
         ctx.dims = (B, H, W)
+        ctx.own, ctx.other = own, other
         STATS["hip"] += 2
         return _nchw(out, B, H, W)
 
@@ -190,11 +213,21 @@ class HipDccl(torch.autograd.Function):
         d_corr = _rows(g)
         d_raw = torch.zeros(B * n, 324, device=g.device)
         lib.dccl_combine_bwd(d_corr, g_back, d_raw, B, H, W)
-        g_own = [torch.zeros(B * n, (H >> i) * (W >> i), device=g.device) for i in range(4)]
-        g_oth = [torch.zeros(B * n, (H >> i) * (W >> i), device=g.device) for i in range(4)]
-        lib.dccl_lookup_bwd(co, g_w2c, d_corr, d_raw, g_own, g_oth)
+        lib.dccl_lookup_bwd(co, g_w2c, d_corr, d_raw, ctx.own[2].buffers(ctx.own[0]), ctx.other[2].buffers(ctx.other[0]))
         STATS["hip"] += 2
-        return (None, None, None, *g_own, *g_oth)
+        zero = torch.zeros(1, device=g.device)
+        return None, None, None, zero, zero, None, None
+
+
+def corr_pyramid(f1: torch.Tensor, f2: torch.Tensor):
+    """-> (levels, token, PyramidGrad) of one branch."""
+    acc = PyramidGrad()
+    *lv, tok = HipCorrPyramid.apply(f1, f2, acc)
+    return list(lv), tok, acc
+
+
+def dccl(coords, g_w2c, g_back, own, other) -> torch.Tensor:
+    return HipDccl.apply(coords, g_w2c, g_back, own[1], other[1], own, other)
 
 
 class HipUpsample(torch.autograd.Function):
@@ -440,8 +473,8 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
     net_b, inp_b = torch.tanh(cnet[B:, :128]), torch.relu(cnet[B:, 128:])
     fm = encoder_forward(model.fnet, torch.cat([i1, i2, i1b, i2b], 0)).float()                  # :144-149
     f1a, f2a, f1b, f2b = fm[:B], fm[B:2 * B], fm[2 * B:3 * B], fm[3 * B:]
-    pyr_a = HipCorrPyramid.apply(f1a, f2a)                                                      # :151-159
-    pyr_b = HipCorrPyramid.apply(f1b, f2b)
+    pyr_a = corr_pyramid(f1a, f2a)                                                              # :151-159
+    pyr_b = corr_pyramid(f1b, f2b)
 
     zr_a, zr_b = fuse_zr(model.ODDC.gru), fuse_zr(model.update_block.gru)
     c1a, c1b = coords0.clone(), coords0.clone()
@@ -461,8 +494,8 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
             c_ba = (coords0 + flow_ba).contiguous()
         flaw_a = HipWarpGcorr.apply(f1a, f2a, c1a)                                              # :173-174
         flaw_ba = HipWarpGcorr.apply(f1a, f2a, c_ba)                                            # :181-182
-        corr_a = HipDccl.apply(c1a, g_b2a_8, g_b2a_8, *pyr_a, *pyr_b)                           # :185, :187
-        corr_b = HipDccl.apply(c1b, g_a2b_8, g_a2b_8, *pyr_b, *pyr_a)                           # :186, :188
+        corr_a = dccl(c1a, g_b2a_8, g_b2a_8, pyr_a, pyr_b)                                      # :185, :187
+        corr_b = dccl(c1b, g_a2b_8, g_a2b_8, pyr_b, pyr_a)                                      # :186, :188
         net_a, mask_a, delta_a = update_block_a(model.ODDC, zr_a, net_a, inp_a, flow_a, corr_a, flaw_a, flow_ba, flaw_ba)
         net_b, mask_b, delta_b = update_block_b(model.update_block, zr_b, net_b, inp_b, corr_b, flow_b)
         c1a = c1a + delta_a                                                                     # :193-197
