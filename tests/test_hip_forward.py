@@ -146,13 +146,26 @@ def test_forward_full_size_vs_oracle(model, params):
     assert mean < EPE_BAR, (mean, mx)
 
 
-def test_training_mode_raises(model):
+def test_training_mode_returns_differentiable_predictions(model):
+    """train() + autograd on -> the HIP autograd tape (prior_flow_amd.autograd); same values as the inference engine."""
+    i1, i2 = gc.synthetic_pair(1, 128, 256)
+    i1, i2 = i1.cuda(), i2.cuda()
+    with torch.no_grad():
+        want_a, want_b = model(i1, i2, iters=2)                 # eval-mode workspace engine, all predictions
     model.train()
+    model.freeze_bn()            # train_flow.py:107-108: BatchNorm keeps its running statistics
     try:
-        x = torch.zeros(1, 3, 128, 256, device="cuda")
-        with pytest.raises(NotImplementedError):
-            model(x, x, iters=1)
+        pa, pb = model(i1, i2, iters=2)
+        assert len(pa) == 2 and len(pb) == 2 and all(p.requires_grad and p.shape == (1, 2, 128, 256) for p in pa + pb)
+        for got, want in zip(pa + pb, want_a + want_b):
+            assert float((got.detach() - want).norm(dim=1).mean()) < EPE_BAR
+        (pa[-1].abs().sum() + pb[-1].abs().sum()).backward()
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        assert len(grads) > 150 and all(torch.isfinite(g).all() for g in grads)
+        flow = model(i1, i2, iters=2, test_mode=True)           # reference returns the last prediction of branch A
+        assert flow.requires_grad and float((flow.detach() - want_a[-1]).norm(dim=1).mean()) < EPE_BAR
     finally:
+        model.zero_grad(set_to_none=True)
         model.eval()
 
 
