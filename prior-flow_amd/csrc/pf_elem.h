@@ -131,6 +131,13 @@ PF_HD PfTaps2 pf_taps0v(float x, float y, int H, int W) {      // W >= 2
     t.w[3] = (xin1 && yin1) ? wy * wx : 0.f;
     return t;
 }
+PF_HD float pf_apply_pairs(const PfTaps2& t, const PfPair p0, const PfPair p1) {
+    float acc = (t.s0hi ? p0.b : p0.a) * t.w[0];
+    acc = acc + (t.s1lo ? p0.a : p0.b) * t.w[1];
+    acc = acc + (t.s0hi ? p1.b : p1.a) * t.w[2];
+    acc = acc + (t.s1lo ? p1.a : p1.b) * t.w[3];
+    return acc;
+}
 PF_HD float pf_apply_v(const PfTaps2& t, const float* img) {
     const PfPair p0 = pf_load2(img + t.r0), p1 = pf_load2(img + t.r1);
     float acc = (t.s0hi ? p0.b : p0.a) * t.w[0];
@@ -305,10 +312,18 @@ struct PfLookupArgs {
     int B, H, W, ld;
 };
 // One call = PF_LOOKUP_TPT consecutive taps (same level, same slow index a): their gather chains
-// (coords -> grid taps -> other-volume taps) are independent, so the loads of all three are in
-// flight together -- the kernel is bound by 3 dependent global round trips, not by bandwidth.
+// (coords -> grid taps -> other-volume taps) are independent, so the loads of all of them are in
+// flight together.  Timing-only ablations (profiles/scratch/ablate_lookup.sh) showed the kernel bound by the
+// NUMBER of gather instructions, cache-resident ones included (no own-window loads -7 us, no grid loads -9 us,
+// no other-volume loads -4 us, no stores -3 us of 32 us).  Consecutive taps of a column share a row (the lower
+// row of tap j is the upper row of tap j+1), so a row pair is loaded once and reused when its ADDRESS matches --
+// same address, same value: results are bit-identical to per-tap loads.  Own window and the two grid components:
+// 4 loads per 3 taps instead of 6 each.  Measured in one call (profiles/scratch/ab_lookup_tpt.sh): 32.8 us without
+// reuse, 27.4 us with it at 3 taps per call, 43 us at 9 taps per call (a whole column: too few, too fat threads).
+#ifndef PF_LOOKUP_TPT
 #define PF_LOOKUP_TPT 3
-PF_HD void pf_lookup_elem(long idx, const PfLookupArgs& a) {  // idx over B*N*(324/3)
+#endif
+PF_HD void pf_lookup_elem(long idx, const PfLookupArgs& a) {  // idx over B*N*(324/TPT)
     const long N = (long)a.H * a.W;
     const int per_row = PF_CORR_CH / PF_LOOKUP_TPT;
     const int k0 = (int)(idx % per_row) * PF_LOOKUP_TPT;
@@ -327,18 +342,48 @@ PF_HD void pf_lookup_elem(long idx, const PfLookupArgs& a) {  // idx over B*N*(3
     // grid (core/corr.py:132-133), and the result indexes row n of the OTHER branch's volume (:135-136)
     const float xo = pf_pymod(cx, (float)Wl), xg = pf_pymod(cx, (float)a.W);
     float gx[PF_LOOKUP_TPT], gy[PF_LOOKUP_TPT], vo[PF_LOOKUP_TPT];
+    int ro = -1, rg = -1;                              // addresses of the row pairs carried from the previous tap
+    PfPair po = {0.f, 0.f}, pgx = {0.f, 0.f}, pgy = {0.f, 0.f};
     for (int j = 0; j < PF_LOOKUP_TPT; ++j) {
         const float cy = cy0 + (float)(tb0 + j - PF_CORR_RADIUS);
         const PfTaps2 t = pf_taps0v(xo, cy, Hl, Wl);
-        vo[j] = pf_apply_v(t, own);
+#ifdef PF_ABL_NO_OWN          // timing-only ablations; never defined in the product build
+        vo[j] = t.w[0] + cy;
+#else
+        {
+            const PfPair p0 = (t.r0 == ro) ? po : pf_load2(own + t.r0);
+            const PfPair p1 = pf_load2(own + t.r1);
+            vo[j] = pf_apply_pairs(t, p0, p1);
+            ro = t.r1; po = p1;
+        }
+#endif
         const PfTaps2 tg = pf_taps0v(xg, cy, a.H, a.W);
-        gx[j] = pf_apply_v(tg, a.g_w2c);
-        gy[j] = pf_apply_v(tg, a.g_w2c + N);
+#ifdef PF_ABL_NO_GRID
+        gx[j] = xg + tg.w[0]; gy[j] = cy + tg.w[1];
+#else
+        {
+            const bool hit = tg.r0 == rg;
+            const PfPair x0 = hit ? pgx : pf_load2(a.g_w2c + tg.r0);
+            const PfPair y0 = hit ? pgy : pf_load2(a.g_w2c + N + tg.r0);
+            const PfPair x1 = pf_load2(a.g_w2c + tg.r1), y1 = pf_load2(a.g_w2c + N + tg.r1);
+            gx[j] = pf_apply_pairs(tg, x0, x1);
+            gy[j] = pf_apply_pairs(tg, y0, y1);
+            rg = tg.r1; pgx = x1; pgy = y1;
+        }
+#endif
     }
     for (int j = 0; j < PF_LOOKUP_TPT; ++j) {
         const PfTaps2 t = pf_taps0v(pf_pymod(gx[j], (float)Wl), gy[j], Hl, Wl);
+#ifndef PF_ABL_NO_STORE
         a.own_out[row * a.ld + k0 + j] = vo[j];
+#endif
+#ifdef PF_ABL_NO_OTH
+        a.raw_out[row * a.ld + k0 + j] = t.w[0] + t.w[3] + vo[j];
+#elif defined(PF_ABL_NO_STORE)
+        if (pf_apply_v(t, oth) + vo[j] == 123.456f) a.raw_out[row * a.ld + k0 + j] = 1.f;
+#else
         a.raw_out[row * a.ld + k0 + j] = pf_apply_v(t, oth);
+#endif
     }
 }
 

@@ -577,6 +577,46 @@ __global__ void __launch_bounds__(kBlock) pf_upsample_bwd_wave(const PfUpsampleB
     }
 }
 
+// K4(c) four channels per thread: the taps (g_back) are per pixel, so a thread's four corner reads and its store are
+// 16-byte accesses of one channel-last row.  Same per-element arithmetic and order as pf_combine_elem (pf_elem.h).
+__global__ void __launch_bounds__(kBlock) pf_combine_vec4(const PfCombineArgs a, const long total) {   // total = rows * 81
+    const long N = (long)a.H * a.W;
+    long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long stride = (long)gridDim.x * kBlock;
+    for (; idx < total; idx += stride) {
+        const int k = (int)(idx % (PF_CORR_CH / 4)) * 4;
+        const long row = idx / (PF_CORR_CH / 4);
+        const long b = row / N, n = row % N;
+        const PfTaps t = pf_taps0(pf_pymod(a.g_back[n], (float)a.W), a.g_back[N + n], a.H, a.W);
+        const float* base = a.raw + b * N * a.ld + k;
+        const float4 r0 = *reinterpret_cast<const float4*>(base + (long)t.idx[0] * a.ld);
+        const float4 r1 = *reinterpret_cast<const float4*>(base + (long)t.idx[1] * a.ld);
+        const float4 r2 = *reinterpret_cast<const float4*>(base + (long)t.idx[2] * a.ld);
+        const float4 r3 = *reinterpret_cast<const float4*>(base + (long)t.idx[3] * a.ld);
+        const float4 o = *reinterpret_cast<const float4*>(a.own + row * a.ld + k);
+        float4 c;
+        c.x = r0.x * t.w[0]; c.x = c.x + r1.x * t.w[1]; c.x = c.x + r2.x * t.w[2]; c.x = c.x + r3.x * t.w[3];
+        c.y = r0.y * t.w[0]; c.y = c.y + r1.y * t.w[1]; c.y = c.y + r2.y * t.w[2]; c.y = c.y + r3.y * t.w[3];
+        c.z = r0.z * t.w[0]; c.z = c.z + r1.z * t.w[1]; c.z = c.z + r2.z * t.w[2]; c.z = c.z + r3.z * t.w[3];
+        c.w = r0.w * t.w[0]; c.w = c.w + r1.w * t.w[1]; c.w = c.w + r2.w * t.w[2]; c.w = c.w + r3.w * t.w[3];
+        float4 out;
+        out.x = o.x + c.x; out.y = o.y + c.y; out.z = o.z + c.z; out.w = o.w + c.w;
+        *reinterpret_cast<float4*>(a.out + row * a.ld_out + k) = out;
+    }
+}
+
+int launch_combine(const PfCombineArgs& a, long total, void* stream) {
+    const bool vec = (a.ld % 4 == 0) && (a.ld_out % 4 == 0) &&
+                     ((((uintptr_t)a.own) | ((uintptr_t)a.raw) | ((uintptr_t)a.out)) % 16 == 0);
+    if (!vec) return pf_launch_elem<PfCombineArgs, pf_combine_elem>(a, total, stream);
+    const long n4 = total / 4;
+    if (n4 <= 0) return PF_OK;
+    long blocks = (n4 + kBlock - 1) / kBlock;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(pf_combine_vec4, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, n4);
+    return (int)hipGetLastError();
+}
+
 int launch_upsample_bwd(const PfUpsampleBwdArgs& a, long total, void* stream) {
     const long rows = total / 64;
     if (rows <= 0) return PF_OK;
@@ -589,6 +629,7 @@ int launch_upsample_bwd(const PfUpsampleBwdArgs& a, long total, void* stream) {
 }  // namespace
 
 #define PF_UPSAMPLE_BWD_LAUNCH(a, total, stream) launch_upsample_bwd(a, total, stream)
+#define PF_COMBINE_LAUNCH(a, total, stream) launch_combine(a, total, stream)
 #define PF_REGION_SUM_LAUNCH(a, stream) launch_region_sums(a, stream)
 #define PF_SEQ_LOSS_LAUNCH(a, stream) launch_seq_loss(a, stream)
 #define PF_SUMSQ_LAUNCH(a, stream) launch_sumsq(a, stream)
