@@ -207,6 +207,85 @@ __global__ void __launch_bounds__(256) pf_small_conv_mfma(const PfSmallConvMulti
     }
 }
 
+// 7x7 convolution over TWO input channels (the motion encoders' flow stems, core/update.py:87,173,175: 2 -> 128, K = 98) on
+// the vector ALUs.  The MFMA formulation above spends its time in per-workgroup round trips (weights, patch, LDS reduction of a
+// K split: 39 us for the three stems of an iteration, 0.6 GFLOP); here a lane owns one output pixel and CPW output channels,
+// the weights of a tap are wave-uniform (scalar loads feeding v_fmac_f32 directly), the 7 x 70 x 2 input patch of a 64-pixel
+// row segment sits in LDS as one 8-byte read per (row, tap column), and nothing is reduced across lanes or waves.
+// One workgroup = 2 waves = 64 pixels x 2*CPW channels; blockIdx.y = problem (up to 4 same-shape stems per launch).
+// Still bound by the latency of the scalar weight loads, not by the 7.8 us of FMA work; in the forward the stems sit on a
+// side stream, so halving them moved the wall time by only +0.3 % (same-box A/B).
+template <int CPW>
+__global__ void __launch_bounds__(128) pf_stem7x7c2_valu(const PfSmallConvMulti multi) {
+    const PfSmallConvArgs& a = multi.p[blockIdx.y];
+    constexpr int PWD = 64 + 6;
+    __shared__ __attribute__((aligned(16))) float patch[7 * PWD * 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int segs = (a.W + 63) / 64;
+    const int cgroups = a.Cout / (2 * CPW);
+    long item = blockIdx.x;
+    const int cg = (int)(item % cgroups); item /= cgroups;
+    const int sx = (int)(item % segs); item /= segs;
+    const int y = (int)(item % a.H);
+    const long b = item / a.H;
+    const int x0 = sx * 64 - 3;
+    for (int e = tid; e < 7 * PWD * 2; e += 128) {
+        const int c = e & 1, px = (e >> 1) % PWD, ky = (e >> 1) / PWD;
+        const int yy = y + ky - 3, xx = x0 + px;
+        float v = 0.f;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+            v = a.in[((b * a.H + yy) * (long)a.W + xx) * a.ld_in + a.c_in_off + c];
+        patch[e] = v;
+    }
+    __syncthreads();
+    const int co0 = cg * 2 * CPW + wave * CPW;
+    float acc[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) acc[i] = a.bias[co0 + i];
+    const float* wbase = a.w + co0;
+    for (int ky = 0; ky < 7; ++ky) {
+        float2 in[7];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) in[kx] = *reinterpret_cast<const float2*>(&patch[(ky * PWD + lane + kx) * 2]);
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const float* w0 = wbase + (long)((ky * 7 + kx) * 2) * a.Cout;
+            const float* w1 = w0 + a.Cout;
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) acc[i] = __builtin_fmaf(in[kx].x, w0[i], acc[i]);
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) acc[i] = __builtin_fmaf(in[kx].y, w1[i], acc[i]);
+        }
+    }
+    const int x = sx * 64 + lane;
+    if (x < a.W) {
+        float* o = a.out + ((b * a.H + y) * (long)a.W + x) * a.ld_out + a.c_out_off + co0;
+#pragma unroll
+        for (int i = 0; i < CPW; i += 4) {
+            float4 v;
+            v.x = acc[i]; v.y = acc[i + 1]; v.z = acc[i + 2]; v.w = acc[i + 3];
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(o + i) = v;
+        }
+    }
+}
+
+bool stem7x7c2_ok(const PfSmallConvArgs& a) {
+    return a.KH == 7 && a.KW == 7 && a.Cin == 2 && a.stride == 1 && !a.nchw && a.Cout % 64 == 0 && a.Ho == a.H && a.Wo == a.W &&
+           a.ld_out % 4 == 0 && a.c_out_off % 4 == 0 && ((uintptr_t)a.out) % 16 == 0;
+}
+
+int launch_stem7x7c2(const PfSmallConvMulti& m, int n, void* stream) {
+    const PfSmallConvArgs& a = m.p[0];
+    const long blocks = (long)a.B * a.H * ((a.W + 63) / 64) * (a.Cout / 64);
+    if (blocks <= 0 || blocks >= (1L << 31)) return PF_ERR_BAD_SHAPE;
+    // CPW = 8: 6 waves per SIMD hide the scalar weight loads best (three stems of 64x128: 22.2 / 19.9 / 17.5 us for
+    // CPW = 32 / 16 / 8 against 36.7 us on the MFMA kernel, profiles/scratch/microbench_stem.py)
+    hipLaunchKernelGGL((pf_stem7x7c2_valu<8>), dim3((unsigned)(blocks * 4), (unsigned)n), dim3(128), 0, (hipStream_t)stream, m);
+    return (int)hipGetLastError();
+}
+
 int launch_small_conv(const PfSmallConvMulti& m, int n, void* stream) {
     const PfSmallConvArgs& a = m.p[0];
     const int K = a.KH * a.KW * a.Cin, KS = (K + 1) / 2;
@@ -658,6 +737,9 @@ static int pf_direct_conv_dispatch_n(const PfDirectConvArgs* ds, int n, long tot
             a.Ho = e.H; a.Wo = e.W;
         }
         for (int i = n; i < 4; ++i) m.p[i] = m.p[0];
+        bool valu = true;
+        for (int i = 0; i < n; ++i) valu = valu && stem7x7c2_ok(m.p[i]);
+        if (valu) return launch_stem7x7c2(m, n, stream);
         return launch_small_conv(m, n, stream);
     }
     for (int i = 0; i < n; ++i) {
