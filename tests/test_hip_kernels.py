@@ -314,6 +314,23 @@ def test_small_conv_partial_segments(lib, dev):
         assert float((out[:, 0] - 5.0).abs().max()) == 0.0 and float((out[:, 129] - 5.0).abs().max()) == 0.0
 
 
+def test_flow_stem_valu_kernel_partial_segments(lib, dev):
+    """16-byte aligned outputs take pf_stem7x7c2_valu (64-pixel row segments, lane = pixel): ragged widths, batch 2,
+    an input column offset and a padded input row stride, against torch conv2d (fp32, tolerance 2e-5)."""
+    for H8, W8 in ((17, 27), (9, 45), (6, 120), (5, 200), (64, 128)):
+        x = gc.uni(f"ragv/x{W8}", (2, 2, H8, W8), -3, 3)
+        w = gc.uni("ragv/w", (128, 2, 7, 7), -0.2, 0.2)
+        b = gc.uni("ragv/b", (128,), -0.1, 0.1)
+        want = torch.relu(torch.nn.functional.conv2d(x, w, b, padding=3))
+        xin = torch.full((2 * H8 * W8, 4), 7.0, device=dev)
+        xin[:, 2:4] = kc.cl(x).to(dev)
+        out = torch.full((2 * H8 * W8, 136), 5.0, device=dev)
+        lib.conv2d_direct(xin, 2, 2, w.permute(2, 3, 1, 0).reshape(49, 2, 128).contiguous().to(dev),
+                          b.to(dev), out, 4, 128, 7, 7, True, 2, H8, W8)
+        kc.check(kc.uncl(out[:, 4:132].cpu(), 2, H8, W8), want, 2e-5, f"7x7 VALU stem W8={W8}")
+        assert float((out[:, :4] - 5.0).abs().max()) == 0.0 and float((out[:, 132:] - 5.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 def test_stem_as_space_to_depth_conv(lib, dev, prec):
     """The 7x7 stride-2 stem (core/extractor.py:122) as space-to-depth + 4x4 stride-1 conv (even
