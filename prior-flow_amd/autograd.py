@@ -54,8 +54,17 @@ def _nchw(rows: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
 _PACKS: Dict[tuple, object] = {}
 
 
-def _pack(w: torch.Tensor, b: Optional[torch.Tensor], kind: str):
-    key = (kind, w.data_ptr(), w._version, tuple(w.shape), _lib.weights_epoch())
+def _src_key(*params: torch.Tensor) -> tuple:
+    """Identity of the parameters a (possibly derived) weight tensor was built from."""
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+def _pack(w: torch.Tensor, b: Optional[torch.Tensor], kind: str, src: Optional[tuple] = None):
+    # derived weights (the fused z|r tensors are rebuilt every forward) are keyed by their source parameters: the
+    # allocator may hand a new tensor the address of a freed one, so the tensor's own address proves nothing
+    if src is None:
+        src = _src_key(w) if b is None else _src_key(w, b)
+    key = (kind, src, tuple(w.shape), _lib.weights_epoch())
     hit = _PACKS.get(key)
     if hit is not None:
         return hit
@@ -78,12 +87,13 @@ class HipConv(torch.autograd.Function):
     """Stride-1 'same' convolution with bias: pf_conv2d forward, pf_conv2d (dgrad) + pf_conv2d_wgrad backward."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, src=None):
         lib = _lib.load()
         B, C, H, W = x.shape
         cout, _, kh, kw = w.shape
         xr = _rows(x.detach())
-        cv = _pack(w, b, "fwd")
+        cv = _pack(w, b, "fwd", src)
+        ctx.src = src
         cp = (cout + 3) // 4 * 4
         out = (torch.empty if cp == cout else torch.zeros)(B * H * W, cp, device=x.device)
         lib.conv2d([cv.desc(xr, 0, C, out, 0, EPI_LINEAR)], B, H, W, xr)
@@ -104,7 +114,7 @@ class HipConv(torch.autograd.Function):
             dy[:, :cout] = _rows(gy)
         dx = None
         if ctx.needs_input_grad[0]:
-            dg = _pack(w, None, "dgrad")
+            dg = _pack(w, None, "dgrad", ctx.src)
             dxr = torch.empty(B * H * W, C, device=gy.device)
             lib.conv2d([dg.desc(dy, 0, cp, dxr, 0, EPI_LINEAR)], B, H, W, dy)
             dx = _nchw(dxr, B, H, W)
@@ -113,7 +123,7 @@ class HipConv(torch.autograd.Function):
         db = torch.zeros(op, device=gy.device)
         lib.conv2d_wgrad(xr, 0, C, dy, 0, cp, dw, db, kh, kw, B, H, W)
         STATS["hip"] += 2
-        return dx, Conv.unpack_wgrad(dw, cout, C, kh, kw), db[:cout].clone()
+        return dx, Conv.unpack_wgrad(dw, cout, C, kh, kw), db[:cout].clone(), None
 
 
 def conv2d(x: torch.Tensor, m: nn.Conv2d) -> torch.Tensor:
@@ -377,18 +387,19 @@ def encoder_forward(enc, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def fuse_zr(gru) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
+def fuse_zr(gru) -> Dict[str, Tuple[torch.Tensor, torch.Tensor, tuple]]:
     """convz | convr of a SepConvGRU half share their input (core/update.py:48-49, :55-56): one convolution with
     the output channels concatenated.  Built once per forward; autograd splits the gradient back into the four
     parameters through the cat nodes."""
     out = {}
     for tag in ("1", "2"):
         cz, cr = getattr(gru, "convz" + tag), getattr(gru, "convr" + tag)
-        out[tag] = (torch.cat([cz.weight, cr.weight], 0), torch.cat([cz.bias, cr.bias], 0))
+        out[tag] = (torch.cat([cz.weight, cr.weight], 0), torch.cat([cz.bias, cr.bias], 0),
+                    _src_key(cz.weight, cr.weight, cz.bias, cr.bias))
     return out
 
 
-def sepconv_gru(gru, zr: Dict[str, Tuple[torch.Tensor, torch.Tensor]], h: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def sepconv_gru(gru, zr: Dict[str, Tuple[torch.Tensor, torch.Tensor, tuple]], h: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """SepConvGRU.forward (core/update.py:45-60)."""
     for tag in ("1", "2"):
         hx = torch.cat([h, x], 1)
