@@ -82,6 +82,15 @@ int pf_dccl_lookup(const float* coords,
                    const float* g_w2c, float* own_out, float* raw_out,
                    int B, int H8, int W8, int ld, void* stream);
 
+/* pf_dccl_lookup with an additional copy of the grid interleaved per pixel, g_w2c_il [H8*W8][2] = (x, y): the two
+ * components of a bilinear row pair become one 16-byte load (the kernel is bound by its gather-instruction count).
+ * g_w2c_il may be NULL (= pf_dccl_lookup).  Results are bit-identical either way. */
+int pf_dccl_lookup_il(const float* coords,
+                      const float* own0, const float* own1, const float* own2, const float* own3,
+                      const float* oth0, const float* oth1, const float* oth2, const float* oth3,
+                      const float* g_w2c, const float* g_w2c_il, float* own_out, float* raw_out,
+                      int B, int H8, int W8, int ld, void* stream);
+
 /* DCCL.__call__ step 3 + the caller's add (core/corr.py:138, core/prior_raft.py:187-188):
  * out = own + img_rotate(raw, g_back), channel-last. */
 int pf_dccl_combine(const float* own, const float* raw, const float* g_back, float* out,

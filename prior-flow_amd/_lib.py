@@ -56,6 +56,7 @@ _SIGNATURES = {
     "pf_corr_pyramid_bf16x3": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_split_bf16": [_fp, _fp, C.c_long, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
+    "pf_dccl_lookup_il": [_fp] * 13 + [_i, _i, _i, _i, _fp],
     "pf_dccl_combine": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_warp_gcorr": [_fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _fp],
     "pf_conv2d": [C.POINTER(ConvDesc), _i, _i, _i, _i, _fp],
@@ -217,13 +218,16 @@ class PfLib:
                                                   *[_ptr(l) for l in levels], B, H8, W8, Cch,
                                                   self._stream(levels[0])), "pf_corr_pyramid_bf16x3")
 
-    def dccl_lookup(self, coords, pyr_own, pyr_other, g_w2c, own_out, raw_out):
-        self._chk(coords, g_w2c, own_out, raw_out, *pyr_own, *pyr_other)
+    def dccl_lookup(self, coords, pyr_own, pyr_other, g_w2c, own_out, raw_out, g_il=None):
+        """g_il: optional interleaved copy [H8*W8, 2] of g_w2c (``interleave_grid``): fewer gather instructions."""
+        self._chk(coords, g_w2c, own_out, raw_out, g_il, *pyr_own, *pyr_other)
         B, _, H, W = coords.shape
-        self._rc(self._dll.pf_dccl_lookup(
+        if g_il is not None and g_il.numel() != g_w2c.numel():
+            raise PfError("dccl_lookup: g_il must hold the same grid as g_w2c")
+        self._rc(self._dll.pf_dccl_lookup_il(
             _ptr(coords), *[_ptr(p) for p in pyr_own], *[_ptr(p) for p in pyr_other],
-            _ptr(g_w2c), _ptr(own_out), _ptr(raw_out), B, H, W, own_out.shape[-1],
-            self._stream(coords)), "pf_dccl_lookup")
+            _ptr(g_w2c), _ptr(g_il), _ptr(own_out), _ptr(raw_out), B, H, W, own_out.shape[-1],
+            self._stream(coords)), "pf_dccl_lookup_il")
 
     def dccl_combine(self, own, raw, g_back, out, B, H8, W8):
         self._chk(own, raw, g_back, out)

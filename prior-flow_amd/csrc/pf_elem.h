@@ -95,6 +95,16 @@ PF_HD float pf_apply_ld(const PfTaps& t, const float* img, long ld) {
 // rows and the order of the four products are those of pf_taps0 / pf_apply, so results are identical.
 // The DCCL lookup is bound by the number of gather instructions (16 per tap before, 8 now).
 struct PfPair { float a, b; };
+struct PfQuad { float a, b, c, d; };
+PF_HD PfQuad pf_load4(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float pf_f4u __attribute__((ext_vector_type(4), aligned(4)));     // dword-aligned 16-byte load
+    const pf_f4u v = *reinterpret_cast<const pf_f4u*>(p);
+    return PfQuad{v.x, v.y, v.z, v.w};
+#else
+    return PfQuad{p[0], p[1], p[2], p[3]};
+#endif
+}
 PF_HD PfPair pf_load2(const float* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float pf_f2u __attribute__((ext_vector_type(2), aligned(4)));     // dword-aligned 8-byte load
@@ -307,6 +317,7 @@ struct PfLookupArgs {
     const float* own[PF_CORR_LEVELS];    // level i: [B*N][H_i*W_i]
     const float* other[PF_CORR_LEVELS];
     const float* g_w2c;             // [2,N]
+    const float* g_il;              // optional: the same grid interleaved [N][2] (x, y per pixel), or null
     float* own_out;                 // channel-last [B*N][ld]
     float* raw_out;                 // channel-last [B*N][ld]
     int B, H, W, ld;
@@ -363,9 +374,16 @@ PF_HD void pf_lookup_elem(long idx, const PfLookupArgs& a) {  // idx over B*N*(3
 #else
         {
             const bool hit = tg.r0 == rg;
-            const PfPair x0 = hit ? pgx : pf_load2(a.g_w2c + tg.r0);
-            const PfPair y0 = hit ? pgy : pf_load2(a.g_w2c + N + tg.r0);
-            const PfPair x1 = pf_load2(a.g_w2c + tg.r1), y1 = pf_load2(a.g_w2c + N + tg.r1);
+            PfPair x0 = pgx, y0 = pgy, x1, y1;
+            if (a.g_il) {
+                // interleaved grid: the row pair of BOTH components is one 16-byte load {x(xb), y(xb), x(xb+1), y(xb+1)}
+                if (!hit) { const PfQuad q = pf_load4(a.g_il + 2 * (long)tg.r0); x0 = PfPair{q.a, q.c}; y0 = PfPair{q.b, q.d}; }
+                const PfQuad q = pf_load4(a.g_il + 2 * (long)tg.r1);
+                x1 = PfPair{q.a, q.c}; y1 = PfPair{q.b, q.d};
+            } else {
+                if (!hit) { x0 = pf_load2(a.g_w2c + tg.r0); y0 = pf_load2(a.g_w2c + N + tg.r0); }
+                x1 = pf_load2(a.g_w2c + tg.r1); y1 = pf_load2(a.g_w2c + N + tg.r1);
+            }
             gx[j] = pf_apply_pairs(tg, x0, x1);
             gy[j] = pf_apply_pairs(tg, y0, y1);
             rg = tg.r1; pgx = x1; pgy = y1;

@@ -224,6 +224,11 @@ class Workspace:
         lib.sample_grid(self.g_a2b, r_a2b)
         lib.sample_grid(self.g_a2b_8, r_a2b)
         lib.sample_grid(self.g_b2a_8, r_b2a)
+        # the lookups' cross-view grid also interleaved per pixel [N][2]: one 16-byte load per bilinear row pair
+        # (PRIORFLOW_GRID_IL=0 keeps the planar loads: A/B knob, results are bit-identical)
+        il = os.environ.get("PRIORFLOW_GRID_IL", "1") != "0"
+        self.g_a2b_8_il = self.g_a2b_8.reshape(2, -1).t().contiguous() if il else None
+        self.g_b2a_8_il = self.g_b2a_8.reshape(2, -1).t().contiguous() if il else None
         # ---- encoders' side
         self.img_stack = z(B, 6, H, W)
         self.img_rot = z(B, 6, H, W)
@@ -404,7 +409,7 @@ class Engine:
                 if ev is None:
                     ev = torch.cuda.Event()
                     ev.record(main)
-                lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+                lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
                 lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
                 sb.wait_event(ev)
             elif fork_from is not None:
@@ -413,18 +418,18 @@ class Engine:
                 sb.wait_stream(main)
             self._await_b(sb, keep=True)
             with torch.cuda.stream(sb):
-                lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b)
+                lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b, ws.g_a2b_8_il)
                 lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
             if not a_first:
-                lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+                lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
                 lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
             main.wait_stream(sb)
         else:
-            lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+            lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
             lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
             if need_b:
                 self._await_b(torch.cuda.current_stream(), keep=True)
-                lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b)
+                lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b, ws.g_a2b_8_il)
                 lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
         d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
         if need_b:
@@ -441,10 +446,10 @@ class Engine:
         self._flow_chain_head(ws)
         lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.c1a, False, ws.conf_in, 0)
         lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.flow_ba, True, ws.conf_in, 4)
-        lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw)
+        lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
         lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
         if need_b:
-            lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own, ws.raw)
+            lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own, ws.raw, ws.g_a2b_8_il)
             lib.dccl_combine(ws.own, ws.raw, ws.g_a2b_8, ws.corr_b, B, H8, W8)
 
     def motion_inputs(self, ws: Workspace, P, need_b: bool):

@@ -152,6 +152,12 @@ def case_dccl(lib, dev):
     want = T(gold["own_a"]) + T(gold["cross_a"])
     check(corr_n[:, :, :8], want, 1e-3, "corr_a vs reference")          # see test_oracle_golden
     assert float((corr_n[:, :, :8] - want).abs().mean()) < 2e-5
+    # interleaved-grid variant (pf_dccl_lookup_il): bit-identical to the planar-grid launch
+    gw = g["a2bT_16x32"]
+    g_il = gw.reshape(2, -1).t().contiguous()
+    own_i, raw_i = torch.empty(N, LD, device=dev), torch.empty(N, LD, device=dev)
+    lib.dccl_lookup(co, pa_d, pb_d, gw, own_i, raw_i, g_il)
+    assert torch.equal(own_i, own) and torch.equal(raw_i, raw), "interleaved grid changes the lookup"
     # other direction (B looks into A)
     lib.dccl_lookup(co, pb_d, pa_d, g["b2aT_16x32"], own, raw)
     lib.dccl_combine(own, raw, g["a2b_16x32"], out, 1, H8, W8)
