@@ -25,6 +25,7 @@ is missing.
 from __future__ import annotations
 
 import math
+import threading
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -83,17 +84,66 @@ def _pack(w: torch.Tensor, b: Optional[torch.Tensor], kind: str, src: Optional[t
     return val
 
 
-class HipConv(torch.autograd.Function):
-    """Stride-1 'same' convolution with bias: pf_conv2d forward, pf_conv2d (dgrad) + pf_conv2d_wgrad backward."""
+class WeightGrad:
+    """Packed weight / bias gradient of ONE convolution, accumulated over all its uses in a backward pass
+    (pf_conv2d_wgrad accumulates): a conv of the update blocks runs `iters` times, and handing autograd a fresh
+    gradient per use cost two zero fills, an unpack copy, a clone and two accumulation adds each time."""
+
+    def __init__(self):
+        self.dw: Optional[torch.Tensor] = None
+        self.db: Optional[torch.Tensor] = None
+
+    def buffers(self, op: int, taps: int, cin_pad: int, device):
+        if self.dw is None:
+            self.dw = torch.zeros(op, taps, cin_pad, device=device)
+            self.db = torch.zeros(op, device=device)
+        return self.dw, self.db
+
+    def take(self):
+        got = (self.dw, self.db) if self.dw is not None else None
+        self.dw = self.db = None
+        return got
+
+
+class WeightGate(torch.autograd.Function):
+    """Returns a one-element token for the parameters (w1, b1[, w2, b2 ...]) of one (possibly fused) convolution.  Every
+    HipConv that uses them takes the token as an input, which orders this node's backward after all of theirs; it then
+    unpacks the accumulated gradient ONCE and splits it over the parameters by output-channel range."""
 
     @staticmethod
-    def forward(ctx, x, w, b, src=None):
+    def forward(ctx, acc, *params):
+        ctx.acc = acc
+        ctx.shapes = [tuple(p.shape) for p in params[0::2]]
+        ctx.set_materialize_grads(False)
+        return torch.zeros(1, device=params[0].device)
+
+    @staticmethod
+    def backward(ctx, _):
+        got = ctx.acc.take()
+        if got is None:
+            return (None,) * (1 + 2 * len(ctx.shapes))
+        dw, db = got
+        grads, o = [], 0
+        for cout, cin, kh, kw in ctx.shapes:
+            grads += [Conv.unpack_wgrad(dw[o:o + cout], cout, cin, kh, kw), db[o:o + cout].clone()]
+            o += cout
+        return (None, *grads)
+
+
+class HipConv(torch.autograd.Function):
+    """Stride-1 'same' convolution with bias: pf_conv2d forward, pf_conv2d (dgrad) + pf_conv2d_wgrad backward.
+    With a (token, WeightGrad) pair the weight / bias gradient goes to the accumulator (see WeightGate) and autograd
+    gets None for w and b; without one it is returned per call."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, src=None, tok=None, acc=None):
         lib = _lib.load()
         B, C, H, W = x.shape
         cout, _, kh, kw = w.shape
         xr = _rows(x.detach())
         cv = _pack(w, b, "fwd", src)
         ctx.src = src
+        ctx.acc = acc if tok is not None else None
         cp = (cout + 3) // 4 * 4
         out = (torch.empty if cp == cout else torch.zeros)(B * H * W, cp, device=x.device)
         lib.conv2d([cv.desc(xr, 0, C, out, 0, EPI_LINEAR)], B, H, W, xr)
@@ -119,11 +169,18 @@ class HipConv(torch.autograd.Function):
             lib.conv2d([dg.desc(dy, 0, cp, dxr, 0, EPI_LINEAR)], B, H, W, dy)
             dx = _nchw(dxr, B, H, W)
         op = (cp + 127) // 128 * 128
+        STATS["hip"] += 2
+        if ctx.acc is not None:
+            dw, db = ctx.acc.buffers(op, kh * kw, (C + 31) // 32 * 32, gy.device)
+            lib.conv2d_wgrad(xr, 0, C, dy, 0, cp, dw, db, kh, kw, B, H, W)
+            return dx, None, None, None, None, None
         dw = torch.zeros(op, kh * kw, (C + 31) // 32 * 32, device=gy.device)
         db = torch.zeros(op, device=gy.device)
         lib.conv2d_wgrad(xr, 0, C, dy, 0, cp, dw, db, kh, kw, B, H, W)
-        STATS["hip"] += 2
-        return dx, Conv.unpack_wgrad(dw, cout, C, kh, kw), db[:cout].clone(), None
+        return dx, Conv.unpack_wgrad(dw, cout, C, kh, kw), db[:cout].clone(), None, None, None
+
+
+_TAPE = threading.local()       # .gates: id(conv module) -> (token, WeightGrad) of the forward being recorded
 
 
 def conv2d(x: torch.Tensor, m: nn.Conv2d) -> torch.Tensor:
@@ -132,7 +189,14 @@ def conv2d(x: torch.Tensor, m: nn.Conv2d) -> torch.Tensor:
     hip = (m.stride == (1, 1) and (kh, kw) in ((3, 3), (1, 5), (5, 1), (1, 1)) and m.padding == (kh // 2, kw // 2)
            and x.shape[1] % 4 == 0 and m.bias is not None and m.dilation == (1, 1) and m.groups == 1)
     if hip:
-        return HipConv.apply(x, m.weight, m.bias)
+        gates = getattr(_TAPE, "gates", None)
+        if gates is None or not m.weight.requires_grad:
+            return HipConv.apply(x, m.weight, m.bias)
+        g = gates.get(id(m))
+        if g is None:
+            acc = WeightGrad()
+            g = gates[id(m)] = (WeightGate.apply(acc, m.weight, m.bias), acc)
+        return HipConv.apply(x, m.weight, m.bias, None, g[0], g[1])
     STATS["torch"] += 1
     return F.conv2d(x, m.weight, m.bias, stride=m.stride, padding=m.padding)
 
@@ -387,19 +451,22 @@ def encoder_forward(enc, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def fuse_zr(gru) -> Dict[str, Tuple[torch.Tensor, torch.Tensor, tuple]]:
+def fuse_zr(gru) -> Dict[str, tuple]:
     """convz | convr of a SepConvGRU half share their input (core/update.py:48-49, :55-56): one convolution with
-    the output channels concatenated.  Built once per forward; autograd splits the gradient back into the four
-    parameters through the cat nodes."""
+    the output channels concatenated.  Built once per forward (values only); the gradient comes back through ONE
+    WeightGate over the four parameters, which splits the accumulated packed gradient by output-channel range."""
     out = {}
     for tag in ("1", "2"):
         cz, cr = getattr(gru, "convz" + tag), getattr(gru, "convr" + tag)
-        out[tag] = (torch.cat([cz.weight, cr.weight], 0), torch.cat([cz.bias, cr.bias], 0),
-                    _src_key(cz.weight, cr.weight, cz.bias, cr.bias))
+        with torch.no_grad():
+            w, b = torch.cat([cz.weight, cr.weight], 0), torch.cat([cz.bias, cr.bias], 0)
+        acc = WeightGrad()
+        tok = WeightGate.apply(acc, cz.weight, cz.bias, cr.weight, cr.bias)
+        out[tag] = (w, b, _src_key(cz.weight, cr.weight, cz.bias, cr.bias), tok if tok.requires_grad else None, acc)
     return out
 
 
-def sepconv_gru(gru, zr: Dict[str, Tuple[torch.Tensor, torch.Tensor, tuple]], h: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def sepconv_gru(gru, zr: Dict[str, tuple], h: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """SepConvGRU.forward (core/update.py:45-60)."""
     for tag in ("1", "2"):
         hx = torch.cat([h, x], 1)
@@ -479,6 +546,14 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
         ys = torch.arange(H8, device=dev, dtype=torch.float32).view(1, 1, H8, 1).expand(B, 1, H8, W8)
         coords0 = torch.cat([xs, ys], 1).contiguous()                                           # :50-56
 
+    _TAPE.gates = {}
+    try:
+        return _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a_8, iters, init_flow)
+    finally:
+        _TAPE.gates = None
+
+
+def _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a_8, iters, init_flow):
     cnet = encoder_forward(model.cnet, torch.cat([i1, i1b], 0))                                 # :133-142
     net_a, inp_a = torch.tanh(cnet[:B, :128]), torch.relu(cnet[:B, 128:])
     net_b, inp_b = torch.tanh(cnet[B:, :128]), torch.relu(cnet[B:, 128:])
