@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of the whole forward: the library of the previous commit (profiles/scratch/libs/libpriorflow_prev.so,
+# Same-box A/B of the whole forward: another build of the library (the previous commit, or a -D variant such as -DPF_DMA_B) (profiles/scratch/libs/libpriorflow_prev.so,
 # built from a worktree of HEAD) against the current build, interleaved.
 for v in prev cur prev cur; do
   if [ $v = prev ]; then export PRIORFLOW_LIB=$PWD/profiles/scratch/libs/libpriorflow_prev.so; else unset PRIORFLOW_LIB; fi
