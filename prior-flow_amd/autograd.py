@@ -22,9 +22,9 @@ sigmoid outside the GRU backward, torch.cat / slicing, and the feature GEMMs of 
 There is no CPU path: every tensor must live on a ROCm device and ``_lib.load()`` raises when the HIP library
 is missing.  ``args.mixed_precision`` (CUDA autocast + GradScaler in the reference, train_flow.py:112,131-139) has no
 counterpart here: the convolutions run the 3-pass bf16 split with fp32 accumulation and fp32 storage, which needs no
-loss scaling.  Gradients reach the parameters through ``.backward()`` / ``torch.autograd.backward`` (the weight and
-pyramid gradients are accumulated in side buffers and handed over by token-ordered nodes at the end of the pass);
-``torch.autograd.grad`` with respect to activations works, with respect to conv parameters it is not supported.
+loss scaling.  The weight and pyramid gradients are accumulated in side buffers and handed to autograd once per
+backward pass by token-ordered nodes (``WeightGate``, ``HipCorrPyramid``), so ``.backward()``, ``torch.autograd.backward``
+and ``torch.autograd.grad`` all see ordinary gradients.
 """
 from __future__ import annotations
 
