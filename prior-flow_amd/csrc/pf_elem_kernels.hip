@@ -24,6 +24,26 @@ int pf_launch_elem(const Args& a, long total, void* stream) {
     return (int)hipGetLastError();
 }
 
+// Experiment knob (not defined in the product build): the DCCL lookup as its own __global__ with a forced occupancy
+// (PF_LOOKUP_WAVES = waves per SIMD the register allocator must make room for).  The generic wrapper uses 90 VGPRs =
+// 5 waves, and that is the optimum: 3 / 4 / 5 / 6 / 8 waves -> 26.7 / 24.3 / 22.9 / 25.1 / 43.4 us per launch
+// (interleaved grid, profiles/scratch/ab_lookup_occ.sh).
+#ifdef PF_LOOKUP_WAVES
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PF_LOOKUP_WAVES, PF_LOOKUP_WAVES)))
+pf_lookup_kernel(const PfLookupArgs a, const long total) {
+    long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long stride = (long)gridDim.x * kBlock;
+    for (; idx < total; idx += stride) pf_lookup_elem(idx, a);
+}
+int launch_lookup(const PfLookupArgs& a, long total, void* stream) {
+    if (total <= 0) return PF_OK;
+    long blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(pf_lookup_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, total);
+    return (int)hipGetLastError();
+}
+#endif
+
 // K5 on a wavefront: one pixel per wave, 4 channels per lane (C == 256), the four 64-channel
 // group sums reduced with 16-lane butterfly shuffles.
 __global__ void __launch_bounds__(kBlock) pf_warp_gcorr_wave(const PfWarpGcorrArgs a, const long rows) {
@@ -709,6 +729,11 @@ int launch_upsample_bwd(const PfUpsampleBwdArgs& a, long total, void* stream) {
 
 #define PF_UPSAMPLE_BWD_LAUNCH(a, total, stream) launch_upsample_bwd(a, total, stream)
 #define PF_COMBINE_LAUNCH(a, total, stream) launch_combine(a, total, stream)
+#ifdef PF_LOOKUP_WAVES
+#define PF_LOOKUP_LAUNCH(a, total, stream) launch_lookup(a, total, stream)
+#else
+#define PF_LOOKUP_LAUNCH(a, total, stream) pf_launch_elem<PfLookupArgs, pf_lookup_elem>(a, total, stream)
+#endif
 #define PF_REGION_SUM_LAUNCH(a, stream) launch_region_sums(a, stream)
 #define PF_SEQ_LOSS_LAUNCH(a, stream) launch_seq_loss(a, stream)
 #define PF_SUMSQ_LAUNCH(a, stream) launch_sumsq(a, stream)

@@ -43,5 +43,7 @@ def timed(fn):
     return s.elapsed_time(e) * 1e3 / reps
 
 
+g8_il = g8.reshape(2, -1).t().contiguous()
 print(f"lookup : {timed(lambda: lib.dccl_lookup(coords, pyr_a, pyr_b, g8, own, raw)):.1f} us/launch")
+print(f"lookup (interleaved grid): {timed(lambda: lib.dccl_lookup(coords, pyr_a, pyr_b, g8, own, raw, g8_il)):.1f} us/launch")
 print(f"combine: {timed(lambda: lib.dccl_combine(own, raw, g8, out, B, H8, W8)):.1f} us/launch")
