@@ -8,6 +8,12 @@ synthetic 512x1024 ERP pairs per GPU (BASELINE.json configs[1]: one pair).  Rank
 independent (the path shards over image pairs; no data-path collective) => weak scaling;
 `value` = pairs processed by all ranks / max-over-ranks wall time of the K timed steps.
 
+Multi-GPU: one process per GPU over torch.distributed ("nccl" = RCCL).  Either the caller provides the
+ranks (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* come from the environment), or `python bench.py --gpus N` alone launches them itself:
+the parent makes NO GPU call, starts N fresh child processes of this script with that environment on
+127.0.0.1, relays rank 0's JSON line and exits with the worst child status.
+
 Extra objects on the JSON line:
   roofline      the dominant kernel (exact-fp32 MFMA implicit-GEMM conv of the update blocks):
                 algorithmic FLOPs of its launches in one forward / their HIP-event time, vs the
@@ -241,20 +247,59 @@ def cpu_baseline(params, i1, i2, flow_gpu):
     return cb, parity
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes; this parent
+    never touches the GPU -- torch.cuda.device_count() does not initialise it) and relay their output."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    rehearsal = os.environ.get("PRIORFLOW_BENCH_BACKEND", "nccl") != "nccl"     # gloo: ranks may share a card
+    if have < n and not (rehearsal and have >= 1):
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
+def init_ranks(world: int, rank: int, device):
+    """torch.distributed for the barrier / max-over-ranks of the timing (the forward itself has no collective).
+    RCCL first; PRIORFLOW_BENCH_BACKEND=gloo selects the CPU backend for rehearsals on a box without N GPUs."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("PRIORFLOW_BENCH_BACKEND", "nccl")       # nccl == RCCL on ROCm
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    probe = torch.ones(1, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(probe)                                             # first collective: builds the communicator
+    assert int(probe.item()) == world, f"all-reduce over {world} ranks returned {probe.item()}"
+    return dist, backend
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but the launcher provides WORLD_SIZE={world}; running {world} rank(s)")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    local = local % max(torch.cuda.device_count(), 1)        # gloo rehearsal of N ranks on one card
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    dist, backend = None, None
+    if world > 1:
+        dist, backend = init_ranks(world, rank, device)
 
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}; building model")
     model, params = build_model(device)
@@ -288,9 +333,10 @@ def main():
         elapsed = time.perf_counter() - t0
     log(f"timed {args.steps} steps in {elapsed:.3f}s")
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        world = dist.get_world_size()                        # the size the communicator really has
 
     result = None
     if rank == 0:
@@ -306,7 +352,8 @@ def main():
             "config": {"workload": f"PriOr-RAFT forward, {args.batch} synthetic 512x1024 ERP pair(s) per GPU per step, "
                                    "iters=12, test_mode (BASELINE.json configs[1])",
                        "pairs_per_gpu_per_step": args.batch, "height": H, "width": W, "iters": ITERS,
-                       "parallelism": f"pairs sharded over {world} rank(s), no collective",
+                       "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"
+                                      + (f"; timing barrier / max over {backend}" if dist is not None else ""),
                        "weights": "deterministic closed-form fill (no checkpoints offline)",
                        "hip_graph": bool(model.use_graph),
                        "encoders": ("libpriorflow_hip.so (HIP kernels)" if model._weights()["precision"] == 1

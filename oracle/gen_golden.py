@@ -140,13 +140,7 @@ def main():
         # batch of 2 (different pairs) -> batch independence
         j1, j2 = gc.synthetic_pair(2, 128, 256, seed=77)
         save("forward_128x256_b2", out=m(j1, j2, iters=2, test_mode=True)[:, :, ::2, ::2])
-        # config 1: demo.py distribution (randn "images"), 256x512, iters=4
-        g = torch.Generator().manual_seed(1234)
-        d1 = torch.randn(1, 3, 256, 512, generator=g)
-        d2 = torch.randn(1, 3, 256, 512, generator=g)
-        # inputs are regenerated by the tests from the same torch.Generator seed (same torch build)
-        save("forward_256x512_demo", out=m(d1, d2, iters=4, test_mode=True)[:, :, ::2, ::2],
-             in_probe=torch.stack([d1.flatten()[:8], d2.flatten()[:8]]))
+        # BASELINE.json configs[0] (demo.py) and configs[4] (640x1280, iters=32): oracle/gen_golden_configs.py
 
 
 if __name__ == "__main__":

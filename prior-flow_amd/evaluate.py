@@ -31,24 +31,31 @@ REGIONS = ("All", "Equator", "Poles", "Center")
 
 
 class InputPadder:
-    """Pads images such that dimensions are divisible by 8 (core/utils/utils.py:7-27)."""
+    """Replicate-pads a batch up to the next multiple of 8 in H and W and crops results back
+    (API of core/utils/utils.py:7-27: ``pad(*tensors)``, ``unpad(tensor)``).  ``mode='sintel'`` centres the
+    image in the padded frame (the odd pixel goes to the bottom / right); any other mode keeps the top edge
+    and pads the bottom only, the width still being centred."""
+
+    MULTIPLE = 8
 
     def __init__(self, dims, mode="sintel"):
-        self.ht, self.wd = dims[-2:]
-        pad_ht = (((self.ht // 8) + 1) * 8 - self.ht) % 8
-        pad_wd = (((self.wd // 8) + 1) * 8 - self.wd) % 8
-        if mode == "sintel":
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
-        else:
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+        height, width = int(dims[-2]), int(dims[-1])
+        extra_h, extra_w = -height % self.MULTIPLE, -width % self.MULTIPLE
+        top = extra_h // 2 if mode == "sintel" else 0
+        left = extra_w // 2
+        self.ht, self.wd = height, width
+        # (left, right, top, bottom): the order torch.nn.functional.pad takes for the last two dims
+        self._pad = [left, extra_w - left, top, extra_h - top]
 
     def pad(self, *inputs):
-        return [F.pad(x, self._pad, mode="replicate") for x in inputs]
+        if not any(self._pad):
+            return list(inputs)
+        return [F.pad(t, self._pad, mode="replicate") for t in inputs]
 
     def unpad(self, x):
-        ht, wd = x.shape[-2:]
-        c = [self._pad[2], ht - self._pad[3], self._pad[0], wd - self._pad[1]]
-        return x[..., c[0]:c[1], c[2]:c[3]]
+        left, right, top, bottom = self._pad
+        rows, cols = x.shape[-2] - bottom, x.shape[-1] - right     # relative to x's own size, like the reference
+        return x[..., top:rows, left:cols]
 
 
 def spherical_mask(H: int, W: int) -> np.ndarray:

@@ -215,7 +215,12 @@ class PriOr_RAFT(nn.Module):
 
     # ---- HIP-graph replay of the whole test_mode forward --------------------------------------
     def _run_graph(self, ws: Workspace, image1, image2, iters):
+        # both signature checks clear self._graphs when a parameter (or a cnet BatchNorm statistic) changed in place:
+        # the captured launches hold pointers to PACKED copies of the weights, of the encoders' too
         self._weights()
+        from ._lib import PREC_BF16X3
+        if (default_precision() if self.precision is None else self.precision) == PREC_BF16X3:
+            self._encoder_plans()
         key = (ws.B, ws.H, ws.W, iters, str(image1.device))
         entry = self._graphs.get(key)
         if entry is None:

@@ -8,8 +8,9 @@ Mirrors, with the reference's names and argument meaning:
     prediction (what ``loss.backward()`` would feed the network) is left in ``.grads``;
   * ``rotate_gt(flow_gt)`` -> ``(flow_gt_B, valid_B)`` (train_flow.py:123-126, ``flo_A2B`` + validity);
   * ``fetch_optimizer(args, model)`` -> ``(FlatAdamW, OneCycleLinearLR)`` (train_flow.py:86-91): AdamW over
-    ONE flat parameter / gradient buffer (the parameters become views of it, so the single RCCL
-    all-reduce of ``parallel.FlatGradAllReduce`` and the fused ``pf_adamw_step`` both see one array)
+    ONE flat parameter / gradient buffer (the parameters become views of it, so the single all-reduce of
+    ``parallel.all_reduce_sum_`` and the fused ``pf_adamw_step`` both see one array; with more than one rank
+    the replicas are synchronised from rank 0 here, see ``FlatAdamW.sync_replicas``)
     and OneCycleLR(max_lr, num_steps + 100, pct_start=0.05, linear, cycle_momentum=False) in closed form;
   * ``clip_grad_norm_(optimizer, max_norm)`` (train_flow.py:137): total norm by ``pf_sum_squares``; the
     clip coefficient is applied inside the AdamW kernel instead of rewriting the gradients.
@@ -21,7 +22,7 @@ from typing import Dict, List, Sequence, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, parallel
 from .engine import rotation_x
 from .evaluate import spherical_mask
 
@@ -125,42 +126,58 @@ class OneCycleLinearLR:
 
 class FlatAdamW:
     """AdamW(model.parameters(), lr, weight_decay, eps) with every parameter, gradient and moment in one
-    flat fp32 buffer each; ``p.data`` / ``p.grad`` of the model become views of ``flat`` / ``grad``."""
+    flat fp32 buffer each; ``p.data`` / ``p.grad`` of the model become views of ``flat`` / ``grad``.
+
+    Use ``optimizer.zero_grad()`` (it zeroes the flat buffer).  Calls that re-bind the tensors behind the
+    optimizer's back -- ``model.zero_grad()`` / torch-style ``zero_grad(set_to_none=True)``, ``model.to()`` /
+    ``.cuda()`` / ``.half()`` after ``fetch_optimizer`` -- are detected by ``step()`` / ``total_grad_norm()``,
+    which copy the stray tensors back into the flat buffers and re-bind them (a parameter that changed
+    dtype or device cannot be repaired and raises ``PfError``)."""
 
     def __init__(self, params, lr: float, weight_decay: float, eps: float, betas=(0.9, 0.999)):
         self.lib = _lib.load()
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
-            raise ValueError("optimizer got an empty parameter list")
-        dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
-        o = 0
-        for p in self.params:
-            k = p.numel()
-            self.flat[o:o + k].copy_(p.data.reshape(-1))
-            p.data = self.flat[o:o + k].view_as(p)
-            p.grad = self.grad[o:o + k].view_as(p)
-            o += k
+        self.params, self.flat, self.grad = parallel.flatten_parameters(params)
+        dev = self.flat.device
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
         self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "eps": eps, "betas": betas}]
         self.step_count = 0
         self.grad_scale = 1.0
+        self.realiased = 0                       # how many tensors step() / total_grad_norm() had to re-bind so far
         self._norm_part = torch.empty(256, dtype=torch.float64, device=dev)
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none: bool = False):
+        """Zeroes the flat gradient buffer.  ``set_to_none`` is accepted for torch compatibility and ignored:
+        the gradients must stay views of the flat buffer."""
         self.grad.zero_()
         self.grad_scale = 1.0
 
+    def _check_aliases(self):
+        for p in self.params:
+            if p.device != self.flat.device or p.dtype != torch.float32:
+                raise _lib.PfError(f"a parameter moved to {p.device}/{p.dtype} after fetch_optimizer(); "
+                                   "create the optimizer after model.cuda() and keep the model in fp32")
+        self.realiased += parallel.realias(self.params, self.flat, self.grad, keep_values=True)
+
+    def sync_replicas(self, model=None, group=None, src: int = 0):
+        """Data-parallel start-up: broadcast rank ``src``'s parameters (the flat buffer) and the model's
+        buffers (cnet's BatchNorm running statistics) to every rank.  No-op for a single process."""
+        self._check_aliases()
+        parallel.sync_replicas(self.flat, list(model.buffers()) if model is not None else (), group, src)
+        _lib.bump_weights_epoch()
+
+    def assert_in_sync(self, group=None):
+        parallel.assert_replicas_in_sync(self.flat, group)
+
     @torch.no_grad()
     def total_grad_norm(self) -> float:
+        self._check_aliases()
         self.lib.sum_squares(self.grad, self._norm_part)
         return float(self._norm_part.sum().sqrt())
 
     @torch.no_grad()
     def step(self):
+        self._check_aliases()
         g = self.param_groups[0]
         self.step_count += 1
         self.lib.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
@@ -177,11 +194,19 @@ def clip_grad_norm_(optimizer: FlatAdamW, max_norm: float) -> float:
     return total
 
 
-def fetch_optimizer(args, model):
-    """Create the optimizer and learning rate scheduler (train_flow.py:86-91)."""
-    optimizer = FlatAdamW(model.parameters(), lr=args.lr, weight_decay=args.wdecay, eps=args.epsilon)
+def fetch_optimizer(args, model, group=None):
+    """Create the optimizer and learning rate scheduler (train_flow.py:86-91).  When torch.distributed runs
+    with more than one rank, every rank's weights and BatchNorm buffers are overwritten with rank 0's here
+    (``nn.DataParallel`` re-broadcasts its module every step, train_flow.py:96; one process per GPU needs it
+    once): ranks may construct the model unseeded."""
+    net = getattr(model, "module", model)
+    optimizer = FlatAdamW(net.parameters(), lr=args.lr, weight_decay=args.wdecay, eps=args.epsilon)
+    optimizer.sync_replicas(net, group)
     scheduler = OneCycleLinearLR(optimizer, args.lr, args.num_steps + 100, pct_start=0.05)
     return optimizer, scheduler
+
+
+SYNC_CHECK_EVERY = 500      # steps between replica checksum comparisons (16-byte all-gather)
 
 
 def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criterion: uniform_loss,
@@ -193,7 +218,6 @@ def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criteri
     RCCL over xGMI, replacing DataParallel's reduce_add (train_flow.py:96)], clip, AdamW, scheduler.
     ``model`` may be the bare module or an ``nn.DataParallel``-style wrapper exposing ``.module``.
     Returns ``(loss, metrics)``; ``metrics['grad_norm']`` is the pre-clip total norm."""
-    import torch.distributed as dist
     net = getattr(model, "module", model)
     optimizer.zero_grad()
     flow_gt_b, valid_b = rotate_gt(flow_gt)
@@ -204,9 +228,10 @@ def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criteri
     seeds += list(criterion.grads)
     # loss.backward(): the criterion has already produced d loss / d prediction for every prediction
     torch.autograd.backward(list(preds_a) + list(preds_b), seeds)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(optimizer.grad, op=dist.ReduceOp.SUM, group=group)
+    parallel.all_reduce_sum_(optimizer.grad, group)
     norm = clip_grad_norm_(optimizer, clip)
     optimizer.step()
     scheduler.step()
+    if optimizer.step_count % SYNC_CHECK_EVERY == 1:      # first step and every SYNC_CHECK_EVERY after it
+        optimizer.assert_in_sync(group)
     return loss_a + loss_b, {**metrics_a, **metrics_b, "grad_norm": norm}

@@ -39,6 +39,13 @@ def main():
     model.load_state_dict(gc.det_state_dict(state_dict_shapes()), strict=True)
     model = model.to(dev).train()
     model.freeze_bn()
+    if rank > 0:
+        # replicas need not be constructed identically: fetch_optimizer broadcasts rank 0's weights and BatchNorm buffers
+        # (the reference's DataParallel re-broadcasts its module every step, train_flow.py:96)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.01 * rank)
+            model.cnet.norm1.running_mean.add_(1.0)
     opt, sched = tr.fetch_optimizer(argparse.Namespace(lr=1e-4, wdecay=5e-5, epsilon=1e-8, num_steps=1000), model)
     i1, i2, gt, valid = (x[rank:rank + 1].to(dev) for x in step_inputs())       # this rank's pair only
     crit = tr.uniform_loss(128, 256, device=dev)
@@ -52,7 +59,7 @@ def main():
     torch.autograd.backward(list(pa) + list(pb), seeds)
     local_norm = opt.total_grad_norm()
     loss = (la + lb).reshape(1).clone()
-    dist.all_reduce(opt.grad, op=dist.ReduceOp.SUM)          # the one data-path collective of training
+    tr.parallel.all_reduce_sum_(opt.grad)                    # the one data-path collective of training
     dist.all_reduce(loss, op=dist.ReduceOp.SUM)
     total = opt.total_grad_norm()
     params = dict(model.named_parameters())
@@ -67,10 +74,12 @@ def main():
     # identical clip + AdamW on every rank keeps the replicas bit-identical
     tr.clip_grad_norm_(opt, 1.0)
     opt.step()
-    chk = opt.flat.double().sum().reshape(1)
-    both = [torch.zeros_like(chk) for _ in range(world)]
-    dist.all_gather(both, chk)
-    same = all(float(b) == float(both[0]) for b in both)
+    try:
+        opt.assert_in_sync()
+        same = True
+    except RuntimeError as exc:
+        print(f"rank {rank}: {exc}", flush=True)
+        same = False
     if rank == 0:
         print(f"parameter checksums after the step identical on all ranks: {same}", flush=True)
     dist.destroy_process_group()

@@ -57,3 +57,33 @@ def test_input_padder():
     assert torch.equal(p.unpad(y), x)
     assert InputPadder((1, 3, 13, 21), mode="kitti")._pad == [1, 2, 0, 3]
     assert InputPadder((1, 3, 512, 1024))._pad == [0, 0, 0, 0]   # the benchmark sizes are not padded
+
+
+def test_load_things_ckpt_matches_the_reference(tmp_path, capsys):
+    """load_things_ckpt (core/prior_raft.py:85-104): `module.` prefix stripped, same-name / same-shape entries
+    loaded, ODDC.{gru,flow_head,mask}.* filled from update_block.*, everything else skipped with the reference's
+    message.  tests/golden/things_ckpt.npz records what the reference did with the synthetic RAFT-things
+    checkpoint of oracle/gen_golden_ckpt.py (key -> checkpoint entry it ended up holding, skip lines)."""
+    import argparse
+    from gen_golden_ckpt import things_checkpoint          # oracle/ is on sys.path (tests/conftest.py)
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    g = gc.load("things_ckpt")
+    torch.manual_seed(7)
+    model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    assert list(before) == [str(k) for k in g["keys"]]
+    ckpt = things_checkpoint({k: tuple(v.shape) for k, v in before.items()})
+    path = str(tmp_path / "raft-things.pth")
+    torch.save(ckpt, path)
+    capsys.readouterr()
+    model.load_things_ckpt(path)
+    printed = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert printed == [str(s) for s in g["skipped"]]
+    after = model.state_dict()
+    n_alias = 0
+    for k, src in zip(g["keys"], g["source"]):
+        k, src = str(k), str(src)
+        want = ckpt[src] if src else before[k]
+        assert torch.equal(after[k], want), (k, src)
+        n_alias += bool(src) and src != "module." + k
+    assert n_alias >= 20                                         # the ODDC <- update_block remap really happened
