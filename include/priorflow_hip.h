@@ -102,6 +102,25 @@ int pf_dccl_combine(const float* own, const float* raw, const float* g_back, flo
 int pf_warp_gcorr(const float* f1, const float* f2, const float* coords, int add_grid,
                   float* dst, int dst_ld, int dst_off, int B, int H8, int W8, int C, void* stream);
 
+/* Motion inputs of one refinement iteration in one launch (core/prior_raft.py:171-182): flow_A = coords1_A - coords0,
+ * flow_B = coords1_B - coords0, flow_B_A = flo_rotate(flow_B, W2C = grid(R_A2B), C2W = grid(R_B2A)), and the two
+ * groupwise correlations flaw_A = gwc(f1A, warp(f2A, coords1_A)), flaw_B_A = gwc(f1A, warp(f2A, coords0 + flow_B_A)).
+ * Bit-identical to pf_flow_prep x2 + pf_flo_rotate + pf_warp_gcorr x2.  Outputs: flow4_a [B*N][4] = flow_A | flow_B_A,
+ * flow2_b [B*N][2]; optional GRU-input tails xa (4 columns at xa_off) / xb (2 columns at xb_off); conf [B*N][conf_ld]
+ * columns 0..3 flaw_A, 4..7 flaw_B_A.  C must be 256. */
+int pf_motion_prep(const float* c1a, const float* c1b, const float* g_w2c, const float* g_c2w,
+                   const float* f1a, const float* f2a, float* flow4_a, float* flow2_b,
+                   float* xa, int xa_ld, int xa_off, float* xb, int xb_ld, int xb_off,
+                   float* conf, int conf_ld, int B, int H8, int W8, int C, void* stream);
+
+/* Confidence stem of the ODDC motion encoder in one launch (core/update.py:177-178,193-194):
+ * out[.., off_out .. off_out+16) = relu(conv3x3_{32->16}(relu(conv3x3_{8->32}(in[.., off_in .. off_in+8))))), zero padding,
+ * exact fp32; w1 [9*8][32], w2 [9*32][16] in the [KH*KW][Cin][Cout] packing of pf_conv2d_direct.  The 32-channel
+ * intermediate map never leaves LDS. */
+int pf_conf_stem(const float* in, int ld_in, int off_in, const float* w1, const float* b1,
+                 const float* w2, const float* b2, float* out, int ld_out, int off_out,
+                 int B, int H8, int W8, void* stream);
+
 /* ---- update blocks ------------------------------------------------------------------------ */
 
 /* Epilogues of pf_conv2d. */
@@ -145,6 +164,21 @@ typedef struct pf_conv_desc {
      * ceil(H8/TH)*ceil(W8/32), TH = 8 for tile 5 else 4.  Finish with pf_channel_stats_final.  NULL = none. */
     double* stats_out;
 } pf_conv_desc;
+
+/* The tail of DCCL.__call__ fused with the first motion-encoder convolution (core/corr.py:138,
+ * core/prior_raft.py:187-188, core/update.py:185 / :92), PF_PREC_BF16X3 arithmetic:
+ *   out[.., off_out .. off_out+256) = relu(conv1x1_{324->256}(own + img_rotate(raw, g_back)))
+ * own, raw: channel-last [B*N][ld] outputs of pf_dccl_lookup; weight: the pf_conv2d packing of the 1x1 conv
+ * (pre-split bf16 [256][1][11] x {hi[32], lo[32]}); cout must be 256.  Bit-identical to pf_dccl_combine followed by
+ * pf_conv2d, but the combined 324-channel tensor is never written. */
+typedef struct pf_combine_conv_desc {
+    const float* own; const float* raw; int ld;
+    const float* g_back;               /* [2][N] rotate-back grid */
+    const void* weight; const float* bias;
+    float* out; int ld_out; int off_out; int cout;
+} pf_combine_conv_desc;
+/* ngroups = 1 | 2: branch A and branch B of an iteration in one launch (grid.y = group). */
+int pf_dccl_combine_conv1x1(const pf_combine_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream);
 
 /* Launch `ngroups` (1..4) same-geometry convolutions in ONE kernel (grid.z = group):
  * branch A and branch B of an iteration run side by side.  H8, W8 = OUTPUT map size. */

@@ -41,6 +41,12 @@ class ConvDesc(C.Structure):
     ]
 
 
+class CombineConvDesc(C.Structure):
+    """Mirror of ``pf_combine_conv_desc`` (include/priorflow_hip.h)."""
+    _fields_ = [("own", _fp), ("raw", _fp), ("ld", _i), ("g_back", _fp), ("weight", _fp), ("bias", _fp),
+                ("out", _fp), ("ld_out", _i), ("off_out", _i), ("cout", _i)]
+
+
 class DirectDesc(C.Structure):
     """Mirror of ``pf_direct_desc`` (include/priorflow_hip.h)."""
     _fields_ = [("in_", _fp), ("ld_in", _i), ("off_in", _i), ("weight", _fp), ("bias", _fp),
@@ -59,7 +65,10 @@ _SIGNATURES = {
     "pf_dccl_lookup_il": [_fp] * 13 + [_i, _i, _i, _i, _fp],
     "pf_dccl_combine": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_warp_gcorr": [_fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _fp],
+    "pf_conf_stem": [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
+    "pf_motion_prep": [_fp] * 9 + [_i, _i, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_conv2d": [C.POINTER(ConvDesc), _i, _i, _i, _i, _fp],
+    "pf_dccl_combine_conv1x1": [C.POINTER(CombineConvDesc), _i, _i, _i, _i, _fp],
     "pf_conv2d_tile": [C.POINTER(ConvDesc), _i, _i, _i, _i],
     "pf_conv2d_direct": [_fp, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_conv2d_direct_group": [C.POINTER(DirectDesc), _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
@@ -196,6 +205,21 @@ class PfLib:
             B, H, W, self._stream(flow)), "pf_flo_rotate")
         return out
 
+    def conf_stem(self, x, off_in, w1, b1, w2, b2, out, off_out, B, H8, W8):
+        """relu(conv3x3 32->16(relu(conv3x3 8->32(x)))) in one launch (core/update.py:193-194); w*: [9*Cin][Cout]."""
+        self._chk(x, w1, b1, w2, b2, out)
+        self._rc(self._dll.pf_conf_stem(_ptr(x), x.shape[-1], off_in, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                                        _ptr(out), out.shape[-1], off_out, B, H8, W8, self._stream(x)), "pf_conf_stem")
+
+    def motion_prep(self, c1a, c1b, g_w2c, g_c2w, f1a, f2a, flow4_a, flow2_b, conf, xa=None, xa_off=0, xb=None, xb_off=0):
+        """One launch for flow_prep x2 + flo_rotate + warp_gcorr x2 (core/prior_raft.py:171-182), bit-identical to them."""
+        self._chk(c1a, c1b, g_w2c, g_c2w, f1a, f2a, flow4_a, flow2_b, conf, xa, xb)
+        B, _, H, W = c1a.shape
+        self._rc(self._dll.pf_motion_prep(
+            _ptr(c1a), _ptr(c1b), _ptr(g_w2c), _ptr(g_c2w), _ptr(f1a), _ptr(f2a), _ptr(flow4_a), _ptr(flow2_b),
+            _ptr(xa), 0 if xa is None else xa.shape[-1], xa_off, _ptr(xb), 0 if xb is None else xb.shape[-1], xb_off,
+            _ptr(conf), conf.shape[-1], B, H, W, f1a.shape[-1], self._stream(c1a)), "pf_motion_prep")
+
     # ---- correlation -------------------------------------------------------------------------
     def corr_pyramid(self, f1, f2, levels, B, H8, W8):
         """f1,f2: channel-last [B*N, C]; levels: 4 tensors [B*N, (H8>>i)*(W8>>i)]."""
@@ -234,6 +258,22 @@ class PfLib:
         self._rc(self._dll.pf_dccl_combine(_ptr(own), _ptr(raw), _ptr(g_back), _ptr(out), B, H8, W8,
                                            own.shape[-1], out.shape[-1], self._stream(own)),
                  "pf_dccl_combine")
+
+    def dccl_combine_conv1x1(self, items, B, H8, W8):
+        """items: 1 or 2 tuples (own, raw, g_back, conv, out, off_out) with `conv` a packed bf16x3 1x1 324->256
+        engine.Conv: out[.., off_out:off_out+256] = relu(conv(own + rotate_back(raw))) without materialising the sum."""
+        arr = (CombineConvDesc * len(items))()
+        keep = []
+        for d, (own, raw, g_back, conv, out, off_out) in zip(arr, items):
+            self._chk(own, raw, g_back, conv.b, out)
+            if conv.precision != PREC_BF16X3 or (conv.kh, conv.kw, conv.cin, conv.cout) != (1, 1, 324, 256):
+                raise PfError("dccl_combine_conv1x1 needs the bf16x3 packing of a 1x1 324(352)->256 convolution")
+            d.own, d.raw, d.ld, d.g_back = own.data_ptr(), raw.data_ptr(), own.shape[-1], g_back.data_ptr()
+            d.weight, d.bias = conv.w.data_ptr(), conv.b.data_ptr()
+            d.out, d.ld_out, d.off_out, d.cout = out.data_ptr(), out.shape[-1], off_out, conv.cout
+            keep.append((own, raw, g_back, conv, out))
+        self._rc(self._dll.pf_dccl_combine_conv1x1(arr, len(items), B, H8, W8, self._stream(items[0][0])),
+                 "pf_dccl_combine_conv1x1")
 
     def warp_gcorr(self, f1, f2, coords, add_grid, dst, dst_off):
         self._chk(f1, f2, coords, dst)

@@ -982,6 +982,63 @@ PF_HD void pf_warp_gcorr_elem(long idx, const PfWarpGcorrArgs& a) {   // idx ove
     a.dst.ptr[row * a.dst.ld + a.dst.c_off + g] = acc / (float)cg;
 }
 
+// ----------------------------------------------------------------------------------------------
+// Per-iteration motion inputs of one pixel, fused (core/prior_raft.py:171-182): the flows of both branches
+// (coords1 - coords0), flo_rotate(flow_B) into view A, and the two feature warps + groupwise correlations whose
+// sample points are coords1_A and coords0 + flow_B_A.  The scalar part below is the arithmetic of pf_flow_prep_elem
+// and pf_flo_rotate_elem, statement for statement (the flow at a corner pixel is formed as coords1 - coords0 first,
+// exactly what the separate flow_prep launch stored), so the fused launch is bit-identical to the five it replaces.
+// ----------------------------------------------------------------------------------------------
+struct PfMotionPrepArgs {
+    const float* c1a; const float* c1b;      // planar coords1 [B,2,N] of branch A / branch B
+    const float* g_w2c; const float* g_c2w;  // flo_rotate(flow_B): W2C = grid(R_A2B), C2W = grid(R_B2A)   [2,N] each
+    const float* f1; const float* f2;        // channel-last features of view A [B*N][256]
+    float* flow4_a;                          // [B*N][4]  flow_A | flow_B_A      (input of the 7x7 flow stems)
+    float* flow2_b;                          // [B*N][2]  flow_B
+    PfDst xa, xb;                            // GRU input tails: 4 columns (flow_A | flow_B_A) / 2 columns (flow_B)
+    float* conf; int conf_ld;                // [B*N][conf_ld]: columns 0..3 flaw_A, 4..7 flaw_B_A
+    int B, H, W;
+};
+struct PfMotionFlows { float ua, va, ub, vb, uba, vba; };
+// camera-frame flow of branch B at pixel p (pf_flow_c_at with flow_B = coords1_B - coords0 formed in place)
+PF_HD void pf_flow_c_at_coords(const PfMotionPrepArgs& a, long b, int p, float& f0, float& f1) {
+    const long N = (long)a.H * a.W;
+    const float Wf = (float)a.W;
+    const float px = (float)(p % a.W), py = (float)(p / a.W);
+    const float fu = a.c1b[(b * 2 + 0) * N + p] - px, fv = a.c1b[(b * 2 + 1) * N + p] - py;
+    float ex = (px + fu) + 0.5f;
+    ex = pf_pymod(ex, Wf) - 0.5f;
+    float ey = py + fv;
+    ey = fminf(fmaxf(ey, -0.5f), (float)a.H - 0.5f);
+    const PfWrapTaps t = pf_wraptaps(ex, ey, a.H, a.W);
+    const float* g0 = a.g_w2c;
+    const float* g1 = a.g_w2c + N;
+    const float a0 = g0[t.ia];
+    const float e0 = pf_wrapmix(t, a0, pf_unwrap_m(a0, g0[t.ib], Wf), pf_unwrap_m(a0, g0[t.ic], Wf),
+                                pf_unwrap_m(a0, g0[t.id], Wf));
+    const float e1 = pf_wrapmix(t, g1[t.ia], g1[t.ib], g1[t.ic], g1[t.id]);
+    f0 = e0 - g0[p];
+    f0 = pf_pymod(f0 + Wf * 0.5f, Wf) - Wf * 0.5f;     // u_clip
+    f1 = e1 - g1[p];
+}
+PF_HD PfMotionFlows pf_motion_flows(long row, const PfMotionPrepArgs& a) {      // row = b*N + n
+    const long N = (long)a.H * a.W;
+    const long b = row / N, n = row % N;
+    const float x = (float)(n % a.W), y = (float)(n / a.W);
+    PfMotionFlows f;
+    f.ua = a.c1a[(b * 2 + 0) * N + n] - x; f.va = a.c1a[(b * 2 + 1) * N + n] - y;
+    f.ub = a.c1b[(b * 2 + 0) * N + n] - x; f.vb = a.c1b[(b * 2 + 1) * N + n] - y;
+    const PfWrapTaps t = pf_wraptaps(a.g_c2w[n], a.g_c2w[N + n], a.H, a.W);
+    float a0, a1, b0, b1, c0, c1, d0, d1;
+    pf_flow_c_at_coords(a, b, t.ia, a0, a1);
+    pf_flow_c_at_coords(a, b, t.ib, b0, b1);
+    pf_flow_c_at_coords(a, b, t.ic, c0, c1);
+    pf_flow_c_at_coords(a, b, t.id, d0, d1);
+    f.uba = pf_wrapmix(t, a0, b0, c0, d0);
+    f.vba = pf_wrapmix(t, a1, b1, c1, d1);
+    return f;
+}
+
 // Backward of K5 (autograd through cycle_bilinear_sampler + groupwise_corr, core/prior_raft.py:173-174,
 // :77-83; coords detached): with gs = d_flaw[group(c)] / (C/4),
 //   d_f1[p][c]        += gs * warped_f2[p][c]

@@ -79,6 +79,109 @@ __global__ void __launch_bounds__(kBlock) pf_warp_gcorr_wave(const PfWarpGcorrAr
     }
 }
 
+// Motion inputs of an iteration in ONE launch (replaces flow_prep x2, flo_rotate, warp_gcorr x2: five dependent
+// latency-bound launches of 8 192 pixels each -- 8.7 + 33 + 18.8 us in the replay of round 1).
+// A workgroup of 256 threads owns 32 consecutive pixels.
+//   stage 1 (thread-per-task): flo_rotate's four corner evaluations of a pixel are independent -- thread (pixel p,
+//            corner c) = tid & 31, tid >> 5 for the first 128 threads -- and meet in LDS; 32 threads then blend them and
+//            write the flows.  (A first version ran this scalar part redundantly in all 64 lanes of a wave-per-pixel
+//            kernel: 66 us per launch -- it is ~1 500 instructions of pymod / floor arithmetic.)
+//   stage 2 (16 lanes per pixel, 4 pixels per wave at a time): lane j loads float4 number 16 i + j of a feature row for
+//            i = 0..3, i.e. the four channels that lane 16 i + j of pf_warp_gcorr_wave holds, and the sums run through the
+//            same xor-butterfly over 16 lanes: the results are bit-identical to that kernel's, the loads are 256-byte
+//            contiguous per pixel, and the row of f1 is loaded once for both warps.
+constexpr int MP_PIX = 32;
+__global__ void __launch_bounds__(256) pf_motion_prep_kernel(const PfMotionPrepArgs a, const long rows) {
+    __shared__ float corner[4][MP_PIX][2];
+    __shared__ float flows[MP_PIX][6];
+    __shared__ float blendw[MP_PIX][4];
+    const int tid = threadIdx.x;
+    const long N = (long)a.H * a.W;
+    const long row0 = (long)blockIdx.x * MP_PIX;
+    // ---- stage 1 ---------------------------------------------------------------------------------------------
+    if (tid < 4 * MP_PIX) {
+        const int p = tid & (MP_PIX - 1), c = tid / MP_PIX;
+        const long row = row0 + p;
+        if (row < rows) {
+            const long b = row / N, n = row % N;
+            const PfWrapTaps t = pf_wraptaps(a.g_c2w[n], a.g_c2w[N + n], a.H, a.W);
+            const int ci = c == 0 ? t.ia : (c == 1 ? t.ib : (c == 2 ? t.ic : t.id));
+            float f0, f1;
+            pf_flow_c_at_coords(a, b, ci, f0, f1);
+            corner[c][p][0] = f0; corner[c][p][1] = f1;
+            if (c == 0) { blendw[p][0] = t.wa; blendw[p][1] = t.wb; blendw[p][2] = t.wc; blendw[p][3] = t.wd; }
+        }
+    }
+    __syncthreads();
+    if (tid < MP_PIX && row0 + tid < rows) {
+        const long row = row0 + tid;
+        const long b = row / N, n = row % N;
+        const float x = (float)(n % a.W), y = (float)(n / a.W);
+        PfMotionFlows f;
+        f.ua = a.c1a[(b * 2 + 0) * N + n] - x; f.va = a.c1a[(b * 2 + 1) * N + n] - y;
+        f.ub = a.c1b[(b * 2 + 0) * N + n] - x; f.vb = a.c1b[(b * 2 + 1) * N + n] - y;
+        PfWrapTaps t;                               // only the weights are used by pf_wrapmix
+        t.wa = blendw[tid][0]; t.wb = blendw[tid][1]; t.wc = blendw[tid][2]; t.wd = blendw[tid][3];
+        f.uba = pf_wrapmix(t, corner[0][tid][0], corner[1][tid][0], corner[2][tid][0], corner[3][tid][0]);
+        f.vba = pf_wrapmix(t, corner[0][tid][1], corner[1][tid][1], corner[2][tid][1], corner[3][tid][1]);
+        reinterpret_cast<float4*>(a.flow4_a)[row] = float4{f.ua, f.va, f.uba, f.vba};
+        reinterpret_cast<float2*>(a.flow2_b)[row] = float2{f.ub, f.vb};
+        if (a.xa.ptr) {
+            float* d = a.xa.ptr + row * a.xa.ld + a.xa.c_off;
+            d[0] = f.ua; d[1] = f.va; d[2] = f.uba; d[3] = f.vba;
+        }
+        pf_store_dst2(a.xb, row, f.ub, f.vb);
+        // sample points of the two warps: coords1_A (:173) and coords0 + flow_B_A (:180)
+        flows[tid][0] = a.c1a[(b * 2 + 0) * N + n]; flows[tid][1] = a.c1a[(b * 2 + 1) * N + n];
+        flows[tid][2] = x + f.uba; flows[tid][3] = y + f.vba;
+    }
+    __syncthreads();
+    // ---- stage 2 ---------------------------------------------------------------------------------------------
+    const int lane = tid & 63, wave = tid >> 6, j = lane & 15, sub = lane >> 4;
+#pragma unroll
+    for (int round = 0; round < MP_PIX / 16; ++round) {
+        const int p = round * 16 + wave * 4 + sub;
+        const long row = row0 + p;
+        if (row >= rows) continue;                  // (whole 16-lane groups drop out together)
+        const long b = row / N;
+        const float4* f1r = reinterpret_cast<const float4*>(a.f1 + row * 256);
+        const float* f2b = a.f2 + b * N * 256;
+        float4 v1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v1[i] = f1r[16 * i + j];
+#pragma unroll
+        for (int wsel = 0; wsel < 2; ++wsel) {
+            const PfTaps t = pf_taps0(pf_pymod(flows[p][2 * wsel], (float)a.W), flows[p][2 * wsel + 1], a.H, a.W);
+            float4 s[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = reinterpret_cast<const float4*>(f2b + (long)t.idx[0] * 256)[16 * i + j];
+                s[i].x = v.x * t.w[0]; s[i].y = v.y * t.w[0]; s[i].z = v.z * t.w[0]; s[i].w = v.w * t.w[0];
+            }
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 v = reinterpret_cast<const float4*>(f2b + (long)t.idx[q] * 256)[16 * i + j];
+                    s[i].x = s[i].x + v.x * t.w[q]; s[i].y = s[i].y + v.y * t.w[q];
+                    s[i].z = s[i].z + v.z * t.w[q]; s[i].w = s[i].w + v.w * t.w[q];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float pr = v1[i].x * s[i].x;
+                pr = pr + v1[i].y * s[i].y;
+                pr = pr + v1[i].z * s[i].z;
+                pr = pr + v1[i].w * s[i].w;
+                pr += __shfl_xor(pr, 1);
+                pr += __shfl_xor(pr, 2);
+                pr += __shfl_xor(pr, 4);
+                pr += __shfl_xor(pr, 8);
+                if (j == 0) a.conf[row * a.conf_ld + 4 * wsel + i] = pr / 64.f;
+            }
+        }
+    }
+}
+
 // Small-Cin convolution on the exact-fp32 matrix cores (7x7 2->128, 3x3 8->32, 3x3 32->16 of the
 // motion encoders, core/update.py:171-178,87; and the encoders' 7x7/2 3->64 stem).
 //
@@ -796,6 +899,130 @@ extern "C" int pf_warp_gcorr(const float* f1, const float* f2, const float* coor
         return (int)hipGetLastError();
     }
     return PF_LAUNCH(warp_gcorr, a, rows * 4, stream);
+}
+
+// Confidence stem of the ODDC motion encoder in ONE launch (core/update.py:177-178,193-194):
+//   out = relu(conv3x3_{32->16}(relu(conv3x3_{8->32}(x))))      (zero padding 1, stride 1, exact fp32 FMA chains)
+// 113 MFLOP per 64x128 map: a latency job (round 1 ran it as two launches of the small-Cin MFMA kernel, 34.7 + 20.1 us
+// in the replay).  A workgroup owns a 4 x 16 pixel tile: the 8 x 20 input patch and the 6 x 18 intermediate map live
+// in LDS, so the intermediate activation never goes to memory.  Stage 1: thread = (channel pair, 1 of 16 pixel
+// lanes), its 2 x 72 weights in registers, 72 patch values per pixel from LDS.  Stage 2: thread = (pixel, group of 4
+// output channels), weights [288][16] read from LDS (the same row for every pixel: a broadcast), k ascending.
+constexpr int CS_TH = 4, CS_TW = 16, CS_CIN = 8, CS_MID = 32, CS_OUT = 16;
+constexpr int CS_PW = CS_TW + 4, CS_PH = CS_TH + 4, CS_MW = CS_TW + 2, CS_MH = CS_TH + 2, CS_MLD = CS_MID + 4;
+struct PfConfStemArgs {
+    const float* in; int ld_in, off_in;
+    const float* w1; const float* b1;       // [9*8][32], [32]
+    const float* w2; const float* b2;       // [9*32][16], [16]
+    float* out; int ld_out, off_out;
+    int B, H, W;
+};
+__global__ void __launch_bounds__(256) pf_conf_stem_kernel(const PfConfStemArgs a) {
+    __shared__ __attribute__((aligned(16))) float patch[CS_PH * CS_PW * CS_CIN];     //  5.0 KB
+    __shared__ __attribute__((aligned(16))) float mid[CS_MH * CS_MW * CS_MLD];       // 15.2 KB
+    __shared__ __attribute__((aligned(16))) float w2s[9 * CS_MID * CS_OUT];          // 18.0 KB
+    const int tid = threadIdx.x;
+    const int tiles_x = (a.W + CS_TW - 1) / CS_TW, tiles_y = (a.H + CS_TH - 1) / CS_TH;
+    const int tile = blockIdx.x;
+    const int x0 = (tile % tiles_x) * CS_TW, y0 = ((tile / tiles_x) % tiles_y) * CS_TH;
+    const long pix0 = (long)(tile / (tiles_x * tiles_y)) * a.H * a.W;
+    // ---- stage 0: input patch (zero outside the map), second-layer weights; first-layer weights to registers ----
+    for (int i = tid; i < CS_PH * CS_PW * 2; i += 256) {
+        const int p = i >> 1, half = i & 1;
+        const int y = y0 + p / CS_PW - 2, x = x0 + p % CS_PW - 2;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+            v = *reinterpret_cast<const float4*>(a.in + (pix0 + (long)y * a.W + x) * a.ld_in + a.off_in + 4 * half);
+        *reinterpret_cast<float4*>(patch + p * CS_CIN + 4 * half) = v;
+    }
+    for (int i = tid; i < 9 * CS_MID * CS_OUT / 4; i += 256)
+        reinterpret_cast<float4*>(w2s)[i] = reinterpret_cast<const float4*>(a.w2)[i];
+    const int cp = tid & 15, pl = tid >> 4;
+    float2 w1r[9 * CS_CIN];
+#pragma unroll
+    for (int k = 0; k < 9 * CS_CIN; ++k) w1r[k] = *reinterpret_cast<const float2*>(a.w1 + k * CS_MID + 2 * cp);
+    const float2 bias1 = *reinterpret_cast<const float2*>(a.b1 + 2 * cp);
+    __syncthreads();
+    // ---- stage 1: intermediate map on the tile + 1-pixel ring; positions outside the image are conv2's zero padding ----
+    for (int p = pl; p < CS_MH * CS_MW; p += 16) {
+        const int my = p / CS_MW, mx = p % CS_MW;
+        const int y = y0 + my - 1, x = x0 + mx - 1;
+        float2 acc = bias1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float* src = patch + ((my + t / 3) * CS_PW + mx + t % 3) * CS_CIN;
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                acc.x = __builtin_fmaf(vv[c], w1r[t * 8 + c].x, acc.x);
+                acc.y = __builtin_fmaf(vv[c], w1r[t * 8 + c].y, acc.y);
+            }
+        }
+        const bool inside = y >= 0 && y < a.H && x >= 0 && x < a.W;
+        float2 r = {inside ? fmaxf(acc.x, 0.f) : 0.f, inside ? fmaxf(acc.y, 0.f) : 0.f};
+        *reinterpret_cast<float2*>(mid + p * CS_MLD + 2 * cp) = r;
+    }
+    __syncthreads();
+    // ---- stage 2 -----------------------------------------------------------------------------------------
+    const int px = tid >> 2, cg = tid & 3;
+    const int oy = px / CS_TW, ox = px % CS_TW;
+    float4 acc = *reinterpret_cast<const float4*>(a.b2 + 4 * cg);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float* m = mid + ((oy + t / 3) * CS_MW + ox + t % 3) * CS_MLD;
+        const float* w = w2s + t * CS_MID * CS_OUT + 4 * cg;
+#pragma unroll
+        for (int c4 = 0; c4 < CS_MID / 4; ++c4) {
+            const float4 mv = *reinterpret_cast<const float4*>(m + 4 * c4);
+            const float mm[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + (4 * c4 + i) * CS_OUT);
+                acc.x = __builtin_fmaf(mm[i], wv.x, acc.x); acc.y = __builtin_fmaf(mm[i], wv.y, acc.y);
+                acc.z = __builtin_fmaf(mm[i], wv.z, acc.z); acc.w = __builtin_fmaf(mm[i], wv.w, acc.w);
+            }
+        }
+    }
+    const int y = y0 + oy, x = x0 + ox;
+    if (y < a.H && x < a.W) {
+        const float4 r = {fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+        *reinterpret_cast<float4*>(a.out + (pix0 + (long)y * a.W + x) * a.ld_out + a.off_out + 4 * cg) = r;
+    }
+}
+
+extern "C" int pf_conf_stem(const float* in, int ld_in, int off_in, const float* w1, const float* b1,
+                            const float* w2, const float* b2, float* out, int ld_out, int off_out,
+                            int B, int H8, int W8, void* stream) {
+    if (!in || !w1 || !b1 || !w2 || !b2 || !out) return PF_ERR_BAD_ARG;
+    if (B <= 0 || H8 <= 0 || W8 <= 0) return PF_ERR_BAD_SHAPE;
+    if (off_in < 0 || off_in + CS_CIN > ld_in || off_out < 0 || off_out + CS_OUT > ld_out) return PF_ERR_BAD_ARG;
+    if ((ld_in | off_in | ld_out | off_out) & 3) return PF_ERR_BAD_SHAPE;          // 16-byte rows
+    PfConfStemArgs a;
+    a.in = in; a.ld_in = ld_in; a.off_in = off_in; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.out = out; a.ld_out = ld_out; a.off_out = off_out; a.B = B; a.H = H8; a.W = W8;
+    const long tiles = (long)B * ((H8 + CS_TH - 1) / CS_TH) * ((W8 + CS_TW - 1) / CS_TW);
+    hipLaunchKernelGGL(pf_conf_stem_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pf_motion_prep(const float* c1a, const float* c1b, const float* g_w2c, const float* g_c2w,
+                              const float* f1a, const float* f2a, float* flow4_a, float* flow2_b,
+                              float* xa, int xa_ld, int xa_off, float* xb, int xb_ld, int xb_off,
+                              float* conf, int conf_ld, int B, int H8, int W8, int C, void* stream) {
+    if (!c1a || !c1b || !g_w2c || !g_c2w || !f1a || !f2a || !flow4_a || !flow2_b || !conf) return PF_ERR_BAD_ARG;
+    if (B <= 0 || H8 <= 1 || W8 <= 1 || C != 256 || conf_ld < 8) return PF_ERR_BAD_SHAPE;
+    if (xa && (xa_off < 0 || xa_off + 4 > xa_ld)) return PF_ERR_BAD_ARG;
+    if (xb && (xb_off < 0 || xb_off + 2 > xb_ld)) return PF_ERR_BAD_ARG;
+    PfMotionPrepArgs a;
+    a.c1a = c1a; a.c1b = c1b; a.g_w2c = g_w2c; a.g_c2w = g_c2w; a.f1 = f1a; a.f2 = f2a;
+    a.flow4_a = flow4_a; a.flow2_b = flow2_b;
+    a.xa = pf_dst(xa, xa_ld, xa_off); a.xb = pf_dst(xb, xb_ld, xb_off);
+    a.conf = conf; a.conf_ld = conf_ld; a.B = B; a.H = H8; a.W = W8;
+    const long rows = (long)B * H8 * W8;
+    hipLaunchKernelGGL(pf_motion_prep_kernel, dim3((unsigned)((rows + MP_PIX - 1) / MP_PIX)), dim3(256), 0,
+                       (hipStream_t)stream, a, rows);
+    return (int)hipGetLastError();
 }
 
 extern "C" const char* pf_version(void) {

@@ -364,12 +364,20 @@ class Engine:
 
     # -- the three independent chains of an iteration ---------------------------------------------
     def _flow_chain_head(self, ws: Workspace):
-        """flows + flo_rotate (:171-179): produces flow4_a, flow2_b, flow_ba and the flow tails of x."""
+        """flows + flo_rotate + the two feature warps / groupwise correlations (:171-182) in ONE launch: produces
+        flow4_a, flow2_b, the flow tails of x_a / x_b and conf_in.  flo_rotate(flow_B, W2C = grid(R_B2A^T) ==
+        grid(R_A2B), C2W = grid(R_B2A)) (:179).  PRIORFLOW_FUSED_PREP=0 keeps the five separate launches (A/B knob;
+        the results are bit-identical)."""
         lib = self.lib
+        if os.environ.get("PRIORFLOW_FUSED_PREP", "1") != "0":
+            lib.motion_prep(ws.c1a, ws.c1b, ws.g_a2b_8, ws.g_b2a_8, ws.f["f1a"], ws.f["f2a"], ws.flow4_a, ws.flow2_b,
+                            ws.conf_in, ws.x_a, 252, ws.x_b, 254)
+            return
         lib.flow_prep(ws.c1a, None, ws.flow4_a, 0, ws.x_a, 252)
         lib.flow_prep(ws.c1b, ws.flow_b, ws.flow2_b, 0, ws.x_b, 254)
-        # flo_rotate(flow_B, W2C = grid(R_B2A^T) == grid(R_A2B), C2W = grid(R_B2A))  (:179)
         lib.flo_rotate(ws.flow_b, ws.g_a2b_8, ws.g_b2a_8, ws.flow_ba, ws.flow4_a, 2, ws.x_a, 254)
+        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.c1a, False, ws.conf_in, 0)
+        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.flow_ba, True, ws.conf_in, 4)
 
     def _flow_chain_tail(self, ws: Workspace, P, need_b: bool):
         """7x7 flow stems + 3x3 (core/update.py:187-191, :94-95) -> cat_a[128:256], cat_b[192:256]."""
@@ -389,17 +397,33 @@ class Engine:
         lib.conv2d(d, B, H8, W8, ws.x_a)
 
     def _conf_chain(self, ws: Workspace, P):
-        """feature warps + groupwise corr + confidence stem (:173-182, core/update.py:193-194) -> cat_a[256:272]."""
-        lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
-        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.c1a, False, ws.conf_in, 0)
-        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.flow_ba, True, ws.conf_in, 4)
-        for dc, x, out, off in ((P["a.cf1"], ws.conf_in, ws.conf_mid, 0), (P["a.cf2"], ws.conf_mid, ws.cat_a, 256)):
-            lib.conv2d_direct(x, 0, dc.cin, dc.w, dc.b, out, off, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
+        """confidence stem on conf_in = [flaw_A | flaw_B_A] (core/update.py:193-194) -> cat_a[256:272]."""
+        self._conf_stem(ws, P)
+
+    def _conf_stem(self, ws: Workspace, P):
+        """relu(conv_conf2(relu(conv_conf1(cat[flaw_A, flaw_B_A])))) (core/update.py:193-194): one launch, the 32-channel
+        intermediate map stays in LDS."""
+        c1, c2 = P["a.cf1"], P["a.cf2"]
+        assert (c1.cin, c1.cout, c1.kh, c1.kw, c2.cin, c2.cout, c2.kh, c2.kw) == (8, 32, 3, 3, 32, 16, 3, 3)
+        self.lib.conf_stem(ws.conf_in, 0, c1.w, c1.b, c2.w, c2.b, ws.cat_a, 256, ws.B, ws.H8, ws.W8)
 
     def _corr_chain(self, ws: Workspace, P, need_b: bool, fork_from=None):
         """DCCL lookups (K3+K4; :185-188) + 1x1 + 3x3 of the motion encoders -> cat_a[0:128], cat_b[0:192].
         A looks into B through grid(R_A2B^T)==grid(R_B2A) and rotates back with grid(R_B2A); B the other way."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
+        # bf16x3: rotate-back + add + convc1 are ONE launch (pf_dccl_combine_conv1x1): corr_a / corr_b never exist
+        fused = P["precision"] == PREC_BF16X3 and os.environ.get("PRIORFLOW_FUSED_COMBINE", "1") != "0"
+
+        def look_a():
+            lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
+            if not fused:
+                lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+
+        def look_b():
+            lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b, ws.g_a2b_8_il)
+            if not fused:
+                lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
+
         if need_b and self.forks & 4:
             # the two branches' lookups are independent gather chains: B's runs beside A's
             main, sb = torch.cuda.current_stream(), self.side[2]
@@ -409,8 +433,7 @@ class Engine:
                 if ev is None:
                     ev = torch.cuda.Event()
                     ev.record(main)
-                lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
-                lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+                look_a()
                 sb.wait_event(ev)
             elif fork_from is not None:
                 sb.wait_event(fork_from)
@@ -418,23 +441,25 @@ class Engine:
                 sb.wait_stream(main)
             self._await_b(sb, keep=True)
             with torch.cuda.stream(sb):
-                lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b, ws.g_a2b_8_il)
-                lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
+                look_b()
             if not a_first:
-                lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
-                lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+                look_a()
             main.wait_stream(sb)
         else:
-            lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
-            lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
+            look_a()
             if need_b:
                 self._await_b(torch.cuda.current_stream(), keep=True)
-                lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b, ws.g_a2b_8_il)
-                lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
-        d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
-        if need_b:
-            d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, ws.c1_b, 0, EPI_RELU))
-        lib.conv2d(d, B, H8, W8, ws.x_a)
+                look_b()
+        if fused:
+            items = [(ws.own, ws.raw, ws.g_b2a_8, P["a.c1"], ws.c1_a, 0)]
+            if need_b:
+                items.append((ws.own_b, ws.raw_b, ws.g_a2b_8, P["b.c1"], ws.c1_b, 0))
+            lib.dccl_combine_conv1x1(items, B, H8, W8)
+        else:
+            d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
+            if need_b:
+                d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, ws.c1_b, 0, EPI_RELU))
+            lib.conv2d(d, B, H8, W8, ws.x_a)
         d = [P["a.c2"].desc(ws.c1_a, 0, 256, ws.cat_a, 0, EPI_RELU)]
         if need_b:
             d.append(P["b.c2"].desc(ws.c1_b, 0, 256, ws.cat_b, 0, EPI_RELU))
@@ -444,8 +469,6 @@ class Engine:
         """flows, flo_rotate and the DCCL lookups of one iteration, single stream (tests)."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
         self._flow_chain_head(ws)
-        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.c1a, False, ws.conf_in, 0)
-        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.flow_ba, True, ws.conf_in, 4)
         lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
         lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
         if need_b:
@@ -481,7 +504,7 @@ class Engine:
             head_done = torch.cuda.Event()
             head_done.record(s1)
             self._flow_chain_tail(ws, P, need_b)
-        s2.wait_event(head_done)            # warp #2 needs flow_ba
+        s2.wait_event(head_done)            # the confidence stem needs conf_in
         with torch.cuda.stream(s2):
             self._conf_chain(ws, P)
         if order != "main-first":
@@ -513,8 +536,7 @@ class Engine:
                 d.append(P["b.c2"].desc(ws.c1_b, 0, 256, ws.cat_b, 0, EPI_RELU))
             conv(d)
             self._flow_chain_tail(ws, P, need_b)
-            for dc, x, out, off in ((P["a.cf1"], ws.conf_in, ws.conf_mid, 0), (P["a.cf2"], ws.conf_mid, ws.cat_a, 256)):
-                lib.conv2d_direct(x, 0, dc.cin, dc.w, dc.b, out, off, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
+            self._conf_stem(ws, P)
         d = [P["a.out"].desc(ws.cat_a, 0, 272, ws.x_a, 128, EPI_RELU)]
         if need_b:
             d.append(P["b.out"].desc(ws.cat_b, 0, 272, ws.x_b, 128, EPI_RELU))

@@ -123,4 +123,72 @@ extern "C" int pf_warp_gcorr(const float* f1, const float* f2, const float* coor
     if (rc != PF_OK) return rc;
     return PF_LAUNCH(warp_gcorr, a, (long)B * H8 * W8 * 4, stream);
 }
+// host statement of the fused confidence stem: two direct convolutions through a temporary
+extern "C" int pf_conf_stem(const float* in, int ld_in, int off_in, const float* w1, const float* b1,
+                            const float* w2, const float* b2, float* out, int ld_out, int off_out,
+                            int B, int H8, int W8, void*) {
+    if (!in || !w1 || !b1 || !w2 || !b2 || !out) return PF_ERR_BAD_ARG;
+    if (B <= 0 || H8 <= 0 || W8 <= 0) return PF_ERR_BAD_SHAPE;
+    const long N = (long)H8 * W8;
+    float* mid = new float[(size_t)B * N * 32];
+    for (int layer = 0; layer < 2; ++layer) {
+        const int cin = layer ? 32 : 8, cout = layer ? 16 : 32;
+        const float* src = layer ? mid : in; const int lds = layer ? 32 : ld_in, offs = layer ? 0 : off_in;
+        float* dst = layer ? out : mid; const int ldd = layer ? ld_out : 32, offd = layer ? off_out : 0;
+        const float* w = layer ? w2 : w1; const float* bias = layer ? b2 : b1;
+#pragma omp parallel for
+        for (long row = 0; row < B * N; ++row) {
+            const long b = row / N, n = row % N;
+            const int y = (int)(n / W8), x = (int)(n % W8);
+            for (int co = 0; co < cout; ++co) {
+                float acc = bias[co];
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if (yy < 0 || yy >= H8 || xx < 0 || xx >= W8) continue;
+                    const float* s = src + (b * N + (long)yy * W8 + xx) * lds + offs;
+                    for (int ci = 0; ci < cin; ++ci) acc = fmaf(s[ci], w[(t * cin + ci) * cout + co], acc);
+                }
+                dst[row * ldd + offd + co] = acc > 0.f ? acc : 0.f;
+            }
+        }
+    }
+    delete[] mid;
+    return PF_OK;
+}
+// scalar statement of the fused motion-prep launch (the device kernel spreads the channels of the two warps over a wave)
+extern "C" int pf_motion_prep(const float* c1a, const float* c1b, const float* g_w2c, const float* g_c2w,
+                              const float* f1a, const float* f2a, float* flow4_a, float* flow2_b,
+                              float* xa, int xa_ld, int xa_off, float* xb, int xb_ld, int xb_off,
+                              float* conf, int conf_ld, int B, int H8, int W8, int C, void*) {
+    if (!c1a || !c1b || !g_w2c || !g_c2w || !f1a || !f2a || !flow4_a || !flow2_b || !conf) return PF_ERR_BAD_ARG;
+    if (B <= 0 || H8 <= 1 || W8 <= 1 || C != 256 || conf_ld < 8) return PF_ERR_BAD_SHAPE;
+    PfMotionPrepArgs a;
+    a.c1a = c1a; a.c1b = c1b; a.g_w2c = g_w2c; a.g_c2w = g_c2w; a.f1 = f1a; a.f2 = f2a;
+    a.flow4_a = flow4_a; a.flow2_b = flow2_b;
+    a.xa = pf_dst(xa, xa_ld, xa_off); a.xb = pf_dst(xb, xb_ld, xb_off);
+    a.conf = conf; a.conf_ld = conf_ld; a.B = B; a.H = H8; a.W = W8;
+    const long N = (long)H8 * W8;
+#pragma omp parallel for
+    for (long row = 0; row < B * N; ++row) {
+        const long b = row / N, n = row % N;
+        const PfMotionFlows f = pf_motion_flows(row, a);
+        float* o = flow4_a + row * 4;
+        o[0] = f.ua; o[1] = f.va; o[2] = f.uba; o[3] = f.vba;
+        flow2_b[row * 2] = f.ub; flow2_b[row * 2 + 1] = f.vb;
+        if (a.xa.ptr) { float* d = a.xa.ptr + row * a.xa.ld + a.xa.c_off; d[0] = f.ua; d[1] = f.va; d[2] = f.uba; d[3] = f.vba; }
+        pf_store_dst2(a.xb, row, f.ub, f.vb);
+        for (int wsel = 0; wsel < 2; ++wsel) {
+            const float x = wsel == 0 ? c1a[(b * 2 + 0) * N + n] : (float)(n % W8) + f.uba;
+            const float y = wsel == 0 ? c1a[(b * 2 + 1) * N + n] : (float)(n / W8) + f.vba;
+            const PfTaps t = pf_taps0(pf_pymod(x, (float)W8), y, H8, W8);
+            for (int g = 0; g < 4; ++g) {
+                float acc = 0.f;
+                for (int c = g * 64; c < (g + 1) * 64; ++c)
+                    acc = acc + f1a[row * 256 + c] * pf_apply_ld(t, f2a + b * N * 256 + c, 256);
+                conf[row * conf_ld + 4 * wsel + g] = acc / 64.f;
+            }
+        }
+    }
+    return PF_OK;
+}
 extern "C" const char* pf_version(void) { return "priorflow host emulation (tests only)"; }

@@ -189,6 +189,55 @@ def case_warp_gcorr(lib, dev):
     check(uncl(dst[:, 4:].cpu(), 1, H8, W8), want, 2e-4, "warp_gcorr add_grid")
 
 
+def case_motion_prep(lib, dev):
+    """pf_motion_prep (core/prior_raft.py:171-182 in one launch) against the oracle: flows of both branches,
+    flo_rotate(flow_B) into view A, groupwise correlations at coords1_A and at coords0 + flow_B_A."""
+    import math
+    B = 2
+    c1a, c1b = gc.nasty_coords("mprep/a", B), gc.nasty_coords("mprep/b", B)
+    f1, f2 = gc.fmaps("mprep", B)
+    g = po.grids_for(8 * H8, 8 * W8)
+    flow4, flow2 = torch.zeros(B * N, 4, device=dev), torch.zeros(B * N, 2, device=dev)
+    xa, xb = torch.full((B * N, 8), 7.25, device=dev), torch.full((B * N, 4), 7.25, device=dev)
+    conf = torch.zeros(B * N, 8, device=dev)
+    ga = torch.empty(2, H8, W8, device=dev)
+    gb = torch.empty(2, H8, W8, device=dev)
+    lib.sample_grid(ga, po.rotation_x(-math.pi / 2))
+    lib.sample_grid(gb, po.rotation_x(math.pi / 2))
+    lib.motion_prep(c1a.to(dev), c1b.to(dev), ga, gb, cl(f1).to(dev), cl(f2).to(dev), flow4, flow2, conf, xa, 4, xb, 2)
+    c0 = po.coords_grid(B, H8, W8)
+    flow_a, flow_b = c1a - c0, c1b - c0
+    flow_ba = po.flo_rotate(flow_b, g["b2a_w2c_8"], g["b2a_8"])      # W2C = grid(R_B2A^T), C2W = grid(R_B2A) (:179)
+    check(flow4[:, :2], cl(flow_a), 0.0, "flow_A")
+    check(flow2, cl(flow_b), 0.0, "flow_B")
+    check(flow4[:, 2:], cl(flow_ba), 1e-4, "flow_B_A")      # coordinates up to 2.5 W: an ulp of the wrapped end point is 1e-5
+    check(xa[:, 4:], flow4.cpu(), 0.0, "x_a tail")
+    check(xb[:, 2:], flow2.cpu(), 0.0, "x_b tail")
+    assert float(xa[:, :4].min()) == 7.25 and float(xb[:, :2].max()) == 7.25
+    check(uncl(conf[:, :4].cpu(), B, H8, W8), po.warp_groupwise_corr(f1, f2, c1a), 3e-6, "flaw_A")
+    got_ba = uncl(flow4[:, 2:].cpu(), B, H8, W8)
+    check(uncl(conf[:, 4:].cpu(), B, H8, W8), po.warp_groupwise_corr(f1, f2, c0 + got_ba), 3e-6, "flaw_B_A")
+
+
+def case_conf_stem(lib, dev):
+    """pf_conf_stem: relu(conv3x3 32->16(relu(conv3x3 8->32(x)))) in one launch (core/update.py:193-194) against torch
+    conv2d, on a ragged map (17 x 27: partial tiles on both axes), with padded row strides and column offsets."""
+    import torch.nn.functional as F
+    B, h, w = 2, 17, 27
+    x = gc.uni("confstem/x", (B, 8, h, w), -1, 1)
+    w1, b1 = gc.uni("confstem/w1", (32, 8, 3, 3), -0.3, 0.3), gc.uni("confstem/b1", (32,), -0.2, 0.2)
+    w2, b2 = gc.uni("confstem/w2", (16, 32, 3, 3), -0.2, 0.2), gc.uni("confstem/b2", (16,), -0.2, 0.2)
+    want = F.relu(F.conv2d(F.relu(F.conv2d(x, w1, b1, padding=1)), w2, b2, padding=1))
+    pack = lambda t: t.permute(2, 3, 1, 0).reshape(-1, t.shape[0]).contiguous().to(dev)       # [KH*KW*Cin][Cout]
+    xin = torch.full((B * h * w, 12), 9.5, device=dev)
+    xin[:, 4:] = cl(x).to(dev)
+    out = torch.full((B * h * w, 24), 7.25, device=dev)
+    lib.conf_stem(xin, 4, pack(w1), b1.to(dev), pack(w2), b2.to(dev), out, 8, B, h, w)
+    check(uncl(out[:, 8:].cpu(), B, h, w), want, 5e-6, "conf stem")      # 288-term fp32 sums of O(1) values
+    assert float(out[:, :8].min()) == 7.25 and float(out[:, :8].max()) == 7.25, "columns outside the slice were written"
+    assert float((want == 0).float().mean()) > 0.05            # the ReLUs are active
+
+
 def case_upsample(lib, dev):
     fl8 = gc.uni("up/flow", (1, 2, H8, W8), -6, 6)
     mk = gc.uni("up/mask", (1, 576, H8, W8), -2, 2)
@@ -578,7 +627,7 @@ def case_norm_backward(lib, dev):
 
 
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
-                     case_warp_gcorr, case_upsample, case_coords_add, case_layout,
+                     case_warp_gcorr, case_motion_prep, case_conf_stem, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
                      case_flow_metrics, case_training_pieces, case_dccl_backward, case_upsample_backward,
                      case_warp_gcorr_backward, case_gru_gate_backward, case_norm_backward,

@@ -159,6 +159,75 @@ def test_conv_mfma_groups_and_gru(lib, dev, params, prec):
     kc.check(kc.uncl(net_b[c].cpu(), 1, H8, W8), want_b, TOL[prec], "update_block.gru vs oracle")
 
 
+def test_motion_prep_equals_the_five_launches_it_replaces(lib, dev):
+    """pf_motion_prep (flows of both branches, flo_rotate(flow_B), both feature warps + groupwise correlations;
+    core/prior_raft.py:171-182) against pf_flow_prep x2 + pf_flo_rotate + pf_warp_gcorr x2 on nasty coordinates
+    (seam crossers, out-of-range y, multi-wrap x): every output bit for bit, untouched columns untouched."""
+    import math
+    from prior_flow_amd.engine import rotation_x
+    B, h, w = 2, H8, W8
+    n = h * w
+    c1a, c1b = gc.nasty_coords("mprep/a", B).to(dev), gc.nasty_coords("mprep/b", B).to(dev)
+    f1, f2 = (kc.cl(t).to(dev) for t in gc.fmaps("mprep", B))
+    g_a2b, g_b2a = torch.empty(2, h, w, device=dev), torch.empty(2, h, w, device=dev)
+    lib.sample_grid(g_a2b, rotation_x(-math.pi / 2))
+    lib.sample_grid(g_b2a, rotation_x(math.pi / 2))
+
+    def bufs():
+        z = lambda *s: torch.full(s, 7.25, device=dev)        # sentinel: columns no kernel owns must keep it
+        return dict(flow4=z(B * n, 4), flow2=z(B * n, 2), xa=z(B * n, 256), xb=z(B * n, 256), conf=z(B * n, 8))
+    want, got = bufs(), bufs()
+    flow_b, flow_ba = torch.empty(B, 2, h, w, device=dev), torch.empty(B, 2, h, w, device=dev)
+    lib.flow_prep(c1a, None, want["flow4"], 0, want["xa"], 252)
+    lib.flow_prep(c1b, flow_b, want["flow2"], 0, want["xb"], 254)
+    lib.flo_rotate(flow_b, g_a2b, g_b2a, flow_ba, want["flow4"], 2, want["xa"], 254)
+    lib.warp_gcorr(f1, f2, c1a, False, want["conf"], 0)
+    lib.warp_gcorr(f1, f2, flow_ba, True, want["conf"], 4)
+    lib.motion_prep(c1a, c1b, g_a2b, g_b2a, f1, f2, got["flow4"], got["flow2"], got["conf"], got["xa"], 252, got["xb"], 254)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
+    assert float(got["xa"][:, :252].min()) == 7.25 and float(got["xb"][:, :254].max()) == 7.25
+    assert float(got["flow4"].abs().max()) > 1.0 and float(got["conf"].abs().max()) > 1e-3
+
+
+def test_combine_conv1x1_equals_combine_then_conv(lib, dev, params):
+    """pf_dccl_combine_conv1x1 (rotate-back + add + convc1 + ReLU in one launch, the 324-channel tensor never written)
+    against pf_dccl_combine followed by pf_conv2d: bit for bit, both branches in one launch, on a map whose pixel count
+    is not a multiple of the 64-pixel tile, with sentinels in the columns it does not own."""
+    import argparse
+    import math
+    from prior_flow_amd._lib import EPI_RELU, PREC_BF16X3
+    from prior_flow_amd.engine import Conv, rotation_x
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    model.load_state_dict(params)
+    model = model.to(dev)
+    convs = [Conv.of(model.ODDC.encoder.convc1_A, PREC_BF16X3), Conv.of(model.update_block.encoder.convc1, PREC_BF16X3)]
+    B, h, w = 2, 17, 27                       # 918 rows: 14 full tiles + 22 pixels
+    n = h * w
+    grids = [torch.empty(2, h, w, device=dev) for _ in range(2)]
+    lib.sample_grid(grids[0], rotation_x(math.pi / 2))
+    lib.sample_grid(grids[1], rotation_x(-math.pi / 2))
+    own = [gc.uni(f"cc/own{i}", (B * n, 324), -3, 3).to(dev) for i in range(2)]
+    raw = [gc.uni(f"cc/raw{i}", (B * n, 324), -3, 3).to(dev) for i in range(2)]
+    want = [torch.full((B * n, 264), 7.25, device=dev) for _ in range(2)]
+    got = [torch.full((B * n, 264), 7.25, device=dev) for _ in range(2)]
+    corr = [torch.empty(B * n, 324, device=dev) for _ in range(2)]
+    for i in range(2):
+        lib.dccl_combine(own[i], raw[i], grids[i], corr[i], B, h, w)
+    lib.conv2d([convs[i].desc(corr[i], 0, 324, want[i], 4, EPI_RELU) for i in range(2)], B, h, w, corr[0])
+    lib.dccl_combine_conv1x1([(own[i], raw[i], grids[i], convs[i], got[i], 4) for i in range(2)], B, h, w)
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(want[i], got[i]), f"branch {i}: max diff {float((want[i] - got[i]).abs().max()):.3e}"
+        assert float(got[i][:, :4].min()) == 7.25 and float(got[i][:, 260:].max()) == 7.25
+        assert float((got[i][:, 4:260] > 0).float().mean()) > 0.2
+    single = torch.full((B * n, 264), 7.25, device=dev)
+    lib.dccl_combine_conv1x1([(own[1], raw[1], grids[1], convs[1], single, 4)], B, h, w)       # one group
+    assert torch.equal(single, want[1])
+
+
 # ---- corr volume + pyramid -------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 16, 64), (1, 24, 40), (1, 16, 24)],
                          ids=lambda s: "B%dx%dx%d" % s)
