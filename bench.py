@@ -15,14 +15,16 @@ the parent makes NO GPU call, starts N fresh child processes of this script with
 127.0.0.1, relays rank 0's JSON line and exits with the worst child status.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (exact-fp32 MFMA implicit-GEMM conv of the update blocks):
-                algorithmic FLOPs of its launches in one forward / their HIP-event time, vs the
-                157.3 TFLOP/s fp32 matrix peak of gfx950;
+  roofline      the dominant kernel (MFMA implicit-GEMM conv of the update blocks): algorithmic FLOPs of
+                its launches in one forward / their HIP-event time, vs the dense bf16 MFMA peak (bf16x3
+                mode: 3 MFMA FLOPs per algorithmic FLOP, reported as mfma_pipe_util) or the fp32 MFMA peak;
   roofline_corr the fused correlation-volume + pyramid build (north_star's HBM target):
                 algorithmic bytes / HIP-event time vs 8 TB/s;
   cpu_baseline  the CPU oracle (oracle/priorflow_oracle.py, the checker -- never the product)
                 timed on the host cores on the same pair, rank 0 at N=1 only, plus the EPE of
-                the GPU flow against it.
+                the GPU flow against it (`parity`);
+  fp32_exact    the same forward in exact-fp32 MFMA arithmetic (the strict reference point beside the
+                bf16x3 headline): pairs/s and EPE vs the oracle, rank 0 at N=1 only.
 """
 from __future__ import annotations
 
@@ -40,6 +42,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import torch  # noqa: E402
 
 H, W, ITERS = 512, 1024, 12
+PMC_FILE = "r2_pmc_traffic.json"   # rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py); not re-measured per run
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
@@ -98,7 +101,7 @@ def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/pmc_traffic.py:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950, KiB -> bytes).
     Counters cannot be collected inside this process; None when the profile file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_FILE)
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -201,7 +204,7 @@ def profile_kernels(model, i1, i2):
                 # the 3-pass split issues 3 bf16 MFMA FLOPs per algorithmic FLOP: pipe utilisation
                 "mfma_issue_tflops": round(achieved * (3 if split else 1), 2),
                 "mfma_pipe_util": round(achieved * (3 if split else 1) / peak, 4),
-                "traffic": pmc_traffic(str(dom)), "traffic_note": "HBM-side bytes/launch, profiles/r1_pmc_traffic.json",
+                "traffic": pmc_traffic(str(dom)), "traffic_note": "HBM-side bytes/launch from the committed PMC passes (profiles/%s): counters cannot be read inside this process" % PMC_FILE,
                 "launches_per_forward": n, "avg_launch_us": round(ms / n * 1e3, 1),
                 "event_gap_us_subtracted": round(gap_ms * 1e3, 2),
                 "gflop_per_forward": round(fl / 1e9, 1),
@@ -212,7 +215,7 @@ def profile_kernels(model, i1, i2):
                      "bound": "hbm",
                      "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                      "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("pf_corr_kernel"),
-                     "traffic_note": "HBM-side bytes/launch, profiles/r1_pmc_traffic.json",
+                     "traffic_note": "HBM-side bytes/launch from the committed PMC passes (profiles/%s)" % PMC_FILE,
                      "launches_per_forward": corr_n, "avg_launch_us": round(corr_t / corr_n * 1e3, 1),
                      "mb_per_launch": round(corr_b / corr_n / 1e6, 1),
                      "note": ("34.4 GFLOP/launch: 3-pass bf16 MFMA + 373 MB of once-written output" if split else
@@ -242,9 +245,40 @@ def cpu_baseline(params, i1, i2, flow_gpu):
           "kind": "port", "sample": f"{1 + len(times)} forwards of the same {i1.shape[0]}x{H}x{W} pair, "
                                       f"iters={ITERS}, torch CPU threads={cores}, best of the timed ones",
           "seconds_per_pair": round(best / i1.shape[0], 3)}
+    cb["reference_note"] = ("the reference itself (imported on CPU in the build container, 8 cores): 7.56 s/pair = 0.132 pairs/s "
+                            "(BASELINE.md section 2); this line times the oracle restatement on this host")
     parity = {"epe_mean": float(epe.mean()), "epe_max": float(epe.max()), "bar": 1e-3,
-              "flow_mean_abs": float(ref.abs().mean())}
-    return cb, parity
+              "flow_mean_abs": float(ref.abs().mean()),
+              "weights": "deterministic synthetic weights with the statistics of a freshly initialised model (no checkpoints "
+                         "offline); the bar is on the mean, isolated pixels reach 1e-2 in sweeps (profiles/r1_parity_sweep.txt)"}
+    return cb, parity, ref
+
+
+def fp32_reference_point(params, device, i1, i2, ref_cpu, steps=5):
+    """The strict reference point beside the bf16x3 headline: the same forward in exact-fp32 MFMA arithmetic
+    (model.precision = PREC_F32; encoders and update blocks on the HIP library), pairs/s and EPE vs the CPU oracle."""
+    from prior_flow_amd._lib import PREC_F32
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    import priorflow_oracle as po
+    m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    m.load_state_dict(params, strict=True)
+    m = m.to(device).eval()
+    m.precision = PREC_F32
+    with torch.no_grad():
+        for _ in range(2):
+            flow = m(i1, i2, iters=ITERS, test_mode=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            flow = m(i1, i2, iters=ITERS, test_mode=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out = {"dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)", "value": round(i1.shape[0] * steps / dt, 3), "unit": "frame-pairs/s",
+           "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps}
+    if ref_cpu is not None:
+        epe = po.epe(flow.cpu(), ref_cpu)
+        out["epe_mean"], out["epe_max"] = float(epe.mean()), float(epe.max())
+    return out
 
 
 def self_launch(args) -> int:
@@ -356,8 +390,7 @@ def main():
                                       + (f"; timing barrier / max over {backend}" if dist is not None else ""),
                        "weights": "deterministic closed-form fill (no checkpoints offline)",
                        "hip_graph": bool(model.use_graph),
-                       "encoders": ("libpriorflow_hip.so (HIP kernels)" if model._weights()["precision"] == 1
-                                    else "PyTorch-ROCm convs (exact-fp32 mode)")},
+                       "encoders": "libpriorflow_hip.so (HIP kernels, both precisions)"},
         }
         try:
             log("per-kernel HIP-event pass")
@@ -365,10 +398,16 @@ def main():
         except Exception as exc:  # measured extras must not hide the headline number
             result["roofline"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
+            ref_cpu = None
             try:
-                result["cpu_baseline"], result["parity"] = cpu_baseline(params, i1c, i2c, flow)
+                result["cpu_baseline"], result["parity"], ref_cpu = cpu_baseline(params, i1c, i2c, flow)
             except Exception as exc:
                 result["cpu_baseline"] = {"error": repr(exc)}
+            if model._weights()["precision"] == 1:
+                try:
+                    result["fp32_exact"] = fp32_reference_point(params, device, i1, i2, ref_cpu)
+                except Exception as exc:
+                    result["fp32_exact"] = {"error": repr(exc)}
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -24,7 +24,7 @@ import torch
 
 import os
 
-from ._lib import (ACT_RELU, ACT_TANH, EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_RELU, PREC_BF16X3, PREC_F32,
+from ._lib import (EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_RELU, PREC_BF16X3, PREC_F32,
                    ConvDesc, PfError, PfLib)
 
 CORR_CH = 324
@@ -302,19 +302,7 @@ class Engine:
         self.lib.img_rotate(ws.img_stack, ws.g_a2b, ws.img_rot)
         return ws.img_rot[:, :3], ws.img_rot[:, 3:]
 
-    # ---- stage 1: features -> channel-last, corr volumes + pyramids --------------------------
-    def load_features(self, ws: Workspace, fmaps: torch.Tensor, cnet: torch.Tensor):
-        """fmaps: NCHW [4B,256,H8,W8] = (f1A,f2A,f1B,f2B); cnet: NCHW [2B,256,H8,W8] = (A,B).
-        net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) (core/prior_raft.py:136-142)."""
-        B, lib = ws.B, self.lib
-        for i, k in enumerate(("f1a", "f2a", "f1b", "f2b")):
-            lib.to_channel_last(fmaps[i * B:(i + 1) * B].contiguous(), 0, 256, ws.f[k], 0)
-        ca, cb = cnet[:B].contiguous(), cnet[B:].contiguous()
-        lib.to_channel_last(ca, 0, 128, ws.net_a[0], 0, ACT_TANH)
-        lib.to_channel_last(ca, 128, 128, ws.x_a, 0, ACT_RELU)
-        lib.to_channel_last(cb, 0, 128, ws.net_b[0], 0, ACT_TANH)
-        lib.to_channel_last(cb, 128, 128, ws.x_b, 0, ACT_RELU)
-
+    # ---- stage 1: corr volumes + pyramids (the encoders write the channel-last features themselves) ----------
     def build_pyramids(self, ws: Workspace, precision: int = PREC_F32):
         """corr + build_pyramid for both views (core/prior_raft.py:151-159)."""
         if precision == PREC_BF16X3:
@@ -683,7 +671,7 @@ class EncoderPlan:
         lib, bufs = self.lib, self._bufs
         d = cv.desc(x, 0, cin, y, 0, EPI_LINEAR, **kw)
         fused = False
-        if self.kind != "batch":
+        if self.kind != "batch" and self.precision == PREC_BF16X3:
             tile = lib.conv2d_tile([d], Bn, h, w)
             if tile >= 3:
                 th = 8 if tile == 5 else 4
@@ -751,9 +739,14 @@ class EncoderPlan:
             Np = h * w
             # conv1 (input x is a materialised activation: no affine)
             s1, t1 = self._conv_norm(blk["c1"], blk["n1"], x, cin, y1, Bn, h, w, cout, 0, stride=st)
-            # conv2 consumes relu(norm1(y1)) folded into its load
-            s2, t2 = self._conv_norm(blk["c2"], blk["n2"], y1, cout, y2, Bn, h, w, cout, 1,
-                                     in_scale=s1, in_shift=t1, in_relu=True)
+            if self.precision == PREC_BF16X3:
+                # conv2 consumes relu(norm1(y1)) folded into its load
+                s2, t2 = self._conv_norm(blk["c2"], blk["n2"], y1, cout, y2, Bn, h, w, cout, 1,
+                                         in_scale=s1, in_shift=t1, in_relu=True)
+            else:
+                # exact-fp32 mode (generic MFMA kernel: no input affine): relu(norm1(y1)) is materialised into `o`
+                lib.norm_act(y1, s1, t1, o, Bn, Np, cout)
+                s2, t2 = self._conv_norm(blk["c2"], blk["n2"], o, cout, y2, Bn, h, w, cout, 1)
             if st != 1:
                 # shortcut: norm3(conv1x1/2(x)); reuse y1 (conv2 has consumed it) for the raw shortcut
                 lib.conv2d([blk["ds"].desc(x, 0, cin, y1, 0, EPI_LINEAR, stride=st)], Bn, h, w, x)

@@ -93,14 +93,14 @@ class PriOr_RAFT(nn.Module):
         return ws
 
     def _encoder_plans(self):
-        """HIP launch plans of cnet / fnet (bf16x3 mode), rebuilt when their weights change."""
+        """HIP launch plans of cnet / fnet (either precision), rebuilt when their weights or the precision change."""
+        precision = default_precision() if self.precision is None else self.precision
         params = list(self.fnet.parameters()) + list(self.cnet.parameters()) + list(self.cnet.buffers())
-        sig = tuple((p.data_ptr(), p._version) for p in params) + (_lib.weights_epoch(),)
+        sig = tuple((p.data_ptr(), p._version) for p in params) + (_lib.weights_epoch(), precision)
         if self._enc_plans is None or sig != self._enc_sig:
-            from ._lib import PREC_BF16X3
             with torch.no_grad():
-                self._enc_plans = (EncoderPlan(self._lib(), self.cnet, PREC_BF16X3),
-                                   EncoderPlan(self._lib(), self.fnet, PREC_BF16X3))
+                self._enc_plans = (EncoderPlan(self._lib(), self.cnet, precision),
+                                   EncoderPlan(self._lib(), self.fnet, precision))
             self._enc_sig = sig
             self._graphs.clear()
         return self._enc_plans
@@ -109,51 +109,42 @@ class PriOr_RAFT(nn.Module):
         """Normalise, rotate to view B, run cnet / fnet (core/prior_raft.py:109-149) and leave the
         features in the workspace (channel-last): f1A,f2A,f1B,f2B; net = tanh(cnet[:128]),
         inp = relu(cnet[128:]) for both views."""
-        from ._lib import EPI_LINEAR, EPI_TANH_RELU, PREC_BF16X3
+        from ._lib import EPI_LINEAR, EPI_TANH_RELU
         B = ws.B
         image1 = 2 * (image1 / 255.0) - 1.0
         image2 = 2 * (image2 / 255.0) - 1.0
         image1_b, image2_b = eng.rotate_images(ws, image1, image2)
-        precision = default_precision() if self.precision is None else self.precision
-        if precision == PREC_BF16X3 and not self.training:
-            cplan, fplan = self._encoder_plans()
-            ws.img_c[:B].copy_(image1); ws.img_c[B:].copy_(image1_b)
-            ws.img_f[:B].copy_(image1); ws.img_f[B:2 * B].copy_(image2)
-            ws.img_f[2 * B:3 * B].copy_(image1_b); ws.img_f[3 * B:].copy_(image2_b)
-            if self.use_streams and int(os.environ.get("PRIORFLOW_FORKS", "15")) & 1:
-                # cnet and fnet are independent: fork them onto two side streams (the fork/join
-                # is captured into the HIP graph as parallel branches) so that the latency-bound
-                # kernels of one (stem, statistics) hide behind the other's convolutions
-                cur = torch.cuda.current_stream()
-                s1, s2 = self._streams()[:2]
-                if int(os.environ.get("PRIORFLOW_ORDER", "15")) & 8:
-                    # fnet (the longer chain) stays on the calling stream and is enqueued first; cnet forks from an event
-                    ev = torch.cuda.Event()
-                    ev.record(cur)
-                    fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
-                    s1.wait_event(ev)
-                    with torch.cuda.stream(s1):
-                        cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
-                    cur.wait_stream(s1)
-                else:
-                    s1.wait_stream(cur)
-                    s2.wait_stream(cur)
-                    with torch.cuda.stream(s1):
-                        cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
-                    with torch.cuda.stream(s2):
-                        fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
-                    cur.wait_stream(s1)
-                    cur.wait_stream(s2)
-            else:
-                cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+        cplan, fplan = self._encoder_plans()       # both precisions run on the HIP library: there is no PyTorch-ROCm branch
+        ws.img_c[:B].copy_(image1); ws.img_c[B:].copy_(image1_b)
+        ws.img_f[:B].copy_(image1); ws.img_f[B:2 * B].copy_(image2)
+        ws.img_f[2 * B:3 * B].copy_(image1_b); ws.img_f[3 * B:].copy_(image2_b)
+        if self.use_streams and int(os.environ.get("PRIORFLOW_FORKS", "15")) & 1:
+            # cnet and fnet are independent: fork them onto two side streams (the fork/join
+            # is captured into the HIP graph as parallel branches) so that the latency-bound
+            # kernels of one (stem, statistics) hide behind the other's convolutions
+            cur = torch.cuda.current_stream()
+            s1, s2 = self._streams()[:2]
+            if int(os.environ.get("PRIORFLOW_ORDER", "15")) & 8:
+                # fnet (the longer chain) stays on the calling stream and is enqueued first; cnet forks from an event
+                ev = torch.cuda.Event()
+                ev.record(cur)
                 fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
-            return
-        # exact-fp32 mode: the encoders stay on PyTorch-ROCm convolutions
-        amp = bool(getattr(self.args, "mixed_precision", False))
-        with torch.autocast("cuda", enabled=amp):
-            cnet = self.cnet(torch.cat([image1, image1_b], 0))
-            fmaps = self.fnet(torch.cat([image1, image2, image1_b, image2_b], 0))
-        eng.load_features(ws, fmaps.float(), cnet.float())
+                s1.wait_event(ev)
+                with torch.cuda.stream(s1):
+                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+                cur.wait_stream(s1)
+            else:
+                s1.wait_stream(cur)
+                s2.wait_stream(cur)
+                with torch.cuda.stream(s1):
+                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+                with torch.cuda.stream(s2):
+                    fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
+                cur.wait_stream(s1)
+                cur.wait_stream(s2)
+        else:
+            cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+            fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
 
     def _streams(self):
         if self._side_streams is None:
@@ -218,9 +209,7 @@ class PriOr_RAFT(nn.Module):
         # both signature checks clear self._graphs when a parameter (or a cnet BatchNorm statistic) changed in place:
         # the captured launches hold pointers to PACKED copies of the weights, of the encoders' too
         self._weights()
-        from ._lib import PREC_BF16X3
-        if (default_precision() if self.precision is None else self.precision) == PREC_BF16X3:
-            self._encoder_plans()
+        self._encoder_plans()
         key = (ws.B, ws.H, ws.W, iters, str(image1.device))
         entry = self._graphs.get(key)
         if entry is None:
