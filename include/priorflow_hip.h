@@ -345,6 +345,15 @@ int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const float* x1,
                     const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
                     int kh, int kw, int B, int H8, int W8, void* stream);
 
+/* Weight / bias gradient of a small-Cin convolution (the 7x7 stems: core/extractor.py:122 3->64 stride 2,
+ * core/update.py:87,173,175 2->128 stride 1; their inputs carry no gradient): exact fp32,
+ *   dw[o][c][ky][kx] += sum_p dy[p][o] * x[stride*p + (ky,kx) - pad][c],  db[o] += sum_p dy[p][o]
+ * x: NCHW planes (nchw != 0) or a channel-last slice; dy: channel-last [B*Hout*Wout][ld_dy]; dw in the framework's own
+ * parameter layout [Cout][Cin][KH][KW]; dw, db ACCUMULATED.  cin <= 4, kh*kw <= 52, stride 1 | 2. */
+int pf_conv2d_wgrad_small(const float* x, int nchw, int ld_in, int off_in, int cin,
+                          const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
+                          int kh, int kw, int stride, int B, int Hout, int Wout, void* stream);
+
 /* channel-last slice -> NCHW. */
 int pf_to_nchw(const float* in, int ld_in, int off_in, int c, float* out, int B, int N,
                void* stream);

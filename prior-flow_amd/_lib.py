@@ -81,6 +81,7 @@ _SIGNATURES = {
     "pf_upsample_flow": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
+    "pf_conv2d_wgrad_small": [_fp, _i, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp],
     "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
     "pf_warp_gcorr_bwd": [_fp, _fp, _fp, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow_bwd": [_fp, _fp, _i, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
@@ -319,6 +320,13 @@ class PfLib:
                                            kh, kw, stride, int(relu), B, Hout, Wout, self._stream(x)),
                  "pf_conv2d_small")
 
+    def conv2d_wgrad_small(self, x, nchw, off_in, cin, dy, off_dy, cout, dw, db, kh, kw, stride, B, Hout, Wout):
+        """dw [Cout,Cin,KH,KW] (+= ), db [Cout] (+= or None) of a small-Cin convolution; x NCHW planes or channel-last."""
+        self._chk(x, dy, dw, db)
+        self._rc(self._dll.pf_conv2d_wgrad_small(_ptr(x), int(nchw), 0 if nchw else x.shape[-1], off_in, cin,
+                                                 _ptr(dy), dy.shape[-1], off_dy, cout, _ptr(dw), _ptr(db),
+                                                 kh, kw, stride, B, Hout, Wout, self._stream(x)), "pf_conv2d_wgrad_small")
+
     def channel_stats(self, y, B, Np, Cch, scale, shift, partials, nblk, eps=1e-5):
         self._chk(y, scale, shift)
         if partials.dtype != torch.float64 or partials.numel() < B * nblk * Cch * 2:
@@ -414,6 +422,18 @@ class PfLib:
         self._rc(self._dll.pf_norm_bwd(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), int(relu), int(instance),
                                        _ptr(part), nblk or 0, _ptr(coef), _ptr(dx), B, Np, Cc, self._stream(dy)),
                  "pf_norm_bwd")
+
+    def norm_bwd_sums(self, dy, x, scale, shift, B, Np, Cc, nblk=None):
+        """Per-(image, channel) means of g and g * (x*scale+shift) over the Np pixels: [B, C, 2] (the reduction stage of
+        pf_norm_bwd's InstanceNorm branch; its dx is written to a scratch buffer and discarded)."""
+        self._chk(dy, x, scale, shift)
+        nblk = nblk or max(1, min(Np, Np // 64))
+        part = torch.empty(B * nblk * Cc * 2, dtype=torch.float64, device=dy.device)
+        coef = torch.empty(B * Cc * 2, dtype=torch.float32, device=dy.device)
+        scratch = torch.empty_like(x)
+        self._rc(self._dll.pf_norm_bwd(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), 0, 1, _ptr(part), nblk, _ptr(coef),
+                                       _ptr(scratch), B, Np, Cc, self._stream(dy)), "pf_norm_bwd")
+        return coef.view(B, Cc, 2)
 
     def gru_q_bwd(self, dh_new, z, q, h, dq_pre, dz, dh):
         """Stage Q of the GRU gate backward; every argument a channel-last [rows, >=C] view (C = dh_new.shape[-1])."""

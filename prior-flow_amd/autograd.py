@@ -8,7 +8,10 @@ in BOTH directions, of every heavy operator:
   ---------------------------------------------  -------------------------------  ----------------------------------------
   nn.Conv2d 3x3 / 1x5 / 5x1 / 1x1, stride 1      pf_conv2d (bf16x3 MFMA)          pf_conv2d on flipped weights (dgrad),
                                                                                   pf_conv2d_wgrad (+ bias column sums)
-  corr + build_pyramid (prior_raft.py:69-75)     pf_corr_pyramid_bf16x3           pf_pyramid_bwd + two feature GEMMs
+  nn.Conv2d 3x3 / 1x1, stride 2 (extractor.py)   pf_conv2d, stride 2              the same two on the zero-stuffed dY
+  nn.Conv2d 7x7 stems (3->64 /2, 2->128)         pf_conv2d_small (exact fp32)     pf_conv2d_wgrad_small (inputs carry no gradient)
+  nn.BatchNorm2d, frozen (freeze_bn)             elementwise affine               pf_norm_bwd (dx, and the sums for d gamma / d beta)
+  corr + build_pyramid (prior_raft.py:69-75)     pf_corr_pyramid_bf16x3           pf_pyramid_bwd + two MFMA GEMMs (pf_conv2d 1x1)
   DCCL.__call__ own + cross (corr.py:113-144)    pf_dccl_lookup + pf_dccl_combine pf_dccl_combine_bwd + pf_dccl_lookup_bwd
   warp + groupwise_corr (prior_raft.py:173-182)  pf_warp_gcorr                    pf_warp_gcorr_bwd
   upsample_flow (prior_raft.py:58-67)            pf_upsample_flow                 pf_upsample_flow_bwd
@@ -16,9 +19,11 @@ in BOTH directions, of every heavy operator:
   InstanceNorm2d (extractor.py:112-113)          elementwise                      pf_norm_bwd
   img_rotate / flo_rotate / sample grids         pf_img_rotate / pf_flo_rotate    (inputs are detached in the reference)
 
-Left on PyTorch-ROCm device ops (plumbing; no HIP backward kernel exists for them yet): the three stride-2
-convolutions and the 7x7/2 stem of each encoder, the 7x7 2->128 flow stems, BatchNorm2d of cnet, ReLU / tanh /
-sigmoid outside the GRU backward, torch.cat / slicing, and the feature GEMMs of the corr backward (torch.bmm).
+No convolution, normalisation or GEMM of a training step runs on PyTorch-ROCm kernels (STATS["torch"] stays 0 for the
+reference's configuration: BatchNorm frozen, train_flow.py:107-108).  What torch still does is plumbing on device
+tensors: ReLU / tanh / sigmoid forward, torch.cat / slicing / transposes, the zero-stuffing copy of a stride-2
+gradient, and autograd's own bookkeeping.  A BatchNorm left in training mode (batch statistics) is the one operator
+without a HIP backward: it falls back to F.batch_norm and is counted in STATS["torch"].
 There is no CPU path: every tensor must live on a ROCm device and ``_lib.load()`` raises when the HIP library
 is missing.  ``args.mixed_precision`` (CUDA autocast + GradScaler in the reference, train_flow.py:112,131-139) has no
 counterpart here: the convolutions run the 3-pass bf16 split with fp32 accumulation and fp32 storage, which needs no
@@ -184,6 +189,116 @@ class HipConv(torch.autograd.Function):
         return dx, Conv.unpack_wgrad(dw, cout, C, kh, kw), db[:cout].clone(), None, None, None
 
 
+class HipConvS2(torch.autograd.Function):
+    """Stride-2 convolution (3x3 pad 1 / 1x1 pad 0: the encoders' down-sampling layers, core/extractor.py:16-17,30-33):
+    pf_conv2d(stride = 2) forward.  Backward on the ZERO-STUFFED gradient dYu (dYu[2p] = dY[p], zero elsewhere, input
+    resolution): dX = stride-1 conv of dYu with the flipped weights, dW = stride-1 weight gradient of (X, dYu) --
+    out[p] = sum_k w[k] x[2p + k - pad]  =>  dX[q] = sum_k w[k] dYu[q - k + pad],  dW[k] = sum_q dYu[q] x[q + k - pad]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        cout, _, kh, kw = w.shape
+        Ho, Wo = H // 2, W // 2
+        xr = _rows(x.detach())
+        cv = _pack(w, b, "fwd")
+        out = torch.empty(B * Ho * Wo, cout, device=x.device)
+        lib.conv2d([cv.desc(xr, 0, C, out, 0, EPI_LINEAR, stride=2)], B, Ho, Wo, xr)
+        ctx.save_for_backward(xr, w)
+        ctx.shape = (B, C, H, W, cout, kh, kw)
+        STATS["hip"] += 1
+        return _nchw(out, B, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xr, w = ctx.saved_tensors
+        B, C, H, W, cout, kh, kw = ctx.shape
+        dyu = torch.zeros(B, H, W, cout, device=gy.device)
+        dyu[:, ::2, ::2] = gy.permute(0, 2, 3, 1)                 # zero-stuffing (a strided copy)
+        dyu = dyu.view(B * H * W, cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dg = _pack(w, None, "dgrad")
+            dxr = torch.empty(B * H * W, C, device=gy.device)
+            lib.conv2d([dg.desc(dyu, 0, cout, dxr, 0, EPI_LINEAR)], B, H, W, dyu)
+            dx = _nchw(dxr, B, H, W)
+        op = (cout + 127) // 128 * 128
+        dw = torch.zeros(op, kh * kw, (C + 31) // 32 * 32, device=gy.device)
+        db = torch.zeros(op, device=gy.device)
+        lib.conv2d_wgrad(xr, 0, C, dyu, 0, cout, dw, db, kh, kw, B, H, W)
+        STATS["hip"] += 2
+        # every zero of dYu adds 0 to db, so the column sums over the stuffed map are the bias gradient
+        return dx, Conv.unpack_wgrad(dw, cout, C, kh, kw), db[:cout].clone()
+
+
+class HipSmallConv(torch.autograd.Function):
+    """The 7x7 stems (3 -> 64 stride 2 of the encoders, core/extractor.py:122; 2 -> 128 stride 1 of the motion encoders,
+    core/update.py:87,173,175) on the exact-fp32 small-Cin kernel; their inputs -- the images, the detached flows --
+    need no gradient, so the backward is the weight / bias gradient alone (pf_conv2d_wgrad_small)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride):
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        cout, _, kh, kw = w.shape
+        Ho, Wo = H // stride, W // stride
+        xin = x.detach().contiguous()                              # NCHW planes
+        wp = w.detach().permute(2, 3, 1, 0).reshape(kh * kw * C, cout).contiguous()      # [KH*KW][Cin][Cout]
+        out = torch.empty(B * Ho * Wo, cout, device=x.device)
+        lib.conv2d_small(xin, True, 0, C, wp, b.detach().contiguous(), out, 0, cout, kh, kw, stride, False, B, Ho, Wo)
+        ctx.save_for_backward(xin)
+        ctx.shape = (B, C, Ho, Wo, cout, kh, kw, stride)
+        STATS["hip"] += 1
+        return _nchw(out, B, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.needs_input_grad[0]:
+            raise _lib.PfError("the small-Cin stem convolutions have no data gradient (their inputs are detached in the reference)")
+        lib = _lib.load()
+        (xin,) = ctx.saved_tensors
+        B, C, Ho, Wo, cout, kh, kw, stride = ctx.shape
+        dw = torch.zeros(cout, C, kh, kw, device=gy.device)
+        db = torch.zeros(cout, device=gy.device)
+        lib.conv2d_wgrad_small(xin, True, 0, C, _rows(gy), 0, cout, dw, db, kh, kw, stride, B, Ho, Wo)
+        STATS["hip"] += 1
+        return None, dw, db, None
+
+
+class HipFrozenBatchNorm(torch.autograd.Function):
+    """nn.BatchNorm2d with frozen statistics (freeze_bn, train_flow.py:107-108): y = x * s + t with
+    s = gamma * rstd, t = beta - mean * s.  Backward: dx = s * g (pf_norm_bwd, fixed statistics); d gamma = sum g * xhat,
+    d beta = sum g from the same kernel's per-(image, channel) sums (its InstanceNorm branch run on xhat = x * rstd -
+    mean * rstd; the dx of that pass is discarded)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps):
+        rstd = torch.rsqrt(var + eps)
+        s = (gamma.detach() * rstd)
+        t = (beta.detach() - mean * s)
+        ctx.save_for_backward(_rows(x.detach()), s, rstd, mean)
+        ctx.shape = x.shape
+        return x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        xr, s, rstd, mean = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        gr = _rows(g)
+        Np = H * W
+        dx = torch.empty_like(xr)
+        rep = lambda v: v.view(1, Cc).expand(B, Cc).contiguous()
+        lib.norm_bwd(gr, xr, rep(s), rep(torch.zeros_like(s)), False, False, dx, B, Np, Cc)
+        coef = lib.norm_bwd_sums(gr, xr, rep(rstd), rep(-mean * rstd), B, Np, Cc)          # [B, C, 2]: mean g, mean g * xhat
+        STATS["hip"] += 2
+        dbeta = coef[:, :, 0].sum(0) * Np
+        dgamma = coef[:, :, 1].sum(0) * Np
+        return _nchw(dx, B, H, W), dgamma, dbeta, None, None, None
+
+
 _TAPE = threading.local()       # .gates: id(conv module) -> (token, WeightGrad) of the forward being recorded
 
 
@@ -201,6 +316,13 @@ def conv2d(x: torch.Tensor, m: nn.Conv2d) -> torch.Tensor:
             acc = WeightGrad()
             g = gates[id(m)] = (WeightGate.apply(acc, m.weight, m.bias), acc)
         return HipConv.apply(x, m.weight, m.bias, None, g[0], g[1])
+    plain = m.bias is not None and m.dilation == (1, 1) and m.groups == 1 and m.padding == (kh // 2, kw // 2)
+    if plain and m.stride == (2, 2) and (kh, kw) in ((3, 3), (1, 1)) and x.shape[1] % 4 == 0 \
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and m.weight.shape[0] % 4 == 0:
+        return HipConvS2.apply(x, m.weight, m.bias)
+    if plain and kh == kw and kh * kw <= 52 and x.shape[1] <= 4 and m.stride in ((1, 1), (2, 2)) \
+            and m.weight.shape[0] % 4 == 0 and not x.requires_grad:
+        return HipSmallConv.apply(x, m.weight, m.bias, m.stride[0])
     STATS["torch"] += 1
     return F.conv2d(x, m.weight, m.bias, stride=m.stride, padding=m.padding)
 
@@ -256,10 +378,24 @@ class HipCorrPyramid(torch.autograd.Function):
             return torch.zeros(B, C, H, W, device=r1.device), torch.zeros(B, C, H, W, device=r1.device), None
         dv = lib.pyramid_bwd(gl, B, H, W).view(B, n, n)       # level 0 becomes the dense volume gradient, in place
         s = 1.0 / math.sqrt(C)
-        d1 = torch.bmm(dv, r2.view(B, n, C)) * s
-        d2 = torch.bmm(dv.transpose(1, 2), r1.view(B, n, C)) * s
-        STATS["hip"] += 1
-        return _nchw(d1.reshape(B * n, C), B, H, W), _nchw(d2.reshape(B * n, C), B, H, W), None
+        # d f1 = dV f2 / sqrt(C), d f2 = dV^T f1 / sqrt(C): two GEMMs per image on the MFMA 1x1 convolution -- rows = the n
+        # pixels of a feature map, "input channels" = the n pixels of the other one, weights = the other feature map^T
+        d1, d2 = torch.empty(B * n, C, device=r1.device), torch.empty(B * n, C, device=r1.device)
+        zero_b = torch.zeros(C, device=r1.device)
+        n4 = (n + 3) // 4 * 4                                 # the kernel reads 16 bytes at a time: K padded with zero columns
+        for b in range(B):
+            dvb = dv[b]
+            dvt = dvb.t()
+            for src, feat, dst in ((dvb, r2, d1), (dvt, r1, d2)):
+                src = F.pad(src, (0, n4 - n)) if n4 != n else src.contiguous()
+                wmat = feat[b * n:(b + 1) * n].t()                                   # [Cout = C][Cin = n]
+                if n4 != n:
+                    wmat = F.pad(wmat, (0, n4 - n))
+                wp, bp = pack_mfma(wmat.reshape(C, n4, 1, 1), zero_b)
+                cv = Conv(wp, bp, 1, 1, n4, C, PREC_BF16X3)
+                lib.conv2d([cv.desc(src, 0, n4, dst[b * n:(b + 1) * n], 0, EPI_LINEAR, scale=s)], 1, H, W, src)
+        STATS["hip"] += 1 + 2 * B
+        return _nchw(d1, B, H, W), _nchw(d2, B, H, W), None
 
 
 class HipDccl(torch.autograd.Function):
@@ -434,7 +570,10 @@ class HipInstanceNorm(torch.autograd.Function):
 def _norm(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
     if isinstance(m, nn.InstanceNorm2d):
         return HipInstanceNorm.apply(x)
-    if isinstance(m, nn.BatchNorm2d):        # running statistics are updated unless frozen (freeze_bn -> eval)
+    if isinstance(m, nn.BatchNorm2d):
+        if not m.training and m.weight is not None:          # frozen statistics (freeze_bn): the reference's configuration
+            return HipFrozenBatchNorm.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+        STATS["torch"] += 1                                   # batch statistics: the one operator left on PyTorch-ROCm
         return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, m.training, m.momentum, m.eps)
     raise _lib.PfError(f"unsupported norm layer {type(m).__name__}")
 

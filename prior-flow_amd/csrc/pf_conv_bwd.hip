@@ -252,7 +252,116 @@ __global__ void __launch_bounds__(256) pf_col_sum_kernel(const float* __restrict
         atomicAdd(db + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
+// ----------------------------------------------------------------------------------------------
+// Weight gradient of the SMALL-Cin convolutions (the 7x7 stems: core/extractor.py:122 3->64 stride 2,
+// core/update.py:87,173,175 2->128 stride 1; their inputs -- images, detached flows -- need no data gradient):
+//   dW[o][c][ky][kx] += sum_p dY[p][o] * X[stride*p + (ky, kx) - pad][c],   db[o] += sum_p dY[p][o]
+// K = KH*KW*Cin <= 196 is far too small for the pixel-reduction MFMA kernel above, and the products are exact-fp32
+// work anyway (the forward of these layers runs on the exact-fp32 small-Cin kernel).  A workgroup walks over 8 x 8
+// output-pixel tiles: the dY tile (64 px x 64 channels) and the input patch live in LDS; thread (o = tid % 64,
+// tg = tid / 64) owns output channel o and every fourth tap, all input channels, in registers across ALL its tiles
+// (<= 13 taps x 4 channels), and adds them to dW once at the end (fp32 atomics; dW, db are ACCUMULATED: zero first).
+// ----------------------------------------------------------------------------------------------
+struct WgradSmallArgs {
+    const float* x; int nchw, ld_in, off_in, cin;
+    const float* dy; int ld_dy, off_dy, cout;
+    float* dw; float* db;
+    int B, Ho, Wo, kh, kw, stride;
+};
+constexpr int WS_T = 8, WS_MAXTAPS = 13, WS_MAXC = 4;
+
+__global__ void __launch_bounds__(256) pf_wgrad_small_kernel(const WgradSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ws_lds[];
+    const int PW = (WS_T - 1) * a.stride + a.kw, PH = (WS_T - 1) * a.stride + a.kh;
+    float* const dyt = ws_lds;                          // [64 px][64 o]
+    float* const patch = ws_lds + 64 * 64;              // [PH][PW][cin]
+    const int tid = threadIdx.x, o = tid & 63, tg = tid >> 6;
+    const int o0 = blockIdx.y * 64;
+    const int taps = a.kh * a.kw, pad_h = a.kh / 2, pad_w = a.kw / 2;
+    const int Hi = a.Ho * a.stride, Wi = a.Wo * a.stride;
+    const int tiles_x = (a.Wo + WS_T - 1) / WS_T, tiles_y = (a.Ho + WS_T - 1) / WS_T;
+    const long ntiles = (long)a.B * tiles_x * tiles_y;
+    int toff[WS_MAXTAPS];                               // patch offset of this thread's j-th tap (or -1)
+#pragma unroll
+    for (int j = 0; j < WS_MAXTAPS; ++j) {
+        const int tap = tg + 4 * j;
+        toff[j] = tap < taps ? ((tap / a.kw) * PW + tap % a.kw) * a.cin : -1;
+    }
+    float acc[WS_MAXTAPS][WS_MAXC];
+#pragma unroll
+    for (int j = 0; j < WS_MAXTAPS; ++j)
+#pragma unroll
+        for (int c = 0; c < WS_MAXC; ++c) acc[j][c] = 0.f;
+    float bsum = 0.f;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = (int)(tile / (tiles_x * tiles_y)), tin = (int)(tile % (tiles_x * tiles_y));
+        const int y0 = (tin / tiles_x) * WS_T, x0 = (tin % tiles_x) * WS_T;
+        __syncthreads();                                // the previous tile's reads are done
+        for (int e = tid; e < 64 * 16; e += 256) {      // dY tile: 64 px x 16 float4
+            const int px = e >> 4, c4 = (e & 15) * 4;
+            const int yy = y0 + (px >> 3), xx = x0 + (px & 7);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (yy < a.Ho && xx < a.Wo && o0 + c4 < a.cout)
+                v = *reinterpret_cast<const f32x4*>(a.dy + ((long)img * a.Ho * a.Wo + (long)yy * a.Wo + xx) * a.ld_dy + a.off_dy + o0 + c4);
+            *reinterpret_cast<f32x4*>(dyt + px * 64 + c4) = v;
+        }
+        for (int e = tid; e < PH * PW * a.cin; e += 256) {
+            const int c = e % a.cin, pp = e / a.cin;
+            const int yy = y0 * a.stride + pp / PW - pad_h, xx = x0 * a.stride + pp % PW - pad_w;
+            float v = 0.f;
+            if (yy >= 0 && yy < Hi && xx >= 0 && xx < Wi)
+                v = a.nchw ? a.x[(((long)img * a.cin + c) * Hi + yy) * Wi + xx]
+                           : a.x[((long)img * Hi * Wi + (long)yy * Wi + xx) * a.ld_in + a.off_in + c];
+            patch[e] = v;
+        }
+        __syncthreads();
+        for (int px = 0; px < 64; ++px) {
+            const float g = dyt[px * 64 + o];
+            if (tg == 0) bsum += g;
+            const float* pb = patch + (((px >> 3) * PW + (px & 7)) * a.stride) * a.cin;
+#pragma unroll
+            for (int j = 0; j < WS_MAXTAPS; ++j) {
+                if (toff[j] < 0) break;                 // wave-uniform (tg is per wave)
+#pragma unroll
+                for (int c = 0; c < WS_MAXC; ++c)
+                    if (c < a.cin) acc[j][c] = __builtin_fmaf(g, pb[toff[j] + c], acc[j][c]);
+            }
+        }
+    }
+    if (o0 + o < a.cout) {
+#pragma unroll
+        for (int j = 0; j < WS_MAXTAPS; ++j) {
+            const int tap = tg + 4 * j;
+            if (tap < taps)
+#pragma unroll
+                for (int c = 0; c < WS_MAXC; ++c)
+                    if (c < a.cin) atomicAdd(a.dw + ((long)(o0 + o) * a.cin + c) * taps + tap, acc[j][c]);
+        }
+        if (tg == 0 && a.db) atomicAdd(a.db + o0 + o, bsum);
+    }
+}
+
 }  // namespace
+
+extern "C" int pf_conv2d_wgrad_small(const float* x, int nchw, int ld_in, int off_in, int cin,
+                                     const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
+                                     int kh, int kw, int stride, int B, int Hout, int Wout, void* stream) {
+    if (!x || !dy || !dw) return PF_ERR_BAD_ARG;
+    if (B <= 0 || Hout <= 0 || Wout <= 0 || cin <= 0 || cin > WS_MAXC || cout <= 0) return PF_ERR_BAD_SHAPE;
+    if (kh < 1 || kw < 1 || kh * kw > 4 * WS_MAXTAPS || (stride != 1 && stride != 2)) return PF_ERR_BAD_SHAPE;
+    if ((ld_dy | off_dy | cout) & 3) return PF_ERR_BAD_SHAPE;                       // 16-byte dY loads
+    if (off_dy < 0 || off_dy + cout > ld_dy || (!nchw && (off_in < 0 || off_in + cin > ld_in))) return PF_ERR_BAD_ARG;
+    WgradSmallArgs a;
+    a.x = x; a.nchw = nchw; a.ld_in = ld_in; a.off_in = off_in; a.cin = cin;
+    a.dy = dy; a.ld_dy = ld_dy; a.off_dy = off_dy; a.cout = cout; a.dw = dw; a.db = db;
+    a.B = B; a.Ho = Hout; a.Wo = Wout; a.kh = kh; a.kw = kw; a.stride = stride;
+    const int PW = (WS_T - 1) * stride + kw, PH = (WS_T - 1) * stride + kh;
+    const size_t lds = (size_t)(64 * 64 + PH * PW * cin) * sizeof(float);
+    const long ntiles = (long)B * ((Hout + WS_T - 1) / WS_T) * ((Wout + WS_T - 1) / WS_T);
+    dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024), (unsigned)((cout + 63) / 64));
+    hipLaunchKernelGGL(pf_wgrad_small_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
 
 extern "C" int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const float* x1, int ld1, int off1, int c1,
                                const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,

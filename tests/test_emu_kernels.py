@@ -30,7 +30,7 @@ def emu():
                                "-I", CSRC, srcs[0], "-o", EMU_SO])
     from prior_flow_amd._lib import PfLib
     return PfLib(EMU_SO, require_cuda=False, optional=("pf_conv2d", "pf_conv2d_tile", "pf_corr_pyramid", "pf_corr_pyramid_bf16x3", "pf_conv2d_wgrad",
-                                                            "pf_dccl_combine_conv1x1"))
+                                                            "pf_dccl_combine_conv1x1", "pf_conv2d_wgrad_small"))
 
 
 @pytest.fixture(scope="module")
