@@ -45,7 +45,8 @@ constexpr int MAX_GROUPS = 4;
 
 struct ConvGroups { pf_conv_desc d[MAX_GROUPS]; };
 
-struct ConvGeom { int M, H, W, N; int taps, nchunks, cin_pad, kh, kw; int stride, Hin, Win, Nin; };
+struct ConvGeom { int M, H, W, N; int taps, nchunks, cin_pad, kh, kw; int stride, Hin, Win, Nin;
+                  int ntn, ntiles, xcd_map; };   // halo kernel: output-channel tiles, pixel tiles (all images), XCD-aware 1-D grid
 
 // Fused epilogue of a wave's NT 32x32 accumulators.  acc[t][r] is output channel jb + 32 t + li
 // of pixel p0 + (r&3) + 8 (r>>2)  (p0 already holds the lane's +4*(lane>>5) row offset).
@@ -391,11 +392,29 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     float* Ah = smem;                                   // [2][HALO_ROWS][LDS_LD]
     float* Bs = smem + 2 * HALO_ROWS * LDS_LD;          // [B_SLOTS][BN][B_ROW bytes]  (ring)
 
+    // XCD-aware work mapping (1-D grid).  Workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2; every
+    // XCD gets a CONTIGUOUS range of the work sequence  q = (group, pixel tile in raster order, output-channel tile) with
+    // the channel tile fastest: the workgroups that read the same input halo (the channel tiles of one pixel tile) and
+    // overlapping halos (vertically / horizontally adjacent pixel tiles) then run on the same XCD at the same time and
+    // find each other's lines in its L2.  With the plain 3-D grid they were spread over all XCDs and every halo came
+    // from beyond L2: the PMC pass read 89 MB of fabric-side fetches per 5x1 GRU launch for 25 MB of input.
+    int grp_i, ntile_i, tile_i;
+    if (g.xcd_map) {
+        const unsigned nwg = gridDim.x, orig = blockIdx.x;
+        const unsigned xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;     // bijective for any nwg
+        const unsigned q = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+        ntile_i = (int)(q % (unsigned)g.ntn);
+        const unsigned r = q / (unsigned)g.ntn;
+        tile_i = (int)(r % (unsigned)g.ntiles);
+        grp_i = (int)(r / (unsigned)g.ntiles);
+    } else {
+        tile_i = blockIdx.x; ntile_i = blockIdx.y; grp_i = blockIdx.z;
+    }
     pf_conv_desc d = groups.d[0];
-    if (blockIdx.z == 1) d = groups.d[1];
-    else if (blockIdx.z == 2) d = groups.d[2];
-    else if (blockIdx.z == 3) d = groups.d[3];
-    const int n0 = blockIdx.y * BN;
+    if (grp_i == 1) d = groups.d[1];
+    else if (grp_i == 2) d = groups.d[2];
+    else if (grp_i == 3) d = groups.d[3];
+    const int n0 = ntile_i * BN;
     if (n0 >= d.cout) return;
 
     const int tid = threadIdx.x;
@@ -403,7 +422,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     const int li = lane & 31, lh = lane >> 5;
     const int wy = (TH == 4) ? wave >> 1 : wave, wn = (TH == 4) ? wave & 1 : 0;
     const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;   // edge tiles may be partial
-    const int tile = blockIdx.x;
+    const int tile = tile_i;
     const int x0 = (tile % tiles_x) * TW;
     const int y0 = ((tile / tiles_x) % tiles_y) * TH;
     const long pix0 = (long)(tile / (tiles_x * tiles_y)) * g.N;      // batch offset in pixels
@@ -510,6 +529,8 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     f32x4 rb0[B_V4], rb1[B_V4];
     unsigned b_goff[B_V4];        // global: ((n0 + row) * wrow + c4) * 4 bytes
     unsigned b_loff[B_V4];        // LDS:    (row * LDS_LD + c4) * 4 bytes
+    // (Rotating the row order per workgroup, so that the CUs of an XCD do not ask its L2 for the same weight line at the
+    // same moment, was measured: no effect.)
 #pragma unroll
     for (int q = 0; q < B_V4; ++q) {
         const int r = (tid + 512 * q) >> 3;
@@ -824,14 +845,19 @@ int launch_conv_halo_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, in
                            (DMA_B ? (size_t)4 * BN * 128 : (size_t)3 * BN * LDS_LD * sizeof(float));
     static_assert(lds <= 160 * 1024, "LDS budget");
     const int B = g.M / g.N;
-    dim3 grid((unsigned)(B * ((g.H + TH - 1) / TH) * ((g.W + 31) / 32)), (unsigned)((max_cout + BN - 1) / BN),
-              (unsigned)ngroups);
+    ConvGeom gg = g;
+    gg.ntiles = B * ((g.H + TH - 1) / TH) * ((g.W + 31) / 32);
+    gg.ntn = (max_cout + BN - 1) / BN;
+    static const bool xcd_map = [] { const char* e = getenv("PRIORFLOW_CONV_XCD"); return !(e && e[0] == '0'); }();   // A/B knob
+    gg.xcd_map = xcd_map ? 1 : 0;
+    dim3 grid((unsigned)gg.ntiles, (unsigned)gg.ntn, (unsigned)ngroups);
+    if (xcd_map) grid = dim3((unsigned)((long)gg.ntiles * gg.ntn * ngroups));
     // up to ~130 KB of dynamic LDS: above the 64 KB default limit
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL((pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>), grid, dim3(512), lds, stream, grp, g);
+    hipLaunchKernelGGL((pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>), grid, dim3(512), lds, stream, grp, gg);
     return (int)hipGetLastError();
 }
 
