@@ -357,6 +357,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+#ifdef PF_STAMPS      // diagnostic build only (profiles/stamp_conv.py): per-wave s_memtime stamps inside the K-step
+#define PF_STAMP_OFF (140 * 1024 / 4)      // floats: the stamp area sits above the operand buffers of the TH = 4 instantiations
+__device__ unsigned long long pf_stamp_buf[8 * 40 * 8];
+#endif
+
 template <int NT, int KH, int KW, bool AFFINE, int TH>
 __global__ void __launch_bounds__(512, 2)      // 8 waves = 2 per SIMD, 256-register budget
 pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
@@ -614,6 +619,25 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         fb[set][t][3] = *reinterpret_cast<const bf16x8*>(bp + b_piece[3]);
     };
 
+    // One 16-byte fragment read (piece P of the 4 A pieces + 4*NT B pieces of a step).  The K loop issues them ONE OR TWO
+    // PER MFMA GAP: with whole fragments fetched in the first gaps (4 reads per gap, all 8 waves right after the barrier)
+    // the LDS queue filled up, the reads blocked the in-order instruction stream and the MFMAs behind them: s_memtime
+    // stamps (profiles/stamp_conv.py) showed ~900 cycles of issue phase for a wave's 12 MFMAs (384 cycles of matrix pipe).
+    constexpr int NP = 4 + 4 * NT;
+    constexpr int FETCH_GAPS = 6 * NT - (NT == 1 ? 1 : 2);      // the last gap(s) stay free: a read's latency is hidden, not exposed at the barrier
+    auto fetch_piece = [&](auto SET, auto P, int halo_buf, int ky, int kx, int slot) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value, p = decltype(P)::value;
+        if constexpr (p < 4) {
+            const char* ap = a_lane + (halo_buf * HALO_ROWS + ky * HW + kx) * (LDS_LD * 4);
+            constexpr int off = (p & 1) * 16 + (p >> 1) * 64;
+            fa[set][p] = *reinterpret_cast<const bf16x8*>(ap + off);
+        } else {
+            constexpr int t = (p - 4) / 4, k = (p - 4) % 4;
+            const char* bp = b_lane + (slot * BN + 32 * t) * B_ROW;
+            fb[set][t][k] = *reinterpret_cast<const bf16x8*>(bp + b_piece[k]);
+        }
+    };
+
     // ---- prologue: halo 0, weight steps 0 and 1 synchronously; steps 2, 3 in flight; frags(0) ------
     // (TAPS == 1: halo chunks 0 and 1 synchronously, chunks 2 and 3 in flight, like the weights)
     // (DMA path: weight steps 0, 1, 2 by DMA, all retired here; steps 3, 4, ... issued from the K loop)
@@ -657,6 +681,9 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     //   M | fetch A(s+1) | M | fetch B(s+1) ... | M | B(s+2) regs -> slot (s+2)%3, issue B(s+4) |
     //   M | halo slice 0 | M | halo slice 1 | ...      (halo(c+1): loads at tap 0, split+store at tap TAPS-2)
     int slot3 = 0;            // s % 3
+#ifdef PF_STAMPS
+    unsigned long long tM[4] = {0, 0, 0, 0};
+#endif
 #ifdef PF_NO_PIN
 #define PF_PIN() do {} while (0)
 #else
@@ -674,6 +701,10 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
         const int s2 = s1 == B_SLOTS - 1 ? 0 : s1 + 1;         // (s+2) % B_SLOTS
         const int s3 = s2 == B_SLOTS - 1 ? 0 : s2 + 1;         // (s+3) % B_SLOTS   (DMA path)
         using NXT = std::integral_constant<int, cur ^ 1>;
+#ifdef PF_STAMPS
+        unsigned long long tA, tB;
+        asm volatile("s_memtime %0" : "=s"(tA) :: "memory");          // everything of step s-1 issued; its LDS ops may be in flight
+#endif
 #ifndef PF_ABLATE_NO_BARRIER
         if constexpr (DMA_B) {
             // the weight DMA of step s+1 was issued at step s-2; VMEM operations issued after it, in order:
@@ -684,6 +715,15 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "n"(YOUNGER) : "memory");
         } else {
             __syncthreads();  // slot (s+1)%3 and the halo of step s+1 are complete; slot (s+2)%3 is idle
+        }
+#endif
+#ifdef PF_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB), "+s"(tA) :: "memory");
+        if (TH == 4 && blockIdx.x == 0 && lane == 0 && s < 40) {
+            unsigned long long* st = reinterpret_cast<unsigned long long*>(smem + PF_STAMP_OFF);
+            st[(wave * 40 + s) * 8 + 0] = tA;
+            st[(wave * 40 + s) * 8 + 1] = tB;
+            if (s > 0) for (int k = 0; k < 4; ++k) st[(wave * 40 + s - 1) * 8 + 2 + k] = tM[k];      // mid-step stamps of step s-1
         }
 #endif
         constexpr int NM = 6 * NT;                     // MFMAs of the step; accumulators alternate
@@ -738,8 +778,10 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
 #endif
             PF_PIN();
 #ifndef PF_ABLATE_NO_FETCH
-            if constexpr (i == 0) fetch_A(NXT{}, nchunk & 1, nky, nkx);
-            if constexpr (i >= 1 && i <= NT) fetch_B(NXT{}, std::integral_constant<int, i - 1>{}, s1);
+            // the 4 + 4*NT fragment reads of step s+1, spread over the first gaps (see fetch_piece)
+            static_for<0, NP>([&](auto P) __attribute__((always_inline)) {
+                if constexpr (decltype(P)::value * FETCH_GAPS / NP == i) fetch_piece(NXT{}, P, nchunk & 1, nky, nkx, s1);
+            });
 #endif
             if constexpr (i == NT + 1 && DMA_B) {
                 dma_B(s + 3, s3);
@@ -759,6 +801,10 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
                 if constexpr (tap == 0 && TAPS > 1) load_A_affine(chunk + 1);
 #endif
             }
+#ifdef PF_STAMPS
+            if constexpr (NT == 2 && (i == 2 || i == 3 || i == 6 || i == 9))
+                asm volatile("s_memtime %0" : "=s"(tM[i == 2 ? 0 : i == 3 ? 1 : i == 6 ? 2 : 3]) :: "memory");
+#endif
             if constexpr (NT == 1) {                    // 6 MFMAs: half of the halo slices in each of two gaps
                 if constexpr (i == 3) static_for<0, A_V4 / 2>([&](auto Q) { halo_slice(Q); });
                 if constexpr (i == 4) static_for<A_V4 / 2, A_V4>([&](auto Q) { halo_slice(Q); });
@@ -779,6 +825,13 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     if ((nchunks & 1) && c2 < (1 << 20))
         static_for<0, TAPS>([&](auto U) { step(U, nchunks - 1); });
 
+#ifdef PF_STAMPS
+    __syncthreads();
+    if (TH == 4 && blockIdx.x == 0) {
+        const unsigned long long* st = reinterpret_cast<const unsigned long long*>(smem + PF_STAMP_OFF);
+        for (int i = tid; i < 8 * 40 * 8; i += 512) pf_stamp_buf[i] = st[i];
+    }
+#endif
     // ---- epilogue -----------------------------------------------------------------------------
 #ifndef PF_ABLATE_NO_EPILOGUE
     // ragged maps (W % 32 or H % TH != 0): the loader already zero-fills what lies outside the image;
@@ -857,7 +910,12 @@ int launch_conv_halo_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, in
         reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return (int)attr;
+#ifdef PF_STAMPS
+    static_assert(TH == 8 || lds <= 140 * 1024, "stamp area");
+    hipLaunchKernelGGL((pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>), grid, dim3(512), 160 * 1024, stream, grp, gg);
+#else
     hipLaunchKernelGGL((pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>), grid, dim3(512), lds, stream, grp, gg);
+#endif
     return (int)hipGetLastError();
 }
 
@@ -960,6 +1018,8 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision
         const long B = g.M / g.N;
         const long tiles4 = B * ((g.H + 3) / 4) * ((g.W + 31) / 32), tiles8 = B * ((g.H + 7) / 8) * ((g.W + 31) / 32);
         const long wgs128 = tiles4 * ngroups * ((max_cout + 127) / 128);
+        static const int force8 = [] { const char* e = getenv("PRIORFLOW_CONV_TH8"); return e ? atoi(e) : 0; }();   // A/B knob
+        if (force8 && g.kh == g.kw && g.kh > 1) return 5;
         if (max_cout <= 64 && g.kh == g.kw && g.kh > 1 && tiles8 * ngroups >= 512) return 5;
         return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
     }
@@ -968,6 +1028,12 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision
     if (max_cout <= 64 || m_tiles64 * ((max_cout + 127) / 128) < 512) return 1;
     return 2;
 }
+
+#ifdef PF_STAMPS
+extern "C" int pf_conv_read_stamps(unsigned long long* out) {   // [8 waves][40 steps][before barrier, after barrier, 4 mid-step stamps, 2 unused]
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_stamp_buf), sizeof(unsigned long long) * 8 * 40 * 8);
+}
+#endif
 
 extern "C" int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
     ConvGroups grp; ConvGeom g; int max_cout;

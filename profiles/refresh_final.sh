@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerates the committed round-2 measurement artefacts on the GPU box (run through gpurun from the repo root):
 #   gpurun_out/final/{pytest_gpu.log,bench_n1.json,kernel_stats.csv,forward_breakdown.txt,iteration_timeline.txt,
-#                     pmc_traffic.json,mfma_busy.json,bench_batch32.json,time_sizes.txt,train_step_time.json,bench_gloo2.json,train_2rank_check.txt}
+#                     pmc_traffic.json,mfma_busy.json,bench_batch32.json,time_sizes.txt,train_step_time.json,bench_gloo2.json,train_2rank_check.txt,
+#                     conv_microbench.txt,conv_stamps_zr.txt}
 export TMPDIR=/tmp
 O=gpurun_out/final
 mkdir -p $O
@@ -26,4 +27,8 @@ python profiles/time_sizes.py 512x1024:12 640x1280:32 480x960:12 256x512:4 > $O/
 python profiles/time_train_step.py 2>/dev/null | tail -1 > $O/train_step_time.json
 PRIORFLOW_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_gloo2.json
 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tests/run_train_2rank.py 2>&1 | grep -E "rank|checksums" > $O/train_2rank_check.txt
+for w in zr q fh1 c2 c1; do python profiles/microbench_conv.py 50 $w 2>/dev/null; done > $O/conv_microbench.txt
+MB_BATCH=8 python profiles/microbench_conv.py 20 zr >> $O/conv_microbench.txt 2>/dev/null
+# in-kernel stamps of the halo conv's K-step (diagnostic build: hipcc ... -DPF_STAMPS -o prior-flow_amd/lib/diag/STAMPS.so)
+[ -f prior-flow_amd/lib/diag/STAMPS.so ] && PRIORFLOW_LIB=$PWD/prior-flow_amd/lib/diag/STAMPS.so python profiles/stamp_conv.py zr 2>/dev/null | head -90 > $O/conv_stamps_zr.txt
 cat $O/pytest_gpu.log; cut -c1-300 $O/bench_n1.json; head -3 $O/forward_breakdown.txt | cut -c1-200; cat $O/time_sizes.txt; cut -c1-200 $O/bench_batch32.json
