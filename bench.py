@@ -126,7 +126,10 @@ def profile_kernels(model, i1, i2):
         flops = sum(2.0 * B * H8 * W8 * d.cout * d.kh * d.kw * (d.c0 + d.c1) for d in descs)
         tile = lib.conv2d_tile(descs, B, H8, W8)
         d0 = descs[0]
-        if tile >= 3:      # halo kernel: the instantiation is <NT, KH, KW, AFFINE, TH> exactly as rocprof names it
+        roles = lib.conv2d_roles(descs, B, H8, W8) if tile in (3, 4) else 0
+        if roles:          # role-specialised waves: <NT, KH, KW, WN> exactly as rocprof names it
+            tile = "pf_conv_ws_kernel<%d, %d, %d, %d>" % (2 if (tile == 4 or roles == 2) else 1, d0.kh, d0.kw, 3 - roles)
+        elif tile >= 3:    # halo kernel: the instantiation is <NT, KH, KW, AFFINE, TH> exactly as rocprof names it
             tile = "pf_conv_halo_kernel<%d, %d, %d, %s, %d>" % (
                 1 if tile == 3 else 2, d0.kh, d0.kw, "true" if d0.in_scale else "false", 8 if tile == 5 else 4)
         else:

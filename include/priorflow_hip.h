@@ -59,8 +59,10 @@ int pf_flo_rotate(const float* flow, const float* g_w2c, const float* g_c2w, flo
 /* PriOr_RAFT.corr + DCCL.build_pyramid (core/prior_raft.py:69-75, core/corr.py:99-111), fused:
  * level0[b][n1][n2] = <f1[b][n1][:], f2[b][n2][:]> / sqrt(C); level i+1 = 2x2 mean of level i
  * over (y2,x2).  f1,f2: channel-last [B*N][C] (C % 32 == 0).  lvl[i]: [B*N][(H8>>i)*(W8>>i)].
- * Requires H8 % 8 == 0 and W8 % 8 == 0 (the fused-pooling fast path needs W8 % 32 == 0;
- * other widths take a two-kernel path). */
+ * Any H8, W8 >= 16 (odd levels pool with floor semantics, like avg_pool2d).  Maps with W8 % 32 == 0 and H8 % 8 == 0
+ * take the fused kernel that writes all four levels in one pass (at B >= 4 and W8 % 64 == 0 its LDS-DMA ring
+ * form); other maps take a generic corr kernel + three pooling passes.  PF_ERR_BAD_SHAPE: C % 32 != 0 or a map
+ * whose row offsets do not fit 32 bits. */
 int pf_corr_pyramid(const float* f1, const float* f2, float* lvl0, float* lvl1, float* lvl2,
                     float* lvl3, int B, int H8, int W8, int C, void* stream);
 
@@ -188,6 +190,11 @@ int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, voi
  * (0: 128x32, 1: 64x64, 2: 64x128 pixels x channels), or a negative PF_ERR_* code.  Lets a
  * profiler attribute measured time to the right kernel instantiation; launches nothing. */
 int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8);
+
+/* Host-only introspection, companion of pf_conv2d_tile for tiles 3 / 4: which wave organisation the launch takes --
+ * 0: every wave stages and multiplies (pf_conv_halo_kernel), 1: four MFMA waves + four loader waves on the same tile
+ * (pf_conv_ws_kernel<NT, KH, KW, 2>), 2: the same with a 256 px x 64 channel tile (pf_conv_ws_kernel<2, KH, KW, 1>). */
+int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8);
 
 /* Tiny-Cin direct convolution (7x7 2->128, 3x3 8->32, 3x3 32->16; core/update.py:171-178,87).
  * Weights packed [KH*KW][Cin][Cout]. */

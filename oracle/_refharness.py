@@ -2,8 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY, and only usable in the build container: the GPU box has
 no /root/reference.  Used by ``oracle/gen_golden.py`` to emit the golden vectors
-under ``tests/golden/`` and by ``tests/test_oracle_vs_reference.py`` (skipped when
-the reference is absent).  Nothing from the reference is copied into this repo.
+under ``tests/golden/`` (and by the other ``oracle/gen_golden_*.py`` generators).  Nothing from the
+reference is copied into this repo; nothing under ``tests/`` imports this file.
 
 Shims (all inert on the hot path):
   * empty stub modules for ``timm`` / ``omegaconf`` (imported, never used),

@@ -10,8 +10,7 @@ Parity pinning: the reference has no tests / golden vectors of its own
 (SURVEY.md §4), so this oracle is pinned against outputs of the reference itself,
 imported in the build container by ``oracle/gen_golden.py`` and committed as
 fixtures under ``tests/golden/`` (``tests/test_oracle_golden.py`` checks every one
-of them; ``tests/test_oracle_vs_reference.py`` re-checks live when /root/reference
-exists).
+of them; the generators ``oracle/gen_golden*.py`` are the only code that imports the reference).
 
 Every function cites the reference lines (relative to /root/reference/PriOr-RAFT)
 it restates.  Tensors are torch CPU fp32, NCHW unless noted.

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "pf_conv2d": [C.POINTER(ConvDesc), _i, _i, _i, _i, _fp],
     "pf_dccl_combine_conv1x1": [C.POINTER(CombineConvDesc), _i, _i, _i, _i, _fp],
     "pf_conv2d_tile": [C.POINTER(ConvDesc), _i, _i, _i, _i],
+    "pf_conv2d_roles": [C.POINTER(ConvDesc), _i, _i, _i, _i],
     "pf_conv2d_direct": [_fp, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_conv2d_direct_group": [C.POINTER(DirectDesc), _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_conv2d_small": [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
@@ -293,6 +294,13 @@ class PfLib:
         rc = self._dll.pf_conv2d_tile(arr, len(descs), B, H8, W8)
         if rc < 0:
             self._rc(rc, "pf_conv2d_tile")
+        return rc
+
+    def conv2d_roles(self, descs: Sequence[ConvDesc], B, H8, W8) -> int:
+        arr = (ConvDesc * len(descs))(*descs)
+        rc = self._dll.pf_conv2d_roles(arr, len(descs), B, H8, W8)
+        if rc < 0:
+            self._rc(rc, "pf_conv2d_roles")
         return rc
 
     def conv2d_direct(self, x, off_in, cin, weight, bias, out, off_out, cout, kh, kw, relu, B, H8, W8):

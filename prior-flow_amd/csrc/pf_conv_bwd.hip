@@ -12,7 +12,7 @@
 // layout for both operands.  gfx950's ds_read_b64_tr_b16 does that transpose inside the LDS read: tiles are
 // staged row-major with plain coalesced 8-byte writes (bf16 hi | lo planes of 32 channels = 64-byte rows,
 // the 3-pass split of pf_conv_mfma.hip) and each lane reads rows 8h .. 8h+7 of its column with two
-// transposed reads (addressing validated on hardware by profiles/scratch/tr_read_check.hip).  64-byte rows
+// transposed reads (addressing validated on hardware in round 1 by a stand-alone lane/element dump).  64-byte rows
 // make every transposed read conflict-free: a 32-lane half covers 4 consecutive rows = 256 contiguous bytes.
 //
 // Work decomposition: workgroup (8 waves) = 128 output channels x 64 input channels x a share of the

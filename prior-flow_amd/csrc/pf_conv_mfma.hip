@@ -682,7 +682,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     //   M | halo slice 0 | M | halo slice 1 | ...      (halo(c+1): loads at tap 0, split+store at tap TAPS-2)
     int slot3 = 0;            // s % 3
 #ifdef PF_STAMPS
-    unsigned long long tM[4] = {0, 0, 0, 0};
+    unsigned long long tM[4] = {0, 0, 0, 0}, tR[2] = {0, 0};
 #endif
 #ifdef PF_NO_PIN
 #define PF_PIN() do {} while (0)
@@ -723,7 +723,11 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
             unsigned long long* st = reinterpret_cast<unsigned long long*>(smem + PF_STAMP_OFF);
             st[(wave * 40 + s) * 8 + 0] = tA;
             st[(wave * 40 + s) * 8 + 1] = tB;
-            if (s > 0) for (int k = 0; k < 4; ++k) st[(wave * 40 + s - 1) * 8 + 2 + k] = tM[k];      // mid-step stamps of step s-1
+            if (s > 0) {                                                                         // mid-step stamps of step s-1
+                for (int k = 0; k < 4; ++k) st[(wave * 40 + s - 1) * 8 + 2 + k] = tM[k];
+                st[(wave * 40 + s - 1) * 8 + 6] = tR[0];
+                st[(wave * 40 + s - 1) * 8 + 7] = tR[1];
+            }
         }
 #endif
         constexpr int NM = 6 * NT;                     // MFMAs of the step; accumulators alternate
@@ -794,7 +798,13 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
                 if constexpr (cur == 0) asm volatile("" :: "v"(rb0[0]), "v"(rb0[B_V4 - 1]));
                 else asm volatile("" :: "v"(rb1[0]), "v"(rb1[B_V4 - 1]));
 #elif !defined(PF_ABLATE_NO_LDS_WRITE)
+#ifdef PF_STAMPS
+                if constexpr (NT == 2) asm volatile("s_memtime %0" : "=s"(tR[0]) :: "memory");     // ring piece starts
+#endif
                 if constexpr (cur == 0) store_B(s2, rb0); else store_B(s2, rb1);
+#ifdef PF_STAMPS
+                if constexpr (NT == 2) asm volatile("s_memtime %0" : "=s"(tR[1]) :: "memory");     // ... stored; now addresses + loads
+#endif
 #endif
 #ifndef PF_ABLATE_NO_GLOBAL
                 if constexpr (cur == 0) load_B(s + 4, rb0); else load_B(s + 4, rb1);
@@ -919,6 +929,24 @@ int launch_conv_halo_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, in
     return (int)hipGetLastError();
 }
 
+template <int NT, int KH, int KW, int WN>
+int launch_conv_ws_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream);
+
+// Which form of the halo kernel a TH = 4 launch takes: 0 the symmetric pf_conv_halo_kernel, 1 pf_conv_ws_kernel with the
+// call's own 128-px tile (WN = 2), 2 pf_conv_ws_kernel with the 256 px x 64 channel tile (WN = 1; only where that still
+// gives every CU a workgroup).  PRIORFLOW_CONV_WS (A/B knob): 0 / 1 cap the choice, default 2.
+static int conv_ws_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout) {
+    static const int ws = [] { const char* e = getenv("PRIORFLOW_CONV_WS"); return e ? atoi(e) : 2; }();
+    if (ws <= 0) return 0;
+    const bool shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1);
+    if (!shape || g.stride != 1) return 0;
+    for (int i = 0; i < ngroups; ++i)
+        if (grp.d[i].stats_out != nullptr || grp.d[i].in_scale != nullptr) return 0;
+    const long wgs256 = (long)(g.M / g.N) * ((g.H + 7) / 8) * ((g.W + 31) / 32) * ngroups * ((max_cout + 63) / 64);
+    // (measured: the 256-px tile wins for the 3x3 convs, -2 % at B=1; for 1x5 / 5x1 its taller halo costs more than the weights save)
+    return (ws >= 2 && g.kh == 3 && max_cout > 64 && wgs256 >= 256) ? 2 : 1;
+}
+
 template <int NT, int TH>
 int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
     // every group of a launch must agree on having an input affine (one instantiation per launch)
@@ -928,6 +956,19 @@ int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int 
     if (affine) {                           // only the encoders' 3x3 convs use it
         if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, true, TH>(grp, ngroups, g, max_cout, stream);
         return PF_ERR_BAD_SHAPE;
+    }
+    if constexpr (TH == 4) {                // role-specialised waves (pf_conv_ws_kernel); PRIORFLOW_CONV_WS=0: symmetric kernel
+        const int ws = conv_ws_choice(grp, ngroups, g, max_cout);
+        if (ws == 2) {
+            if (g.kh == 3 && g.kw == 3) return launch_conv_ws_t<2, 3, 3, 1>(grp, ngroups, g, max_cout, stream);
+            if (g.kh == 1 && g.kw == 5) return launch_conv_ws_t<2, 1, 5, 1>(grp, ngroups, g, max_cout, stream);
+            if (g.kh == 5 && g.kw == 1) return launch_conv_ws_t<2, 5, 1, 1>(grp, ngroups, g, max_cout, stream);
+        }
+        if (ws == 1) {
+            if (g.kh == 3 && g.kw == 3) return launch_conv_ws_t<NT, 3, 3, 2>(grp, ngroups, g, max_cout, stream);
+            if (g.kh == 1 && g.kw == 5) return launch_conv_ws_t<NT, 1, 5, 2>(grp, ngroups, g, max_cout, stream);
+            if (g.kh == 5 && g.kw == 1) return launch_conv_ws_t<NT, 5, 1, 2>(grp, ngroups, g, max_cout, stream);
+        }
     }
     if (g.kh == 3 && g.kw == 3) return launch_conv_halo_t<NT, 3, 3, false, TH>(grp, ngroups, g, max_cout, stream);
     if (g.kh == 4 && g.kw == 4) return launch_conv_halo_t<NT, 4, 4, false, TH>(grp, ngroups, g, max_cout, stream);
@@ -949,6 +990,331 @@ int launch_conv(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_c
         hipLaunchKernelGGL((pf_conv_mfma_kernel<WM, WN, NT, true>), grid, dim3(256), lds, stream, grp, g);
     else
         hipLaunchKernelGGL((pf_conv_mfma_kernel<WM, WN, NT, false>), grid, dim3(256), lds, stream, grp, g);
+    return (int)hipGetLastError();
+}
+
+
+// =====================================================================================================================
+// Role-specialised form of the halo kernel for the update blocks' multi-tap convs (3x3, 1x5, 5x1; TH = 4, no input
+// affine, no fused statistics).  Same tile (128 px x 64*NT channels), same LDS images, same ring protocol and ONE
+// barrier per K-step as pf_conv_halo_kernel -- but the 8 waves no longer all do everything:
+//   waves 0..3  MFMA waves: 64 px x 32*NT channels each (two pixel rows, acc[2][NT]); their stream is the step's
+//               12*NT MFMAs with the 8 + 4*NT fragment reads of the next step in the gaps, nothing else;
+//   waves 4..7  loader waves (256 threads): every global load, the halo's hi|lo split, every LDS write.
+// Why: s_memtime stamps of the symmetric kernel (profiles/stamp_conv.py) showed that a wave's
+// staging instructions (weight registers -> LDS, global loads, halo split) block its own in-order stream for
+// 150-350 cycles per K-step and that its SIMD partner, running the same stream a little later, blocks on the same
+// shared ports -- the matrix pipe idles for the SUM of both.  Here the partner of every MFMA wave is a loader wave,
+// so staging runs beside the matrix pipe by construction (waves w and w + 4 share a SIMD).  The MFMA waves are the
+// older half: VALU / LDS issue arbitration favours them.
+// Per accumulator the MFMA order over (ks, pass) is the symmetric kernel's, so results are bit-identical.
+// WN = 2: tile 128 px (4 rows) x 64*NT channels, MFMA waves 2 (row pairs) x 2 (channel halves);
+// WN = 1: tile 256 px (8 rows) x 32*NT channels, MFMA waves 4 (row pairs) x 1 -- half the weight bytes per MFMA: the
+//         per-CU stream out of L2 (weights + halo, ~18 B/clk at best) is what bounds the K-step.
+template <int NT, int KH, int KW, int WN>
+__global__ void __launch_bounds__(512, 2)
+pf_conv_ws_kernel(const ConvGroups groups, const ConvGeom g) {
+    static_assert(WN == 1 || WN == 2, "");
+    constexpr int TH = 8 / WN, TW = 32, BN = 32 * NT * WN, TAPS = KH * KW;
+    static_assert(TAPS >= 3, "multi-tap convs only (the 1x1 cadence lives in pf_conv_halo_kernel)");
+    constexpr int HW = TW + KW - 1, HH = TH + KH - 1;
+    constexpr int LROWS = 32;                               // rows per loader pass: 256 loader threads, 8 x 16 B per row
+    constexpr int A_V4 = (HH * HW + LROWS - 1) / LROWS;     // halo float4 per loader thread and chunk
+    constexpr int HALO_ROWS = LROWS * A_V4;
+    static_assert(BN % LROWS == 0, "");
+    constexpr int B_V4 = BN / LROWS;                        // weight float4 per loader thread and K-step
+    constexpr int B_ROW = LDS_LD * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ah = smem;                                       // [2][HALO_ROWS][LDS_LD]
+    float* Bs = smem + 2 * HALO_ROWS * LDS_LD;              // [3][BN][LDS_LD]  (ring)
+
+    int grp_i, ntile_i, tile_i;                             // XCD-aware work mapping: see pf_conv_halo_kernel
+    {
+        const unsigned nwg = gridDim.x, orig = blockIdx.x;
+        const unsigned xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
+        const unsigned q = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+        ntile_i = (int)(q % (unsigned)g.ntn);
+        const unsigned r = q / (unsigned)g.ntn;
+        tile_i = (int)(r % (unsigned)g.ntiles);
+        grp_i = (int)(r / (unsigned)g.ntiles);
+    }
+    pf_conv_desc d = groups.d[0];
+    if (grp_i == 1) d = groups.d[1];
+    else if (grp_i == 2) d = groups.d[2];
+    else if (grp_i == 3) d = groups.d[3];
+    const int n0 = ntile_i * BN;
+    if (n0 >= d.cout) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+    const int x0 = (tile_i % tiles_x) * TW;
+    const int y0 = ((tile_i / tiles_x) % tiles_y) * TH;
+    const long pix0 = (long)(tile_i / (tiles_x * tiles_y)) * g.N;
+    constexpr int ph = KH / 2, pw = KW / 2;
+    const int nchunks = g.nchunks;
+    const long wrow = (long)TAPS * g.cin_pad;
+    char* const ah_bytes = reinterpret_cast<char*>(Ah);
+    char* const bs_bytes = reinterpret_cast<char*>(Bs);
+    int slot3 = 0;                                          // s % 3, carried by both roles alike
+
+    if (wave >= 4) {
+        // ================================ loader waves ================================
+        const int ltid = tid - 256;
+        const int c4 = (ltid & 7) * 4;
+        const int ctot = d.c0 + d.c1;
+        // per-slice source rows: byte offsets of the pixel row in either input segment, or "outside"
+        long a_off0[A_V4], a_off1[A_V4];
+        unsigned a_loff[A_V4], a_in = 0;
+#pragma unroll
+        for (int q = 0; q < A_V4; ++q) {
+            const int r = (ltid + 256 * q) >> 3;
+            const int yy = y0 + r / HW - ph, xx = x0 + r % HW - pw;
+            const bool in = r < HH * HW && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+            const long pix = in ? pix0 + (long)yy * g.W + xx : 0;
+            a_off0[q] = pix * d.ld0 * 4;
+            a_off1[q] = pix * d.ld1 * 4;
+            a_in |= in ? (1u << q) : 0u;
+            a_loff[q] = (unsigned)((r * LDS_LD) * 4 + 2 * c4);
+        }
+        unsigned b_goff[B_V4], b_loff[B_V4];
+#pragma unroll
+        for (int q = 0; q < B_V4; ++q) {
+            const int r = (ltid + 256 * q) >> 3;
+            b_goff[q] = (unsigned)(((long)(n0 + r) * wrow + c4) * 4);
+            b_loff[q] = (unsigned)((r * LDS_LD + c4) * 4);
+        }
+        const char* const wbytes = reinterpret_cast<const char*>(d.weight);
+        // Weights: FOUR register sets -- tile k lives in set k % 4, is loaded at step k-6 and stored into ring slot k % 3 at
+        // step k-2, so four K-steps of weights (64 KB per CU at BN = 128) are in flight: the stamps of the two-set form showed
+        // the ring store waiting ~400 cycles for data requested two steps (~2 300 cycles) earlier.
+        // Halo: the slices of a chunk form G groups; group k is loaded at tap k and split + stored at tap G + k, so no step
+        // carries more than 1/G of the halo work (all of it at tap 0 / tap TAPS-2 made those two steps 1.3x / 1.6x as long).
+        constexpr int G = (TAPS - 1) / 2;
+        static_assert(2 * G <= TAPS - 1, "the last group is stored before the chunk's last tap");
+        f32x4 ra[A_V4], rb[4][B_V4];
+        bool a_chunk_ok = false;                            // this thread's 4 channels of the chunk being loaded exist
+        const char* a_base = nullptr;
+        bool a_seg0 = true;
+        auto begin_A = [&](int chunk) __attribute__((always_inline)) {
+            if (chunk >= nchunks) chunk = nchunks - 1;      // tail: harmless re-read, stored to the idle buffer
+            const int c = chunk * KC + c4;
+            a_seg0 = c < d.c0;                              // a chunk lies in ONE segment (c0 % 32 == 0 when c1 > 0)
+            a_base = a_seg0 ? reinterpret_cast<const char*>(d.in0 + d.off0 + c)
+                            : reinterpret_cast<const char*>(d.in1 + d.off1 + (c - d.c0));
+            a_chunk_ok = c < ctot;
+            if (!a_chunk_ok) a_base = reinterpret_cast<const char*>(d.in0 + d.off0);
+        };
+        auto load_A = [&](auto K) __attribute__((always_inline)) {                  // group K of the chunk begun last
+            constexpr int k = decltype(K)::value;
+            static_for<k * A_V4 / G, (k + 1) * A_V4 / G>([&](auto Q) __attribute__((always_inline)) {
+                constexpr int q = decltype(Q)::value;
+                const long off = a_chunk_ok ? (a_seg0 ? a_off0[q] : a_off1[q]) : 0;
+                ra[q] = *reinterpret_cast<const f32x4*>(a_base + off);
+            });
+        };
+        auto store_A = [&](auto K, int buf) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            char* hb = ah_bytes + buf * (HALO_ROWS * LDS_LD * 4);
+            static_for<k * A_V4 / G, (k + 1) * A_V4 / G>([&](auto Q) __attribute__((always_inline)) {
+                constexpr int q = decltype(Q)::value;
+                const bool ok = a_chunk_ok && ((a_in >> q) & 1u);
+                const f32x4 v = ok ? ra[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const bf16x4 hi = __builtin_convertvector(v, bf16x4);          // hi = bf16(v) (RNE); lo = bf16(v - hi)
+                const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
+                const bf16x4 lo = __builtin_convertvector(rest, bf16x4);
+                *reinterpret_cast<bf16x4*>(hb + a_loff[q]) = hi;
+                *reinterpret_cast<bf16x4*>(hb + a_loff[q] + 64) = lo;
+            });
+        };
+        auto load_B = [&](int chunk, int tap, auto SET) __attribute__((always_inline)) {
+            constexpr int set = decltype(SET)::value;
+            if (chunk >= nchunks) chunk = nchunks - 1;      // tail: harmless re-read
+            const char* wp = wbytes + ((long)tap * g.cin_pad + chunk * KC) * 4;      // wave-uniform
+#pragma unroll
+            for (int q = 0; q < B_V4; ++q) rb[set][q] = *reinterpret_cast<const f32x4*>(wp + b_goff[q]);
+        };
+        auto store_B = [&](int slot, auto SET) __attribute__((always_inline)) {
+            constexpr int set = decltype(SET)::value;
+            char* bs = bs_bytes + slot * (BN * B_ROW);
+#pragma unroll
+            for (int q = 0; q < B_V4; ++q) *reinterpret_cast<f32x4*>(bs + b_loff[q]) = rb[set][q];
+        };
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+        // prologue: halo 0 and weight tiles 0, 1 synchronously; tiles 2..5 in flight
+        begin_A(0);
+        static_for<0, G>([&](auto K) { load_A(K); });
+        load_B(0, 0, S0{});
+        load_B(1 / TAPS, 1 % TAPS, S1{});
+        static_for<0, G>([&](auto K) { store_A(K, 0); });
+        store_B(0, S0{});
+        store_B(1, S1{});
+        load_B(2 / TAPS, 2 % TAPS, S2{});
+        load_B(3 / TAPS, 3 % TAPS, S3{});
+        load_B(4 / TAPS, 4 % TAPS, S0{});
+        load_B(5 / TAPS, 5 % TAPS, S1{});
+        __syncthreads();
+#ifdef PF_STAMPS
+        unsigned long long tL[2] = {0, 0};
+#endif
+        // U = position inside a group of FOUR chunks (the set index (s + 2) % 4 must be compile-time: 4 * TAPS steps)
+        auto lstep = [&](auto U, int chunk) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value;
+            constexpr int tap = u % TAPS;
+            using SET = std::integral_constant<int, (u + 2) % 4>;
+            const int s1 = slot3 == 2 ? 0 : slot3 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+#ifdef PF_STAMPS
+            unsigned long long tA, tB;
+            asm volatile("s_memtime %0" : "=s"(tA) :: "memory");
+#endif
+            __syncthreads();          // the MFMA waves are done with slot (s+2)%3 and with the other halo buffer
+#ifdef PF_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB), "+s"(tA) :: "memory");
+            { const int s = chunk * TAPS + tap;
+              if (blockIdx.x == 0 && lane == 0 && s < 40) {
+                unsigned long long* st = reinterpret_cast<unsigned long long*>(smem + PF_STAMP_OFF);
+                st[(wave * 40 + s) * 8 + 0] = tA; st[(wave * 40 + s) * 8 + 1] = tB;
+                if (s > 0) { st[(wave * 40 + s - 1) * 8 + 2] = tL[0]; st[(wave * 40 + s - 1) * 8 + 3] = tL[1]; } } }
+#endif
+            store_B(s2, SET{});                                                          // tile s+2 (loaded at step s-4)
+#ifdef PF_STAMPS
+            asm volatile("s_memtime %0" : "=s"(tL[0]) :: "memory");
+#endif
+            constexpr int t6 = (tap + 6) % TAPS, c6 = (tap + 6) / TAPS;
+            load_B(chunk + c6, t6, SET{});                                               // tile s+6
+#ifdef PF_STAMPS
+            asm volatile("s_memtime %0" : "=s"(tL[1]) :: "memory");
+#endif
+            if constexpr (tap == 0) begin_A(chunk + 1);
+            if constexpr (tap < G) load_A(std::integral_constant<int, tap>{});
+            if constexpr (tap >= G && tap < 2 * G) store_A(std::integral_constant<int, tap - G>{}, (chunk + 1) & 1);
+            slot3 = s1;
+        };
+        int c4i = 0;
+        for (; c4i + 3 < nchunks; c4i += 4)
+            static_for<0, 4 * TAPS>([&](auto U) { lstep(U, c4i + decltype(U)::value / TAPS); });
+        if (c4i < nchunks) static_for<0, TAPS>([&](auto U) { lstep(U, c4i); });
+        if (c4i + 1 < nchunks) static_for<TAPS, 2 * TAPS>([&](auto U) { lstep(U, c4i + 1); });
+        if (c4i + 2 < nchunks) static_for<2 * TAPS, 3 * TAPS>([&](auto U) { lstep(U, c4i + 2); });
+        return;                                             // the epilogue belongs to the MFMA waves (no barrier in it)
+    }
+
+    // ================================== MFMA waves ==================================
+    const int wy2 = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;     // pixel rows 2*wy2, 2*wy2 + 1; channel part wn
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    const char* a_lane = ah_bytes + ((2 * wy2) * HW + li) * (LDS_LD * 4) + 32 * lh;
+    const char* b_lane = bs_bytes + (32 * NT * wn + li) * B_ROW + 32 * lh;
+    // fragments, double buffered in registers: [set][...][piece]; pieces 0,1 = hi K-halves, 2,3 = lo K-halves
+    bf16x8 fa[2][2][4], fb[2][NT][4];
+    constexpr int NP = 8 + 4 * NT;                          // fragment reads per step
+    constexpr int NM = 12 * NT;                             // MFMAs per step
+    constexpr int FETCH_GAPS = NM - 2;
+    auto fetch_piece = [&](auto SET, auto P, int halo_buf, int ky, int kx, int slot) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value, p = decltype(P)::value;
+        if constexpr (p < 8) {
+            constexpr int m = p / 4, k = p % 4;
+            const char* ap = a_lane + (halo_buf * HALO_ROWS + (ky + m) * HW + kx) * (LDS_LD * 4);
+            fa[set][m][k] = *reinterpret_cast<const bf16x8*>(ap + (k & 1) * 16 + (k >> 1) * 64);
+        } else {
+            constexpr int t = (p - 8) / 4, k = (p - 8) % 4;
+            const char* bp = b_lane + (slot * BN + 32 * t) * B_ROW;
+            fb[set][t][k] = *reinterpret_cast<const bf16x8*>(bp + (k & 1) * 16 + (k >> 1) * 64);
+        }
+    };
+    __syncthreads();                                        // prologue of the loader waves is in LDS
+    static_for<0, NP>([&](auto P) { fetch_piece(std::integral_constant<int, 0>{}, P, 0, 0, 0, 0); });
+    auto mstep = [&](auto U, int chunk) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        constexpr int tap = u % TAPS, cur = u & 1;
+        constexpr int ntap = (tap + 1) % TAPS, nky = ntap / KW, nkx = ntap % KW;
+        const int nchunk = (tap == TAPS - 1) ? chunk + 1 : chunk;
+        const int s1 = slot3 == 2 ? 0 : slot3 + 1;
+        using NXT = std::integral_constant<int, cur ^ 1>;
+#ifdef PF_STAMPS
+        unsigned long long tA, tB;
+        asm volatile("s_memtime %0" : "=s"(tA) :: "memory");
+#endif
+        __syncthreads();              // slot (s+1)%3 and the halo of step s+1 are complete; fragment set `cur` has landed
+#ifdef PF_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB), "+s"(tA) :: "memory");
+        { const int s = chunk * TAPS + tap;
+          if (blockIdx.x == 0 && lane == 0 && s < 40) {
+            unsigned long long* st = reinterpret_cast<unsigned long long*>(smem + PF_STAMP_OFF);
+            st[(wave * 40 + s) * 8 + 0] = tA; st[(wave * 40 + s) * 8 + 1] = tB; } }
+#endif
+        static_for<0, NM>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            constexpr int idx = i % (2 * NT), m = idx / NT, t = idx % NT, j = i / (2 * NT), ks = j / 3, pass = j % 3;
+            if constexpr (pass == 0)
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][m][2 + ks], fb[cur][t][ks], acc[m][t], 0, 0, 0);
+            else if constexpr (pass == 1)
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][m][ks], fb[cur][t][2 + ks], acc[m][t], 0, 0, 0);
+            else
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][m][ks], fb[cur][t][ks], acc[m][t], 0, 0, 0);
+            PF_PIN();
+            static_for<0, NP>([&](auto P) __attribute__((always_inline)) {
+                if constexpr (decltype(P)::value * FETCH_GAPS / NP == i) fetch_piece(NXT{}, P, nchunk & 1, nky, nkx, s1);
+            });
+            PF_PIN();
+        });
+        slot3 = s1;
+    };
+    {
+        int c2 = 0;
+        for (; c2 + 1 < nchunks; c2 += 2)
+            static_for<0, 2 * TAPS>([&](auto U) { mstep(U, c2 + decltype(U)::value / TAPS); });
+        if (nchunks & 1)
+            static_for<0, TAPS>([&](auto U) { mstep(U, nchunks - 1); });
+    }
+#ifdef PF_STAMPS
+    if (blockIdx.x == 0) {            // (the loader waves wrote their stamps before their last barrier arrival... give them time)
+        __builtin_amdgcn_s_sleep(127);
+        const unsigned long long* st = reinterpret_cast<const unsigned long long*>(smem + PF_STAMP_OFF);
+        for (int i = tid; i < 8 * 40 * 8; i += 256) pf_stamp_buf[i] = st[i];
+    }
+#endif
+    const bool ragged = (g.W % TW) != 0 || (g.H % TH) != 0;
+    static_for<0, 2>([&](auto M) __attribute__((always_inline)) {      // (a runtime-indexed acc[m] would put the accumulators in scratch)
+        constexpr int m = decltype(M)::value;
+        const int wy = 2 * wy2 + m;
+        const bool row_ok = y0 + wy < g.H;
+        const int xlim = row_ok ? g.W - x0 - 4 * lh : 0;
+        const long p0 = pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh;
+        if (ragged) tile_epilogue<NT, true>(d, acc[m], n0 + 32 * NT * wn, li, p0, p0 + (xlim > 0 ? xlim : 0));
+        else tile_epilogue<NT, false>(d, acc[m], n0 + 32 * NT * wn, li, p0, 0);
+    });
+}
+
+template <int NT, int KH, int KW, int WN>
+int launch_conv_ws_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
+    constexpr int BN = 32 * NT * WN, TH = 8 / WN;
+    constexpr int HALO_ROWS = ((TH + KH - 1) * (32 + KW - 1) + 31) / 32 * 32;
+    constexpr size_t lds = (size_t)2 * HALO_ROWS * LDS_LD * sizeof(float) + (size_t)3 * BN * LDS_LD * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    const int B = g.M / g.N;
+    ConvGeom gg = g;
+    gg.ntiles = B * ((g.H + TH - 1) / TH) * ((g.W + 31) / 32);
+    gg.ntn = (max_cout + BN - 1) / BN;
+    gg.xcd_map = 1;
+    const dim3 grid((unsigned)((long)gg.ntiles * gg.ntn * ngroups));
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&pf_conv_ws_kernel<NT, KH, KW, WN>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return (int)attr;
+#ifdef PF_STAMPS
+    static_assert(lds <= 140 * 1024, "stamp area");
+    hipLaunchKernelGGL((pf_conv_ws_kernel<NT, KH, KW, WN>), grid, dim3(512), 160 * 1024, stream, grp, gg);
+#else
+    hipLaunchKernelGGL((pf_conv_ws_kernel<NT, KH, KW, WN>), grid, dim3(512), lds, stream, grp, gg);
+#endif
     return (int)hipGetLastError();
 }
 
@@ -1030,7 +1396,7 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision
 }
 
 #ifdef PF_STAMPS
-extern "C" int pf_conv_read_stamps(unsigned long long* out) {   // [8 waves][40 steps][before barrier, after barrier, 4 mid-step stamps, 2 unused]
+extern "C" int pf_conv_read_stamps(unsigned long long* out) {   // [8 waves][40 steps][before barrier, after barrier, 4 mid-step stamps, 2 ring-piece stamps]
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_stamp_buf), sizeof(unsigned long long) * 8 * 40 * 8);
 }
 #endif
@@ -1039,6 +1405,14 @@ extern "C" int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int
     ConvGroups grp; ConvGeom g; int max_cout;
     const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
     return rc != PF_OK ? rc : conv_tile(g, ngroups, max_cout, descs[0].precision);
+}
+
+extern "C" int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
+    ConvGroups grp; ConvGeom g; int max_cout;
+    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
+    if (rc != PF_OK) return rc;
+    const int tile = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    return (tile == 3 || tile == 4) ? conv_ws_choice(grp, ngroups, g, max_cout) : 0;
 }
 
 extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream) {

@@ -324,12 +324,12 @@ struct PfLookupArgs {
 };
 // One call = PF_LOOKUP_TPT consecutive taps (same level, same slow index a): their gather chains
 // (coords -> grid taps -> other-volume taps) are independent, so the loads of all of them are in
-// flight together.  Timing-only ablations (profiles/scratch/ablate_lookup.sh) showed the kernel bound by the
+// flight together.  Timing-only ablations (round 1; profiles/microbench_lookup.py is the harness) showed the kernel bound by the
 // NUMBER of gather instructions, cache-resident ones included (no own-window loads -7 us, no grid loads -9 us,
 // no other-volume loads -4 us, no stores -3 us of 32 us).  Consecutive taps of a column share a row (the lower
 // row of tap j is the upper row of tap j+1), so a row pair is loaded once and reused when its ADDRESS matches --
 // same address, same value: results are bit-identical to per-tap loads.  Own window and the two grid components:
-// 4 loads per 3 taps instead of 6 each.  Measured in one call (profiles/scratch/ab_lookup_tpt.sh): 32.8 us without
+// 4 loads per 3 taps instead of 6 each.  Measured in one call (round-1 A/B): 32.8 us without
 // reuse, 27.4 us with it at 3 taps per call, 43 us at 9 taps per call (a whole column: too few, too fat threads).
 #ifndef PF_LOOKUP_TPT
 #define PF_LOOKUP_TPT 3

@@ -27,7 +27,7 @@ int pf_launch_elem(const Args& a, long total, void* stream) {
 // Experiment knob (not defined in the product build): the DCCL lookup as its own __global__ with a forced occupancy
 // (PF_LOOKUP_WAVES = waves per SIMD the register allocator must make room for).  The generic wrapper uses 90 VGPRs =
 // 5 waves, and that is the optimum: 3 / 4 / 5 / 6 / 8 waves -> 26.7 / 24.3 / 22.9 / 25.1 / 43.4 us per launch
-// (interleaved grid, profiles/scratch/ab_lookup_occ.sh).
+// (interleaved grid; round-1 A/B).
 #ifdef PF_LOOKUP_WAVES
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PF_LOOKUP_WAVES, PF_LOOKUP_WAVES)))
 pf_lookup_kernel(const PfLookupArgs a, const long total) {
@@ -404,7 +404,7 @@ int launch_stem7x7c2(const PfSmallConvMulti& m, int n, void* stream) {
     const long blocks = (long)a.B * a.H * ((a.W + 63) / 64) * (a.Cout / 64);
     if (blocks <= 0 || blocks >= (1L << 31)) return PF_ERR_BAD_SHAPE;
     // CPW = 8: 6 waves per SIMD hide the scalar weight loads best (three stems of 64x128: 22.2 / 19.9 / 17.5 us for
-    // CPW = 32 / 16 / 8 against 36.7 us on the MFMA kernel, profiles/scratch/microbench_stem.py)
+    // CPW = 32 / 16 / 8 against 36.7 us on the MFMA kernel; round-1 micro-benchmark)
     hipLaunchKernelGGL((pf_stem7x7c2_valu<8>), dim3((unsigned)(blocks * 4), (unsigned)n), dim3(128), 0, (hipStream_t)stream, m);
     return (int)hipGetLastError();
 }
@@ -1026,5 +1026,5 @@ extern "C" int pf_motion_prep(const float* c1a, const float* c1b, const float* g
 }
 
 extern "C" const char* pf_version(void) {
-    return "priorflow-hip r1 gfx950 (bf16x3 / exact-fp32 MFMA implicit-GEMM convs, fused corr+pyramid, HIP encoders)";
+    return "priorflow-hip r2 gfx950 (bf16x3 / exact-fp32 MFMA implicit-GEMM convs, fused corr+pyramid, fused combine+1x1, HIP encoders, HIP training backward)";
 }

@@ -70,7 +70,9 @@ class BasicEncoder(nn.Module):
 
     def forward(self, x):
         """x: one NCHW batch (callers concatenate the image list on dim 0 themselves).
-        SURVEY.md §8f rank 1: the encoders still run on PyTorch-ROCm convolutions."""
+        Plain-torch statement of core/extractor.py:144-170, kept for the state_dict tree and for CPU shape checks;
+        the product never calls it: inference runs ``engine.EncoderPlan`` (HIP, either precision) and training
+        ``autograd.encoder_forward``."""
         x = self.relu1(self.norm1(self.conv1(x)))
         x = self.layer3(self.layer2(self.layer1(x)))
         x = self.conv2(x)

@@ -94,5 +94,5 @@ for _ in range(reps):
 e.record()
 torch.cuda.synchronize()
 us = s.elapsed_time(e) * 1e3 / reps
-print(f"{which}: tile {lib.conv2d_tile(descs, 1, H8, W8)}  {us:.1f} us/launch  {flops / us / 1e6:.1f} TFLOP/s algorithmic "
+print(f"{which}: tile {lib.conv2d_tile(descs, 1, H8, W8)} roles {lib.conv2d_roles(descs, 1, H8, W8)}  {us:.1f} us/launch  {flops / us / 1e6:.1f} TFLOP/s algorithmic "
       f"({'fp32' if prec == PREC_F32 else 'bf16x3'})")

@@ -14,7 +14,7 @@ from prior_flow_amd.engine import rotation_x
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 # PF_LIB=<path> times another build of the per-element kernels (e.g. the ablation variants of
-# profiles/scratch/ablate_lookup.sh, which hold only pf_elem_kernels.hip)
+# round-1 ablation builds, which held only pf_elem_kernels.hip)
 lib = _lib.PfLib(os.environ["PF_LIB"], optional=tuple(_lib._SIGNATURES)) if os.environ.get("PF_LIB") else _lib.load()
 dev = torch.device("cuda:0")
 B, H8, W8 = 1, 64, 128

@@ -33,11 +33,22 @@ if os.environ.get("STAMP_CHILD") != "1":
     assert rc == 0, rc
     t = np.frombuffer(buf, dtype=np.uint64).reshape(8, 40, 8).astype(np.int64)
     nsteps = 38
+    if os.environ.get("STAMP_SIMPLE", "0") == "1":      # barrier stamps only (the role-specialised kernel): issue phase and wait per wave
+        print(f"{which}: per step and wave: issue = cycles from the barrier exit to the next barrier arrival, wait = cycles in the barrier")
+        for s in range(1, nsteps):
+            issue = t[:, s + 1, 0] - t[:, s, 1]
+            wait = t[:, s + 1, 1] - t[:, s + 1, 0]
+            print(f"step {s:2d}  issue: " + " ".join(f"{int(x):5d}" for x in issue) + "   wait: " + " ".join(f"{int(x):5d}" for x in wait)
+                  + f"   step {int(t[:, s + 1, 1].max() - t[:, s, 1].max()):5d}"
+                  + "   loaders: ring slot written at " + " ".join(f"{int(t[w, s, 2] - t[w, s, 1]):4d}" for w in range(4, 8))
+                  + ", loads issued at " + " ".join(f"{int(t[w, s, 3] - t[w, s, 1]):4d}" for w in range(4, 8)))
+        sys.exit(0)
     print(f"{which}: s_memtime ticks, workgroup 0; per step and wave: cycles from the barrier exit (B) to")
-    print("   m0 = after gap 2 (3 MFMAs issued) | m1 = after gap 3 (ring store/load piece) | m2 = after gap 6 | m3 = after gap 9 | A = all issued | next B")
+    print("   m0 = after gap 2 (3 MFMAs issued) | m1 = after gap 3 (ring piece: start = M3 issued, stored = slot s+2 written from registers, then addresses + loads of s+4) | m2 = after gap 6 | m3 = after gap 9 | A = all issued | next B")
     for s in range(1, nsteps):
         print(f"step {s}")
         for w in range(8):
             b = t[w, s, 1]
             m = [int(t[w, s, 2 + k] - b) for k in range(4)]
-            print(f"   wave {w}: m0 {m[0]:5d}  m1 {m[1]:5d}  m2 {m[2]:5d}  m3 {m[3]:5d}  A {int(t[w, s + 1, 0] - b):5d}  nextB {int(t[w, s + 1, 1] - b):5d}")
+            r = [int(t[w, s, 6 + k] - b) for k in range(2)]
+            print(f"   wave {w}: m0 {m[0]:5d}  [ring piece: start {r[0]:5d} stored {r[1]:5d}]  m1 {m[1]:5d}  m2 {m[2]:5d}  m3 {m[3]:5d}  A {int(t[w, s + 1, 0] - b):5d}  nextB {int(t[w, s + 1, 1] - b):5d}")

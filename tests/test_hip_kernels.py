@@ -517,3 +517,25 @@ def test_encoder_plan_vs_reference_golden(lib, dev, params, which):
     kc.check(got[:, sel], g[which], 3e-4, f"{which} vs reference")
     want = po.encoder(params, which + ".", im, "instance" if which == "fnet" else "batch")
     kc.check(got, want, 3e-4, f"{which} vs oracle (all channels)")
+
+
+@pytest.mark.gpu
+def test_conv_roles_kernel_matches_symmetric_kernel_bitwise(tmp_path):
+    """pf_conv_ws_kernel (four MFMA waves + four loader waves, either tile) accumulates every output in the symmetric
+    halo kernel's order: same bits.  PRIORFLOW_CONV_WS is read once per process, so each form runs in a child."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for ws in ("0", "1", "2"):
+        path = str(tmp_path / f"ws{ws}.pt")
+        env = dict(os.environ, PRIORFLOW_CONV_WS=ws)
+        subprocess.run([sys.executable, os.path.join(here, "run_conv_case.py"), path], check=True, env=env, timeout=600)
+        res[ws] = torch.load(path)
+    assert set(res["0"]["roles"].values()) == {0}
+    assert set(res["1"]["roles"].values()) == {1}
+    assert 2 in res["2"]["roles"].values() and 1 in res["2"]["roles"].values()       # both tiles of the default are exercised
+    for key, ref in res["0"]["out"].items():
+        assert torch.isfinite(ref).all() and ref.abs().max() > 0.05, key
+        for ws in ("1", "2"):
+            assert torch.equal(res[ws]["out"][key], ref), (key, ws, (res[ws]["out"][key] - ref).abs().max().item())
