@@ -84,13 +84,35 @@ else:
     cv = [conv(128, 256, 3, 3) for _ in range(3)]
     descs = [cv[i].desc(net[i % 2], 0, 128, out[i], 0, EPI_RELU) for i in range(3)]
     flops = 3 * 2.0 * N * 256 * 9 * 128
-for _ in range(3):
-    lib.conv2d(descs, 1, H8, W8, x[0])
+# MB_WSETS=n: rotate through n copies of the weights (as in the forward, where ~40 MB of other layers' weights pass
+# through the 4 MB L2 between two uses of a layer: the weight stream then comes from the Infinity Cache, not from L2)
+WSETS = int(os.environ.get("MB_WSETS", "1"))
+variants = [descs]
+if WSETS > 1:
+    import ctypes
+    for k in range(1, WSETS):
+        ds = []
+        for d_ in descs:
+            d2 = type(d_)()
+            ctypes.memmove(ctypes.byref(d2), ctypes.byref(d_), ctypes.sizeof(d_))
+            w2 = torch.empty_like(d_._keep[9]).copy_(d_._keep[9])
+            d2.weight = w2.data_ptr()
+            d2._keep = d_._keep + (w2,)
+            ds.append(d2)
+        variants.append(ds)
+for k in range(3):
+    lib.conv2d(variants[k % WSETS], 1, H8, W8, x[0])
 torch.cuda.synchronize()
+if os.environ.get("MB_EACH", "0") == "1":      # per-launch times (looking for outliers)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for k in range(reps):
+        evs[k][0].record(); lib.conv2d(variants[k % WSETS], 1, H8, W8, x[0]); evs[k][1].record()
+    torch.cuda.synchronize()
+    print(which, "per-launch us:", " ".join(f"{a.elapsed_time(b) * 1e3:.0f}" for a, b in evs))
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
-for _ in range(reps):
-    lib.conv2d(descs, 1, H8, W8, x[0])
+for k in range(reps):
+    lib.conv2d(variants[k % WSETS], 1, H8, W8, x[0])
 e.record()
 torch.cuda.synchronize()
 us = s.elapsed_time(e) * 1e3 / reps
