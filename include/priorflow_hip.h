@@ -93,6 +93,21 @@ int pf_dccl_lookup_il(const float* coords,
                       const float* g_w2c, const float* g_w2c_il, float* own_out, float* raw_out,
                       int B, int H8, int W8, int ld, void* stream);
 
+/* Both branches' lookups of one iteration (core/prior_raft.py:185-188: corr_fn_A(coords1_A), corr_fn_B(coords1_B)) as ONE
+ * launch: descs[0] and descs[1] are two pf_dccl_lookup_il problems of the same shape.  Alone a lookup moves 95 MB at
+ * half the HBM rate; as two concurrent launches on two queues the pair took as long as back to back and cost a
+ * cross-queue join (~10 us) on the critical chain -- one grid over both has neither. */
+typedef struct pf_lookup_desc {
+    const float* coords;        /* planar [B,2,H8,W8] */
+    const float* own[4];        /* this view's pyramid, level i: [B*N][(H8>>i)*(W8>>i)] */
+    const float* other[4];      /* the other view's pyramid */
+    const float* g_w2c;         /* [2,H8,W8] */
+    const float* g_w2c_il;      /* optional interleaved copy [N][2], or NULL */
+    float* own_out;             /* [B*N][ld] */
+    float* raw_out;             /* [B*N][ld] */
+} pf_lookup_desc;
+int pf_dccl_lookup_pair(const pf_lookup_desc* descs, int B, int H8, int W8, int ld, void* stream);
+
 /* DCCL.__call__ step 3 + the caller's add (core/corr.py:138, core/prior_raft.py:187-188):
  * out = own + img_rotate(raw, g_back), channel-last. */
 int pf_dccl_combine(const float* own, const float* raw, const float* g_back, float* out,

@@ -23,6 +23,12 @@ _fp = C.c_void_p
 _i = C.c_int
 
 
+class LookupDesc(C.Structure):
+    """Mirror of ``pf_lookup_desc`` (include/priorflow_hip.h)."""
+    _fields_ = [("coords", C.c_void_p), ("own", C.c_void_p * 4), ("other", C.c_void_p * 4), ("g_w2c", C.c_void_p),
+                ("g_w2c_il", C.c_void_p), ("own_out", C.c_void_p), ("raw_out", C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     """Mirror of ``pf_conv_desc`` (include/priorflow_hip.h)."""
     _fields_ = [
@@ -63,6 +69,7 @@ _SIGNATURES = {
     "pf_split_bf16": [_fp, _fp, C.c_long, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
     "pf_dccl_lookup_il": [_fp] * 13 + [_i, _i, _i, _i, _fp],
+    "pf_dccl_lookup_pair": [C.c_void_p, _i, _i, _i, _i, _fp],
     "pf_dccl_combine": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_warp_gcorr": [_fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _fp],
     "pf_conf_stem": [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
@@ -254,6 +261,27 @@ class PfLib:
             _ptr(coords), *[_ptr(p) for p in pyr_own], *[_ptr(p) for p in pyr_other],
             _ptr(g_w2c), _ptr(g_il), _ptr(own_out), _ptr(raw_out), B, H, W, own_out.shape[-1],
             self._stream(coords)), "pf_dccl_lookup_il")
+
+    def dccl_lookup_pair(self, items):
+        """items: two tuples (coords, pyr_own, pyr_other, g_w2c, own_out, raw_out, g_il) -- both branches' lookups, one launch."""
+        if len(items) != 2:
+            raise PfError("dccl_lookup_pair takes exactly two problems")
+        arr = (LookupDesc * 2)()
+        for d, (coords, pyr_own, pyr_other, g_w2c, own_out, raw_out, g_il) in zip(arr, items):
+            self._chk(coords, g_w2c, own_out, raw_out, g_il, *pyr_own, *pyr_other)
+            if coords.shape != items[0][0].shape or own_out.shape != items[0][4].shape:
+                raise PfError("dccl_lookup_pair: the two problems must have the same shape")
+            d.coords = coords.data_ptr()
+            for l in range(4):
+                d.own[l] = pyr_own[l].data_ptr()
+                d.other[l] = pyr_other[l].data_ptr()
+            d.g_w2c = g_w2c.data_ptr()
+            d.g_w2c_il = g_il.data_ptr() if g_il is not None else None
+            d.own_out, d.raw_out = own_out.data_ptr(), raw_out.data_ptr()
+        coords, own_out = items[0][0], items[0][4]
+        B, _, H, W = coords.shape
+        self._rc(self._dll.pf_dccl_lookup_pair(C.cast(arr, C.c_void_p), B, H, W, own_out.shape[-1], self._stream(coords)),
+                 "pf_dccl_lookup_pair")
 
     def dccl_combine(self, own, raw, g_back, out, B, H8, W8):
         self._chk(own, raw, g_back, out)

@@ -167,6 +167,19 @@ def case_dccl(lib, dev):
     o_own, o_cross = po.dccl_lookup(co.cpu(), po.build_pyramid(vb), po.build_pyramid(va),
                                     g["b2aT_16x32"].cpu(), g["a2b_16x32"].cpu())
     check(corr_n, o_own + o_cross, 1e-3, "corr_b vs oracle (all pixels)")
+    # both directions as ONE launch (pf_dccl_lookup_pair): bit-identical to the two single launches
+    own_a, raw_a = torch.empty(N, LD, device=dev), torch.empty(N, LD, device=dev)
+    lib.dccl_lookup(co, pa_d, pb_d, gw, own_a, raw_a, g_il)
+    co_b = co.flip(-1).contiguous()                      # different coordinates for the second problem
+    own_b1, raw_b1 = torch.empty(N, LD, device=dev), torch.empty(N, LD, device=dev)
+    lib.dccl_lookup(co_b, pb_d, pa_d, g["b2aT_16x32"], own_b1, raw_b1)
+    pa2, pb2 = (torch.full((N, LD), 3.0, device=dev) for _ in range(2)), (torch.full((N, LD), 3.0, device=dev) for _ in range(2))
+    own_pa, raw_pa = pa2
+    own_pb, raw_pb = pb2
+    lib.dccl_lookup_pair([(co, pa_d, pb_d, gw, own_pa, raw_pa, g_il),
+                          (co_b, pb_d, pa_d, g["b2aT_16x32"], own_pb, raw_pb, None)])
+    assert torch.equal(own_pa, own_a) and torch.equal(raw_pa, raw_a), "pair launch, problem 0"
+    assert torch.equal(own_pb, own_b1) and torch.equal(raw_pb, raw_b1), "pair launch, problem 1"
     # padded row stride
     own2 = torch.full((N, 336), 7.0, device=dev)
     raw2 = torch.full((N, 336), 7.0, device=dev)
