@@ -23,6 +23,13 @@ _fp = C.c_void_p
 _i = C.c_int
 
 
+def _norm_bwd_blocks(Np: int) -> int:
+    """Pixel chunks of pf_norm_bwd's two-stage reduction: ~sqrt(Np), so the partial pass (one thread per chunk and channel)
+    and the final pass (one thread per channel, looping over the chunks) are equally long serial loops.  (Np // 64 made
+    the final pass of a 192x256 map a 768-step loop: 88 us per call.)"""
+    return max(1, min(Np, int(round(Np ** 0.5))))
+
+
 class LookupDesc(C.Structure):
     """Mirror of ``pf_lookup_desc`` (include/priorflow_hip.h)."""
     _fields_ = [("coords", C.c_void_p), ("own", C.c_void_p * 4), ("other", C.c_void_p * 4), ("g_w2c", C.c_void_p),
@@ -452,7 +459,7 @@ class PfLib:
         self._chk(dy, x, scale, shift, dx)
         part = coef = None
         if instance:
-            nblk = nblk or max(1, min(Np, Np // 64))
+            nblk = nblk or _norm_bwd_blocks(Np)
             part = torch.empty(B * nblk * Cc * 2, dtype=torch.float64, device=dy.device)
             coef = torch.empty(B * Cc * 2, dtype=torch.float32, device=dy.device)
         self._rc(self._dll.pf_norm_bwd(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), int(relu), int(instance),
@@ -463,7 +470,7 @@ class PfLib:
         """Per-(image, channel) means of g and g * (x*scale+shift) over the Np pixels: [B, C, 2] (the reduction stage of
         pf_norm_bwd's InstanceNorm branch; its dx is written to a scratch buffer and discarded)."""
         self._chk(dy, x, scale, shift)
-        nblk = nblk or max(1, min(Np, Np // 64))
+        nblk = nblk or _norm_bwd_blocks(Np)
         part = torch.empty(B * nblk * Cc * 2, dtype=torch.float64, device=dy.device)
         coef = torch.empty(B * Cc * 2, dtype=torch.float32, device=dy.device)
         scratch = torch.empty_like(x)

@@ -270,6 +270,7 @@ struct WgradSmallArgs {
 };
 constexpr int WS_T = 8, WS_MAXTAPS = 13, WS_MAXC = 4;
 
+template <int CIN>
 __global__ void __launch_bounds__(256) pf_wgrad_small_kernel(const WgradSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ws_lds[];
     const int PW = (WS_T - 1) * a.stride + a.kw, PH = (WS_T - 1) * a.stride + a.kh;
@@ -285,13 +286,13 @@ __global__ void __launch_bounds__(256) pf_wgrad_small_kernel(const WgradSmallArg
 #pragma unroll
     for (int j = 0; j < WS_MAXTAPS; ++j) {
         const int tap = tg + 4 * j;
-        toff[j] = tap < taps ? ((tap / a.kw) * PW + tap % a.kw) * a.cin : -1;
+        toff[j] = tap < taps ? ((tap / a.kw) * PW + tap % a.kw) * CIN : 0;      // a tap past the window re-reads tap 0 (never stored)
     }
-    float acc[WS_MAXTAPS][WS_MAXC];
+    float acc[WS_MAXTAPS][CIN];
 #pragma unroll
     for (int j = 0; j < WS_MAXTAPS; ++j)
 #pragma unroll
-        for (int c = 0; c < WS_MAXC; ++c) acc[j][c] = 0.f;
+        for (int c = 0; c < CIN; ++c) acc[j][c] = 0.f;
     float bsum = 0.f;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int img = (int)(tile / (tiles_x * tiles_y)), tin = (int)(tile % (tiles_x * tiles_y));
@@ -305,12 +306,12 @@ __global__ void __launch_bounds__(256) pf_wgrad_small_kernel(const WgradSmallArg
                 v = *reinterpret_cast<const f32x4*>(a.dy + ((long)img * a.Ho * a.Wo + (long)yy * a.Wo + xx) * a.ld_dy + a.off_dy + o0 + c4);
             *reinterpret_cast<f32x4*>(dyt + px * 64 + c4) = v;
         }
-        for (int e = tid; e < PH * PW * a.cin; e += 256) {
-            const int c = e % a.cin, pp = e / a.cin;
+        for (int e = tid; e < PH * PW * CIN; e += 256) {
+            const int c = e % CIN, pp = e / CIN;
             const int yy = y0 * a.stride + pp / PW - pad_h, xx = x0 * a.stride + pp % PW - pad_w;
             float v = 0.f;
             if (yy >= 0 && yy < Hi && xx >= 0 && xx < Wi)
-                v = a.nchw ? a.x[(((long)img * a.cin + c) * Hi + yy) * Wi + xx]
+                v = a.nchw ? a.x[(((long)img * CIN + c) * Hi + yy) * Wi + xx]
                            : a.x[((long)img * Hi * Wi + (long)yy * Wi + xx) * a.ld_in + a.off_in + c];
             patch[e] = v;
         }
@@ -318,14 +319,18 @@ __global__ void __launch_bounds__(256) pf_wgrad_small_kernel(const WgradSmallArg
         for (int px = 0; px < 64; ++px) {
             const float g = dyt[px * 64 + o];
             if (tg == 0) bsum += g;
-            const float* pb = patch + (((px >> 3) * PW + (px & 7)) * a.stride) * a.cin;
+            const float* pb = patch + (((px >> 3) * PW + (px & 7)) * a.stride) * CIN;
+            // no data-dependent branch in here: the 13 x CIN patch reads of a pixel are independent and issue back to back
+            // (with a `break` on the first unused tap they were one exposed LDS round trip each: 136 us per flow stem)
+            float xv[WS_MAXTAPS][CIN];
 #pragma unroll
-            for (int j = 0; j < WS_MAXTAPS; ++j) {
-                if (toff[j] < 0) break;                 // wave-uniform (tg is per wave)
+            for (int j = 0; j < WS_MAXTAPS; ++j)
 #pragma unroll
-                for (int c = 0; c < WS_MAXC; ++c)
-                    if (c < a.cin) acc[j][c] = __builtin_fmaf(g, pb[toff[j] + c], acc[j][c]);
-            }
+                for (int c = 0; c < CIN; ++c) xv[j][c] = pb[toff[j] + c];
+#pragma unroll
+            for (int j = 0; j < WS_MAXTAPS; ++j)
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) acc[j][c] = __builtin_fmaf(g, xv[j][c], acc[j][c]);
         }
     }
     if (o0 + o < a.cout) {
@@ -334,8 +339,7 @@ __global__ void __launch_bounds__(256) pf_wgrad_small_kernel(const WgradSmallArg
             const int tap = tg + 4 * j;
             if (tap < taps)
 #pragma unroll
-                for (int c = 0; c < WS_MAXC; ++c)
-                    if (c < a.cin) atomicAdd(a.dw + ((long)(o0 + o) * a.cin + c) * taps + tap, acc[j][c]);
+                for (int c = 0; c < CIN; ++c) atomicAdd(a.dw + ((long)(o0 + o) * CIN + c) * taps + tap, acc[j][c]);
         }
         if (tg == 0 && a.db) atomicAdd(a.db + o0 + o, bsum);
     }
@@ -359,7 +363,12 @@ extern "C" int pf_conv2d_wgrad_small(const float* x, int nchw, int ld_in, int of
     const size_t lds = (size_t)(64 * 64 + PH * PW * cin) * sizeof(float);
     const long ntiles = (long)B * ((Hout + WS_T - 1) / WS_T) * ((Wout + WS_T - 1) / WS_T);
     dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024), (unsigned)((cout + 63) / 64));
-    hipLaunchKernelGGL(pf_wgrad_small_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    switch (cin) {
+        case 1: hipLaunchKernelGGL(pf_wgrad_small_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL(pf_wgrad_small_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
+        case 3: hipLaunchKernelGGL(pf_wgrad_small_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL(pf_wgrad_small_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
+    }
     return (int)hipGetLastError();
 }
 
