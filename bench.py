@@ -351,10 +351,17 @@ def main():
     i1c, i2c = synthetic_pair(args.batch, H, W, seed=shard_seed(1234, rank))
     i1, i2 = i1c.to(device), i2c.to(device)
 
+    def rank_barrier():
+        # RCCL's barrier is an all-reduce on a device tensor: name the device, or it guesses from the global rank
+        if backend == "nccl":
+            dist.barrier(device_ids=[local])
+        else:
+            dist.barrier()
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            rank_barrier()
         torch.cuda.synchronize()
 
     with torch.no_grad():
@@ -413,7 +420,7 @@ def main():
                     result["fp32_exact"] = {"error": repr(exc)}
         print(json.dumps(result), flush=True)
     if dist is not None:
-        dist.barrier()
+        rank_barrier()
         dist.destroy_process_group()
     return result
 

@@ -201,9 +201,9 @@ int pf_dccl_combine_conv1x1(const pf_combine_conv_desc* descs, int ngroups, int 
  * branch A and branch B of an iteration run side by side.  H8, W8 = OUTPUT map size. */
 int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream);
 
-/* Host-only introspection: which workgroup tile pf_conv2d would use for this launch
- * (0: 128x32, 1: 64x64, 2: 64x128 pixels x channels), or a negative PF_ERR_* code.  Lets a
- * profiler attribute measured time to the right kernel instantiation; launches nothing. */
+/* Host-only introspection: which workgroup tile pf_conv2d would use for this launch -- generic kernel 0: 128x32,
+ * 1: 64x64, 2: 64x128 (pixels x channels); halo kernel 3: 128x64, 4: 128x128, 5: 256x64 (8-row tile) -- or a negative
+ * PF_ERR_* code.  Lets a profiler attribute measured time to the right kernel instantiation; launches nothing. */
 int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8);
 
 /* Host-only introspection, companion of pf_conv2d_tile for tiles 3 / 4: which wave organisation the launch takes --

@@ -2,7 +2,7 @@
 # Regenerates the committed round-2 measurement artefacts on the GPU box (run through gpurun from the repo root):
 #   gpurun_out/final/{pytest_gpu.log,bench_n1.json,kernel_stats.csv,forward_breakdown.txt,iteration_timeline.txt,
 #                     pmc_traffic.json,mfma_busy.json,bench_batch32.json,time_sizes.txt,train_step_time.json,bench_gloo2.json,train_2rank_check.txt,
-#                     conv_microbench.txt,conv_stamps_zr.txt}
+#                     conv_microbench.txt,conv_stamps_symmetric_zr.txt,conv_stamps_roles_zr.txt}
 export TMPDIR=/tmp
 O=gpurun_out/final
 mkdir -p $O
@@ -30,5 +30,8 @@ python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --mas
 for w in zr q fh1 c2 c1; do python profiles/microbench_conv.py 50 $w 2>/dev/null; done > $O/conv_microbench.txt
 MB_BATCH=8 python profiles/microbench_conv.py 20 zr >> $O/conv_microbench.txt 2>/dev/null
 # in-kernel stamps of the halo conv's K-step (diagnostic build: hipcc ... -DPF_STAMPS -o prior-flow_amd/lib/diag/STAMPS.so)
-[ -f prior-flow_amd/lib/diag/STAMPS.so ] && PRIORFLOW_LIB=$PWD/prior-flow_amd/lib/diag/STAMPS.so python profiles/stamp_conv.py zr 2>/dev/null | head -90 > $O/conv_stamps_zr.txt
+if [ -f prior-flow_amd/lib/diag/STAMPS.so ]; then
+  PRIORFLOW_CONV_WS=0 PRIORFLOW_LIB=$PWD/prior-flow_amd/lib/diag/STAMPS.so python profiles/stamp_conv.py zr 2>/dev/null | head -90 > $O/conv_stamps_symmetric_zr.txt
+  STAMP_SIMPLE=1 PRIORFLOW_CONV_WS=1 PRIORFLOW_LIB=$PWD/prior-flow_amd/lib/diag/STAMPS.so python profiles/stamp_conv.py zr 2>/dev/null | head -40 > $O/conv_stamps_roles_zr.txt
+fi
 cat $O/pytest_gpu.log; cut -c1-300 $O/bench_n1.json; head -3 $O/forward_breakdown.txt | cut -c1-200; cat $O/time_sizes.txt; cut -c1-200 $O/bench_batch32.json
