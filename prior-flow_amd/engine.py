@@ -242,6 +242,10 @@ class Workspace:
         self.pyr_a = [z(rows, (H8 >> i) * (W8 >> i)) for i in range(4)]
         self.pyr_b = [z(rows, (H8 >> i) * (W8 >> i)) for i in range(4)]
         # ---- loop state
+        # coords0 (the pixel grid, core/utils/utils.py:75-78) is a constant of the shape: built once, copied per forward
+        xs = torch.arange(W8, device=device, dtype=torch.float32).view(1, 1, 1, W8).expand(B, 1, H8, W8)
+        ys = torch.arange(H8, device=device, dtype=torch.float32).view(1, 1, H8, 1).expand(B, 1, H8, W8)
+        self.coords0 = torch.cat([xs, ys], 1).contiguous()
         self.c1a = z(B, 2, H8, W8)
         self.c1b = z(B, 2, H8, W8)
         self.flow_b = z(B, 2, H8, W8)
@@ -318,11 +322,8 @@ class Engine:
     def init_coords(self, ws: Workspace, init_flow: Optional[torch.Tensor]):
         """initialize_flow (+ init_flow) (core/prior_raft.py:161-165)."""
         B, H8, W8 = ws.B, ws.H8, ws.W8
-        xs = torch.arange(W8, device=ws.device, dtype=torch.float32).view(1, 1, 1, W8).expand(B, 1, H8, W8)
-        ys = torch.arange(H8, device=ws.device, dtype=torch.float32).view(1, 1, H8, 1).expand(B, 1, H8, W8)
-        c0 = torch.cat([xs, ys], 1)
-        ws.c1a.copy_(c0)
-        ws.c1b.copy_(c0)
+        ws.c1a.copy_(ws.coords0)
+        ws.c1b.copy_(ws.coords0)
         if init_flow is not None:
             fl = init_flow.to(torch.float32).contiguous()
             ws.c1a.add_(fl)
