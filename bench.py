@@ -127,7 +127,10 @@ def profile_kernels(model, i1, i2):
         tile = lib.conv2d_tile(descs, B, H8, W8)
         d0 = descs[0]
         roles = lib.conv2d_roles(descs, B, H8, W8) if tile in (3, 4) else 0
-        if roles:          # role-specialised waves: <NT, KH, KW, WN> exactly as rocprof names it
+        if roles >= 16:    # pre-split operands: the all-DMA kernel, <NT, KH, KW, WN> exactly as rocprof names it
+            r = roles - 16
+            tile = "pf_conv_dma_kernel<%d, %d, %d, %d>" % (2 if (tile == 4 or r == 2) else 1, d0.kh, d0.kw, 3 - r)
+        elif roles:        # role-specialised waves: <NT, KH, KW, WN> exactly as rocprof names it
             tile = "pf_conv_ws_kernel<%d, %d, %d, %d>" % (2 if (tile == 4 or roles == 2) else 1, d0.kh, d0.kw, 3 - roles)
         elif tile >= 3:    # halo kernel: the instantiation is <NT, KH, KW, AFFINE, TH> exactly as rocprof names it
             tile = "pf_conv_halo_kernel<%d, %d, %d, %s, %d>" % (

@@ -124,19 +124,22 @@ int pf_warp_gcorr(const float* f1, const float* f2, const float* coords, int add
  * groupwise correlations flaw_A = gwc(f1A, warp(f2A, coords1_A)), flaw_B_A = gwc(f1A, warp(f2A, coords0 + flow_B_A)).
  * Bit-identical to pf_flow_prep x2 + pf_flo_rotate + pf_warp_gcorr x2.  Outputs: flow4_a [B*N][4] = flow_A | flow_B_A,
  * flow2_b [B*N][2]; optional GRU-input tails xa (4 columns at xa_off) / xb (2 columns at xb_off); conf [B*N][conf_ld]
- * columns 0..3 flaw_A, 4..7 flaw_B_A.  C must be 256. */
+ * columns 0..3 flaw_A, 4..7 flaw_B_A.  C must be 256.  xa_split / xb_split (with xa_lds / xb_lds chunks per row): optional
+ * split twins (see pf_conv_desc) of the GRU-input buffers, tails written at the same channel offsets xa_off / xb_off. */
 int pf_motion_prep(const float* c1a, const float* c1b, const float* g_w2c, const float* g_c2w,
                    const float* f1a, const float* f2a, float* flow4_a, float* flow2_b,
                    float* xa, int xa_ld, int xa_off, float* xb, int xb_ld, int xb_off,
+                   void* xa_split, int xa_lds, void* xb_split, int xb_lds,
                    float* conf, int conf_ld, int B, int H8, int W8, int C, void* stream);
 
 /* Confidence stem of the ODDC motion encoder in one launch (core/update.py:177-178,193-194):
  * out[.., off_out .. off_out+16) = relu(conv3x3_{32->16}(relu(conv3x3_{8->32}(in[.., off_in .. off_in+8))))), zero padding,
  * exact fp32; w1 [9*8][32], w2 [9*32][16] in the [KH*KW][Cin][Cout] packing of pf_conv2d_direct.  The 32-channel
- * intermediate map never leaves LDS. */
+ * intermediate map never leaves LDS.  out_split / lds_out: optional split twin of `out` (see pf_conv_desc) written at the
+ * same channel offset (% 4 == 0); `out` may then be NULL. */
 int pf_conf_stem(const float* in, int ld_in, int off_in, const float* w1, const float* b1,
                  const float* w2, const float* b2, float* out, int ld_out, int off_out,
-                 int B, int H8, int W8, void* stream);
+                 void* out_split, int lds_out, int B, int H8, int W8, void* stream);
 
 /* ---- update blocks ------------------------------------------------------------------------ */
 
@@ -180,6 +183,20 @@ typedef struct pf_conv_desc {
      * fp64 sum / sum of squares of output channel c over one workgroup tile, nblk = tiles per image =
      * ceil(H8/TH)*ceil(W8/32), TH = 8 for tile 5 else 4.  Finish with pf_channel_stats_final.  NULL = none. */
     double* stats_out;
+    /* Pre-split activations (PF_PREC_BF16X3 only).  A "split twin" of a channel-last map holds, per pixel row and per
+     * 32-channel chunk, the 128 bytes {bf16 hi[32], bf16 lo[32]} with hi = bf16(x) (round to nearest even) and
+     * lo = bf16(x - hi): [rows][lds chunks][128 B] -- exactly what the kernels otherwise compute from fp32 while staging,
+     * so results are bit-identical.  Channels past the logical width of a row are zero.
+     *   in0_split / in1_split (with lds0 / lds1 chunks per row; off0 / off1 / c0 must be multiples of 32): when EVERY group of
+     *     a stride-1 3x3 / 1x5 / 5x1 launch without in_scale / stats_out provides them, the operands go global -> LDS by DMA
+     *     (pf_conv_dma_kernel: no VALU split, no ds_write) and in0 / in1 may be NULL; other launches ignore them and need in0.
+     *   out_split (lds_out chunks per row; off_out % 32 == 0): the epilogue also writes the split twin of `out` at the same
+     *     channel offset; `out` may then be NULL (twin only).  aux_split / lds_aux: the same for `aux_out` (GRU_ZR: r*h,
+     *     TANH_RELU: inp).  Any kernel form honours the output twins. */
+    const void* in0_split; int lds0;
+    const void* in1_split; int lds1;
+    void* out_split; int lds_out;
+    void* aux_split; int lds_aux;
 } pf_conv_desc;
 
 /* The tail of DCCL.__call__ fused with the first motion-encoder convolution (core/corr.py:138,
@@ -193,6 +210,8 @@ typedef struct pf_combine_conv_desc {
     const float* g_back;               /* [2][N] rotate-back grid */
     const void* weight; const float* bias;
     float* out; int ld_out; int off_out; int cout;
+    void* out_split; int lds_out;      /* optional split twin of `out` (see pf_conv_desc), same channel offset (% 32 == 0);
+                                        * `out` may then be NULL */
 } pf_combine_conv_desc;
 /* ngroups = 1 | 2: branch A and branch B of an iteration in one launch (grid.y = group). */
 int pf_dccl_combine_conv1x1(const pf_combine_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream);
@@ -208,7 +227,8 @@ int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8
 
 /* Host-only introspection, companion of pf_conv2d_tile for tiles 3 / 4: which wave organisation the launch takes --
  * 0: every wave stages and multiplies (pf_conv_halo_kernel), 1: four MFMA waves + four loader waves on the same tile
- * (pf_conv_ws_kernel<NT, KH, KW, 2>), 2: the same with a 256 px x 64 channel tile (pf_conv_ws_kernel<2, KH, KW, 1>). */
+ * (pf_conv_ws_kernel<NT, KH, KW, 2>), 2: the same with a 256 px x 64 channel tile (pf_conv_ws_kernel<2, KH, KW, 1>);
+ * 16 + 1 | 16 + 2: the launch has pre-split operands and takes the all-DMA kernel (pf_conv_dma_kernel) with that tile. */
 int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8);
 
 /* Tiny-Cin direct convolution (7x7 2->128, 3x3 8->32, 3x3 32->16; core/update.py:171-178,87).
@@ -225,6 +245,8 @@ typedef struct pf_direct_desc {
     const float* in;  int ld_in, off_in;
     const float* weight; const float* bias;
     float* out;       int ld_out, off_out;
+    void* out_split;  int lds_out;     /* optional split twin of `out` (see pf_conv_desc; 7x7 2 -> C stems only), same
+                                        * channel offset (% 8 == 0); `out` may then be NULL */
 } pf_direct_desc;
 int pf_conv2d_direct_group(const pf_direct_desc* descs, int n, int cin, int cout, int kh, int kw, int relu,
                            int B, int H8, int W8, void* stream);

@@ -51,19 +51,23 @@ class ConvDesc(C.Structure):
         ("precision", _i), ("stride", _i),
         ("in_scale", _fp), ("in_shift", _fp), ("in_relu", _i),
         ("stats_out", _fp),
+        ("in0_split", _fp), ("lds0", _i),
+        ("in1_split", _fp), ("lds1", _i),
+        ("out_split", _fp), ("lds_out", _i),
+        ("aux_split", _fp), ("lds_aux", _i),
     ]
 
 
 class CombineConvDesc(C.Structure):
     """Mirror of ``pf_combine_conv_desc`` (include/priorflow_hip.h)."""
     _fields_ = [("own", _fp), ("raw", _fp), ("ld", _i), ("g_back", _fp), ("weight", _fp), ("bias", _fp),
-                ("out", _fp), ("ld_out", _i), ("off_out", _i), ("cout", _i)]
+                ("out", _fp), ("ld_out", _i), ("off_out", _i), ("cout", _i), ("out_split", _fp), ("lds_out", _i)]
 
 
 class DirectDesc(C.Structure):
     """Mirror of ``pf_direct_desc`` (include/priorflow_hip.h)."""
     _fields_ = [("in_", _fp), ("ld_in", _i), ("off_in", _i), ("weight", _fp), ("bias", _fp),
-                ("out", _fp), ("ld_out", _i), ("off_out", _i)]
+                ("out", _fp), ("ld_out", _i), ("off_out", _i), ("out_split", _fp), ("lds_out", _i)]
 
 
 _SIGNATURES = {
@@ -79,8 +83,8 @@ _SIGNATURES = {
     "pf_dccl_lookup_pair": [C.c_void_p, _i, _i, _i, _i, _fp],
     "pf_dccl_combine": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_warp_gcorr": [_fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _fp],
-    "pf_conf_stem": [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
-    "pf_motion_prep": [_fp] * 9 + [_i, _i, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
+    "pf_conf_stem": [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _fp],
+    "pf_motion_prep": [_fp] * 9 + [_i, _i, _fp, _i, _i, _fp, _i, _fp, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_conv2d": [C.POINTER(ConvDesc), _i, _i, _i, _i, _fp],
     "pf_dccl_combine_conv1x1": [C.POINTER(CombineConvDesc), _i, _i, _i, _i, _fp],
     "pf_conv2d_tile": [C.POINTER(ConvDesc), _i, _i, _i, _i],
@@ -123,6 +127,15 @@ class PfError(RuntimeError):
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _twin(t: Optional[torch.Tensor]):
+    """(pointer, chunks per row) of a split twin [rows, chunks, 2, 32] bfloat16 (``engine.split_twin``), or (None, 0)."""
+    if t is None:
+        return None, 0
+    if t.dtype != torch.bfloat16 or t.dim() != 4 or tuple(t.shape[2:]) != (2, 32) or not t.is_contiguous():
+        raise PfError("a split twin is a contiguous bfloat16 tensor [rows, chunks, 2, 32]")
+    return C.c_void_p(t.data_ptr()), t.shape[1]
 
 
 class PfLib:
@@ -221,20 +234,26 @@ class PfLib:
             B, H, W, self._stream(flow)), "pf_flo_rotate")
         return out
 
-    def conf_stem(self, x, off_in, w1, b1, w2, b2, out, off_out, B, H8, W8):
-        """relu(conv3x3 32->16(relu(conv3x3 8->32(x)))) in one launch (core/update.py:193-194); w*: [9*Cin][Cout]."""
+    def conf_stem(self, x, off_in, w1, b1, w2, b2, out, off_out, B, H8, W8, out_split=None):
+        """relu(conv3x3 32->16(relu(conv3x3 8->32(x)))) in one launch (core/update.py:193-194); w*: [9*Cin][Cout].
+        out_split: optional split twin of `out` written at the same channel offset (`out` may then be None)."""
         self._chk(x, w1, b1, w2, b2, out)
+        sp, lds = _twin(out_split)
         self._rc(self._dll.pf_conf_stem(_ptr(x), x.shape[-1], off_in, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
-                                        _ptr(out), out.shape[-1], off_out, B, H8, W8, self._stream(x)), "pf_conf_stem")
+                                        _ptr(out), 0 if out is None else out.shape[-1], off_out, sp, lds,
+                                        B, H8, W8, self._stream(x)), "pf_conf_stem")
 
-    def motion_prep(self, c1a, c1b, g_w2c, g_c2w, f1a, f2a, flow4_a, flow2_b, conf, xa=None, xa_off=0, xb=None, xb_off=0):
-        """One launch for flow_prep x2 + flo_rotate + warp_gcorr x2 (core/prior_raft.py:171-182), bit-identical to them."""
+    def motion_prep(self, c1a, c1b, g_w2c, g_c2w, f1a, f2a, flow4_a, flow2_b, conf, xa=None, xa_off=0, xb=None, xb_off=0,
+                    xa_split=None, xb_split=None):
+        """One launch for flow_prep x2 + flo_rotate + warp_gcorr x2 (core/prior_raft.py:171-182), bit-identical to them.
+        xa_split / xb_split: optional split twins of the GRU input buffers (tails written at xa_off / xb_off)."""
         self._chk(c1a, c1b, g_w2c, g_c2w, f1a, f2a, flow4_a, flow2_b, conf, xa, xb)
         B, _, H, W = c1a.shape
+        (sa, la), (sb, lb) = _twin(xa_split), _twin(xb_split)
         self._rc(self._dll.pf_motion_prep(
             _ptr(c1a), _ptr(c1b), _ptr(g_w2c), _ptr(g_c2w), _ptr(f1a), _ptr(f2a), _ptr(flow4_a), _ptr(flow2_b),
             _ptr(xa), 0 if xa is None else xa.shape[-1], xa_off, _ptr(xb), 0 if xb is None else xb.shape[-1], xb_off,
-            _ptr(conf), conf.shape[-1], B, H, W, f1a.shape[-1], self._stream(c1a)), "pf_motion_prep")
+            sa, la, sb, lb, _ptr(conf), conf.shape[-1], B, H, W, f1a.shape[-1], self._stream(c1a)), "pf_motion_prep")
 
     # ---- correlation -------------------------------------------------------------------------
     def corr_pyramid(self, f1, f2, levels, B, H8, W8):
@@ -297,18 +316,23 @@ class PfLib:
                  "pf_dccl_combine")
 
     def dccl_combine_conv1x1(self, items, B, H8, W8):
-        """items: 1 or 2 tuples (own, raw, g_back, conv, out, off_out) with `conv` a packed bf16x3 1x1 324->256
-        engine.Conv: out[.., off_out:off_out+256] = relu(conv(own + rotate_back(raw))) without materialising the sum."""
+        """items: 1 or 2 tuples (own, raw, g_back, conv, out, off_out[, out_split]) with `conv` a packed bf16x3 1x1 324->256
+        engine.Conv: out[.., off_out:off_out+256] = relu(conv(own + rotate_back(raw))) without materialising the sum.
+        out_split: optional split twin of `out` (`out` may then be None)."""
         arr = (CombineConvDesc * len(items))()
         keep = []
-        for d, (own, raw, g_back, conv, out, off_out) in zip(arr, items):
+        for d, item in zip(arr, items):
+            own, raw, g_back, conv, out, off_out = item[:6]
+            out_split = item[6] if len(item) > 6 else None
+            d.out_split, d.lds_out = _twin(out_split)
             self._chk(own, raw, g_back, conv.b, out)
             if conv.precision != PREC_BF16X3 or (conv.kh, conv.kw, conv.cin, conv.cout) != (1, 1, 324, 256):
                 raise PfError("dccl_combine_conv1x1 needs the bf16x3 packing of a 1x1 324(352)->256 convolution")
             d.own, d.raw, d.ld, d.g_back = own.data_ptr(), raw.data_ptr(), own.shape[-1], g_back.data_ptr()
             d.weight, d.bias = conv.w.data_ptr(), conv.b.data_ptr()
-            d.out, d.ld_out, d.off_out, d.cout = out.data_ptr(), out.shape[-1], off_out, conv.cout
-            keep.append((own, raw, g_back, conv, out))
+            d.out = out.data_ptr() if out is not None else None
+            d.ld_out, d.off_out, d.cout = (out.shape[-1] if out is not None else 0), off_out, conv.cout
+            keep.append((own, raw, g_back, conv, out, out_split))
         self._rc(self._dll.pf_dccl_combine_conv1x1(arr, len(items), B, H8, W8, self._stream(items[0][0])),
                  "pf_dccl_combine_conv1x1")
 
@@ -345,13 +369,16 @@ class PfLib:
                                             B, H8, W8, self._stream(x)), "pf_conv2d_direct")
 
     def conv2d_direct_group(self, problems, cin, cout, kh, kw, relu, B, H8, W8):
-        """problems: 1..4 tuples (x, off_in, weight, bias, out, off_out) of one shape -> one launch."""
+        """problems: 1..4 tuples (x, off_in, weight, bias, out, off_out[, out_split]) of one shape -> one launch.
+        out_split: optional split twin of `out` (7x7 2 -> C stems; `out` may then be None)."""
         arr = (DirectDesc * len(problems))()
-        for d, (x, off_in, weight, bias, out, off_out) in zip(arr, problems):
+        for d, item in zip(arr, problems):
+            x, off_in, weight, bias, out, off_out = item[:6]
             self._chk(x, weight, bias, out)
             d.in_, d.ld_in, d.off_in = _ptr(x), x.shape[-1], off_in
             d.weight, d.bias = _ptr(weight), _ptr(bias)
-            d.out, d.ld_out, d.off_out = _ptr(out), out.shape[-1], off_out
+            d.out, d.ld_out, d.off_out = _ptr(out), (out.shape[-1] if out is not None else 0), off_out
+            d.out_split, d.lds_out = _twin(item[6] if len(item) > 6 else None)
         self._rc(self._dll.pf_conv2d_direct_group(arr, len(problems), cin, cout, kh, kw, int(relu), B, H8, W8,
                                                   self._stream(problems[0][0])), "pf_conv2d_direct_group")
 

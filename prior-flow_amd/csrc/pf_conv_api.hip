@@ -1,0 +1,143 @@
+// pf_conv2d: argument validation, tile choice and dispatch (host side).  The kernels live in pf_conv_mfma.hip (generic,
+// halo and role-specialised kernels on fp32 activations) and pf_conv_dma.hip (all-DMA kernel on pre-split activations).
+#include <stdlib.h>
+#include "pf_conv_priv.h"
+
+using namespace pfconv;
+
+// validation + geometry shared by pf_conv2d and pf_conv2d_tile
+// PRIORFLOW_CONV_GENERIC=1 forces the generic kernel (A/B comparisons, debugging)
+static bool pf_conv_force_generic() {
+    static const bool v = [] { const char* e = getenv("PRIORFLOW_CONV_GENERIC"); return e && e[0] == '1'; }();
+    return v;
+}
+
+static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8,
+                        ConvGroups& grp, ConvGeom& g, int& max_cout) {   // H8, W8: OUTPUT map size
+    if (!descs || ngroups < 1 || ngroups > MAX_GROUPS) return PF_ERR_BAD_ARG;
+    if (B <= 0 || H8 <= 0 || W8 <= 0) return PF_ERR_BAD_SHAPE;
+    max_cout = 0;
+    const pf_conv_desc& f = descs[0];
+    for (int i = 0; i < ngroups; ++i) {
+        const pf_conv_desc& d = descs[i];
+        if ((!d.in0 && !d.in0_split) || !d.weight || !d.bias || (!d.out && !d.out_split)) return PF_ERR_BAD_ARG;
+        if (d.c0 <= 0 || d.c1 < 0 || (d.c1 > 0 && !d.in1 && !d.in1_split)) return PF_ERR_BAD_ARG;
+        // split twins (include/priorflow_hip.h): bf16x3 arithmetic, chunk-aligned slices that fit their rows
+        if ((d.in0_split || d.in1_split || d.out_split || d.aux_split) && d.precision != PF_PREC_BF16X3) return PF_ERR_BAD_ARG;
+        if (d.in0_split && ((d.off0 & 31) || d.lds0 * 32 < d.off0 + d.c0)) return PF_ERR_BAD_SHAPE;
+        if (d.in1_split && d.c1 > 0 && ((d.off1 & 31) || (d.c0 & 31) || d.lds1 * 32 < d.off1 + d.c1)) return PF_ERR_BAD_SHAPE;
+        if (d.out_split && ((d.off_out & 31) || d.lds_out <= 0)) return PF_ERR_BAD_SHAPE;
+        if (d.aux_split && d.lds_aux * 32 < 128) return PF_ERR_BAD_SHAPE;
+        if ((d.in0_split != nullptr) != (f.in0_split != nullptr) || (d.c1 > 0 && (d.in1_split != nullptr) != (d.in0_split != nullptr)))
+            return PF_ERR_BAD_ARG;              // every group and both segments agree on the operand form
+        // same geometry in every group: one kernel, one K loop
+        if (d.kh != f.kh || d.kw != f.kw || d.c0 + d.c1 != f.c0 + f.c1) return PF_ERR_BAD_SHAPE;
+        // odd k: window [-k/2, k/2]; even k: [-k/2, k/2 - 1] (the space-to-depth form of the 7x7/2 stem)
+        if (d.kh < 1 || d.kw < 1 || d.kh > 7 || d.kw > 7 || d.cout <= 0) return PF_ERR_BAD_SHAPE;
+        // 16-byte loads: every channel offset / stride must be a multiple of 4 floats
+        if ((d.off0 | d.c0 | d.c1) & 3) return PF_ERR_BAD_SHAPE;
+        if (d.in0 && (d.ld0 & 3)) return PF_ERR_BAD_SHAPE;
+        if (d.c1 > 0 && ((d.off1 & 3) || (d.in1 && (d.ld1 & 3)) || (d.c0 % KC) != 0)) return PF_ERR_BAD_SHAPE;
+        if (d.off0 < 0 || (d.in0 && d.off0 + d.c0 > d.ld0) || (d.c1 > 0 && (d.off1 < 0 || (d.in1 && d.off1 + d.c1 > d.ld1))))
+            return PF_ERR_BAD_ARG;
+        if (d.epilogue < PF_EPI_LINEAR || d.epilogue > PF_EPI_TANH_RELU) return PF_ERR_BAD_ARG;
+        if (d.stride != f.stride || (d.stride != 1 && d.stride != 2)) return PF_ERR_BAD_SHAPE;
+        if ((d.in_scale == nullptr) != (d.in_shift == nullptr)) return PF_ERR_BAD_ARG;
+        if (d.epilogue == PF_EPI_TANH_RELU && (d.cout != 256 || (!d.aux_out && !d.aux_split) || (d.aux_out && d.ld_aux < 128))) return PF_ERR_BAD_ARG;
+        if (d.precision != f.precision || (d.precision != PF_PREC_F32 && d.precision != PF_PREC_BF16X3))
+            return PF_ERR_BAD_ARG;
+        const int out_w = (d.epilogue == PF_EPI_GRU_ZR || d.epilogue == PF_EPI_TANH_RELU) ? 128 : d.cout;
+        if (d.off_out < 0 || (d.out && d.off_out + out_w > d.ld_out) || (d.out_split && d.off_out + out_w > d.lds_out * 32))
+            return PF_ERR_BAD_ARG;
+        if (d.epilogue == PF_EPI_GRU_ZR && (d.cout != 256 || !d.h || (!d.aux_out && !d.aux_split) || (d.aux_out && d.ld_aux < 128) || d.ld_h < 128))
+            return PF_ERR_BAD_ARG;
+        if (d.epilogue == PF_EPI_GRU_Q && (d.cout != 128 || !d.h || !d.z || d.ld_z < 128 || d.ld_h < 128))
+            return PF_ERR_BAD_ARG;
+        grp.d[i] = d;
+        if (d.cout > max_cout) max_cout = d.cout;
+    }
+    for (int i = ngroups; i < MAX_GROUPS; ++i) grp.d[i] = descs[0];
+    g.H = H8; g.W = W8; g.N = H8 * W8; g.M = B * H8 * W8;
+    g.kh = f.kh; g.kw = f.kw; g.taps = f.kh * f.kw;
+    g.cin_pad = (f.c0 + f.c1 + KC - 1) / KC * KC;
+    g.nchunks = g.cin_pad / KC;
+    g.stride = f.stride; g.Hin = H8 * f.stride; g.Win = W8 * f.stride; g.Nin = g.Hin * g.Win;
+    return PF_OK;
+}
+
+// Tile choice: the packed weights are zero-padded to a multiple of 128 output channels, so any
+// BN in {32,64,128} is legal.  Small problems (one 512x1024 pair = 8192 pixels per branch) need
+// the smaller tile to put >= 1 workgroup on each of the 256 CUs.
+// 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
+// 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3; any map size: edge tiles may be partial)
+// 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, enough pixels to fill the chip)
+static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
+    const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1) ||
+                            (g.kh == 4 && g.kw == 4) || (g.kh == 1 && g.kw == 1);
+    if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1 && !pf_conv_force_generic()) {
+        const long B = g.M / g.N;
+        const long tiles4 = B * ((g.H + 3) / 4) * ((g.W + 31) / 32), tiles8 = B * ((g.H + 7) / 8) * ((g.W + 31) / 32);
+        const long wgs128 = tiles4 * ngroups * ((max_cout + 127) / 128);
+        static const int force8 = [] { const char* e = getenv("PRIORFLOW_CONV_TH8"); return e ? atoi(e) : 0; }();   // A/B knob
+        if (force8 && g.kh == g.kw && g.kh > 1) return 5;
+        if (max_cout <= 64 && g.kh == g.kw && g.kh > 1 && tiles8 * ngroups >= 512) return 5;
+        return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
+    }
+    const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;
+    if (max_cout <= 32) return 0;
+    if (max_cout <= 64 || m_tiles64 * ((max_cout + 127) / 128) < 512) return 1;
+    return 2;
+}
+
+// Pre-split operands (pf_conv_desc.in0_split): which tile the all-DMA kernel takes -- 0: not applicable (fp32 operands,
+// a shape / option it does not implement), else the pf_conv2d_roles code (1: 128-px tile, 2: 256 px x 64 channels).
+// PRIORFLOW_CONV_DMA=0 (A/B knob) sends every launch to the register-staged kernels, which need the fp32 operands.
+static int conv_dma_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, int tile_id) {
+    static const bool on = [] { const char* e = getenv("PRIORFLOW_CONV_DMA"); return !(e && e[0] == '0'); }();
+    if (!on || !grp.d[0].in0_split || (tile_id != 3 && tile_id != 4)) return 0;
+    const bool shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1);
+    if (!shape || g.stride != 1) return 0;
+    for (int i = 0; i < ngroups; ++i)
+        if (grp.d[i].stats_out != nullptr || grp.d[i].in_scale != nullptr) return 0;
+    const long wgs256 = (long)(g.M / g.N) * ((g.H + 7) / 8) * ((g.W + 31) / 32) * ngroups * ((max_cout + 63) / 64);
+    return (g.kh == 3 && max_cout > 64 && wgs256 >= 256) ? 2 : 1;
+}
+
+
+extern "C" int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
+    ConvGroups grp; ConvGeom g; int max_cout;
+    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
+    return rc != PF_OK ? rc : conv_tile(g, ngroups, max_cout, descs[0].precision);
+}
+
+extern "C" int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
+    ConvGroups grp; ConvGeom g; int max_cout;
+    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
+    if (rc != PF_OK) return rc;
+    const int tile = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    if (const int dma = conv_dma_choice(grp, ngroups, g, max_cout, tile)) return 16 + dma;
+    return (tile == 3 || tile == 4) ? pf_conv_ws_choice(grp, ngroups, g, max_cout) : 0;
+}
+
+extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream) {
+    ConvGroups grp; ConvGeom g; int max_cout;
+    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
+    if (rc != PF_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const bool split = descs[0].precision == PF_PREC_BF16X3;
+    const int tile_id = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    for (int i = 0; i < ngroups; ++i) {     // the input affine and the fused statistics are implemented by the halo kernel only
+        if (descs[i].in_scale && tile_id < 3) return PF_ERR_BAD_SHAPE;
+        if (descs[i].stats_out && (tile_id < 3 || descs[i].epilogue != PF_EPI_LINEAR)) return PF_ERR_BAD_SHAPE;
+    }
+    if (const int roles = conv_dma_choice(grp, ngroups, g, max_cout, tile_id))      // pre-split operands: the all-DMA kernel
+        return pf_conv_dma_launch(grp, ngroups, g, max_cout, tile_id == 4 ? 2 : 1, roles, s);
+    for (int i = 0; i < ngroups; ++i)
+        if (!descs[i].in0 || (descs[i].c1 > 0 && !descs[i].in1)) return PF_ERR_BAD_ARG;   // fp32 operands needed from here on
+    switch (tile_id) {
+        case 0: case 1: case 2: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
+        case 3: return pf_conv_part1_launch(grp, ngroups, g, max_cout, s);
+        case 4: return pf_conv_part2_launch(grp, ngroups, g, max_cout, s);
+        default: return pf_conv_part3_launch(grp, ngroups, g, max_cout, s);
+    }
+}

@@ -28,123 +28,10 @@
 // Software pipeline: global loads of K-step s+1 are issued before the MFMAs of step s and
 // written to the other LDS buffer at the top of the next iteration; one __syncthreads per K-step.
 #include <stdlib.h>
-#include <type_traits>
-#include "pf_common.h"
-#include "../../include/priorflow_hip.h"
+#include "pf_conv_priv.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain 16-byte loads, no struct memcpy
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int KC = 32;        // channels per K-step
-constexpr int LDS_LD = 36;    // padded row stride (floats)
-constexpr int MAX_GROUPS = 4;
-
-struct ConvGroups { pf_conv_desc d[MAX_GROUPS]; };
-
-struct ConvGeom { int M, H, W, N; int taps, nchunks, cin_pad, kh, kw; int stride, Hin, Win, Nin;
-                  int ntn, ntiles, xcd_map; };   // halo kernel: output-channel tiles, pixel tiles (all images), XCD-aware 1-D grid
-
-// Fused epilogue of a wave's NT 32x32 accumulators.  acc[t][r] is output channel jb + 32 t + li
-// of pixel p0 + (r&3) + 8 (r>>2)  (p0 already holds the lane's +4*(lane>>5) row offset).
-// The first version ran a generic per-element routine (epilogue kind re-tested, 64-bit address
-// products and, for the GRU kinds, a dependent load -> compute -> store chain per element because
-// output and state pointers may alias): 8 360 instructions and 9-15 us of a 65-70 us launch.
-// Here the kind is tested once per tile, a lane keeps one base pointer per array and adds
-// row * ld offsets, the channel-half decisions of the split epilogues are wave-uniform (jb is
-// scalar), and the GRU operands of a tile are gathered before anything is stored.
-// Gate nonlinearities of the fused epilogues on the hardware transcendental pipe: v_exp_f32 + v_rcp_f32 (1 ulp each)
-// instead of ocml's expf / tanhf and an IEEE division -- ~5 instructions per element instead of ~25; absolute error
-// < 3e-7 on outputs in (-1, 1), two orders below the bf16x3 GEMM's own rounding.
-// (PF_PREC_F32, the exact validation mode, keeps expf / tanhf and the IEEE division.)
-template <bool FAST>
-__device__ __forceinline__ float pf_sigmoid(float x) {
-    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
-    else return 1.f / (1.f + expf(-x));
-}
-template <bool FAST>
-__device__ __forceinline__ float pf_tanh(float x) {             // fast form: 1 - 2 / (1 + e^(2x)); saturates cleanly at +-1
-    if constexpr (FAST) return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
-    else return tanhf(x);
-}
-
-template <int NT, bool CHECK, bool FAST>
-__device__ __forceinline__ void tile_epilogue_t(const pf_conv_desc& d, const f32x16 (&acc)[NT], int jb, int li,
-                                                long p0, long plimit) {
-    const int epi = d.epilogue;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int jt = jb + 32 * t;                 // wave-uniform
-        const int j = jt + li;
-        if (j >= d.cout) continue;
-        const float bias = d.bias[j];
-        auto roff = [](int r) { return (r & 3) + 8 * (r >> 2); };
-        auto live = [&](int r) { return !CHECK || p0 + roff(r) < plimit; };
-        if (epi == PF_EPI_LINEAR) {
-            float* o = d.out + d.off_out + p0 * d.ld_out + j;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (live(r)) o[roff(r) * d.ld_out] = (acc[t][r] + bias) * d.scale;
-        } else if (epi == PF_EPI_RELU) {
-            float* o = d.out + d.off_out + p0 * d.ld_out + j;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (live(r)) o[roff(r) * d.ld_out] = fmaxf(acc[t][r] + bias, 0.f);
-        } else if (epi == PF_EPI_GRU_ZR) {
-            if (jt < 128) {                                                       // z
-                float* o = d.out + d.off_out + p0 * d.ld_out + j;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (live(r)) o[roff(r) * d.ld_out] = pf_sigmoid<FAST>(acc[t][r] + bias);
-            } else {                                                              // r * h
-                const float* hp = d.h + p0 * d.ld_h + (j - 128);
-                float* o = d.aux_out + p0 * d.ld_aux + (j - 128);
-                float hv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hv[r] = live(r) ? hp[roff(r) * d.ld_h] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (live(r)) o[roff(r) * d.ld_aux] = pf_sigmoid<FAST>(acc[t][r] + bias) * hv[r];
-            }
-        } else if (epi == PF_EPI_TANH_RELU) {
-            if (jt < 128) {                                                       // net
-                float* o = d.out + d.off_out + p0 * d.ld_out + j;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (live(r)) o[roff(r) * d.ld_out] = pf_tanh<FAST>(acc[t][r] + bias);
-            } else {                                                              // inp
-                float* o = d.aux_out + p0 * d.ld_aux + (j - 128);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (live(r)) o[roff(r) * d.ld_aux] = fmaxf(acc[t][r] + bias, 0.f);
-            }
-        } else {   // PF_EPI_GRU_Q:  h' = (1 - z) h + z tanh(v)
-            const float* zp = d.z + p0 * d.ld_z + j;
-            const float* hp = d.h + p0 * d.ld_h + j;
-            float* o = d.out + d.off_out + p0 * d.ld_out + j;
-            float zv[16], hv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                zv[r] = live(r) ? zp[roff(r) * d.ld_z] : 0.f;
-                hv[r] = live(r) ? hp[roff(r) * d.ld_h] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (live(r)) o[roff(r) * d.ld_out] = (1.f - zv[r]) * hv[r] + zv[r] * pf_tanh<FAST>(acc[t][r] + bias);
-        }
-    }
-}
-
-template <int NT, bool CHECK>
-__device__ __forceinline__ void tile_epilogue(const pf_conv_desc& d, const f32x16 (&acc)[NT], int jb, int li,
-                                              long p0, long plimit) {
-    const bool gated = d.epilogue == PF_EPI_GRU_ZR || d.epilogue == PF_EPI_GRU_Q || d.epilogue == PF_EPI_TANH_RELU;
-    if (gated && d.precision == PF_PREC_F32) tile_epilogue_t<NT, CHECK, false>(d, acc, jb, li, p0, plimit);
-    else tile_epilogue_t<NT, CHECK, true>(d, acc, jb, li, p0, plimit);
-}
+using namespace pfconv;
 
 template <int WM, int WN, int NT, bool SPLIT>
 __global__ void __launch_bounds__(256, 2)   // 2 waves/SIMD -> 256-register budget, no spills
@@ -349,14 +236,6 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
 // even with barriers, LDS writes and global loads removed).  One barrier per K-step.
 // Wave w: tile row w>>1 (32 pixels = one MFMA M-block), output channels (w&1)*32*NT + [0, 32*NT).
 // ----------------------------------------------------------------------------------------------
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 #ifdef PF_STAMPS      // diagnostic build only (profiles/stamp_conv.py): per-wave s_memtime stamps inside the K-step
 #define PF_STAMP_OFF (140 * 1024 / 4)      // floats: the stamp area sits above the operand buffers of the TH = 4 instantiations
 __device__ unsigned long long pf_stamp_buf[8 * 40 * 8];
@@ -935,7 +814,7 @@ int launch_conv_ws_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int 
 // Which form of the halo kernel a TH = 4 launch takes: 0 the symmetric pf_conv_halo_kernel, 1 pf_conv_ws_kernel with the
 // call's own 128-px tile (WN = 2), 2 pf_conv_ws_kernel with the 256 px x 64 channel tile (WN = 1; only where that still
 // gives every CU a workgroup).  PRIORFLOW_CONV_WS (A/B knob): 0 / 1 cap the choice, default 2.
-static int conv_ws_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout) {
+int conv_ws_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout) {
     static const int ws = [] { const char* e = getenv("PRIORFLOW_CONV_WS"); return e ? atoi(e) : 2; }();
     if (ws <= 0) return 0;
     const bool shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1);
@@ -960,9 +839,7 @@ int launch_conv_halo(const ConvGroups& grp, int ngroups, const ConvGeom& g, int 
     if constexpr (TH == 4) {                // role-specialised waves (pf_conv_ws_kernel); PRIORFLOW_CONV_WS=0: symmetric kernel
         const int ws = conv_ws_choice(grp, ngroups, g, max_cout);
         if (ws == 2) {
-            if (g.kh == 3 && g.kw == 3) return launch_conv_ws_t<2, 3, 3, 1>(grp, ngroups, g, max_cout, stream);
-            if (g.kh == 1 && g.kw == 5) return launch_conv_ws_t<2, 1, 5, 1>(grp, ngroups, g, max_cout, stream);
-            if (g.kh == 5 && g.kw == 1) return launch_conv_ws_t<2, 5, 1, 1>(grp, ngroups, g, max_cout, stream);
+            if (g.kh == 3 && g.kw == 3) return pf_conv_ws256_launch(grp, ngroups, g, max_cout, stream);   // (3x3 only: conv_ws_choice)
         }
         if (ws == 1) {
             if (g.kh == 3 && g.kw == 3) return launch_conv_ws_t<NT, 3, 3, 2>(grp, ngroups, g, max_cout, stream);
@@ -1320,118 +1197,60 @@ int launch_conv_ws_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int 
 
 }  // namespace
 
-// validation + geometry shared by pf_conv2d and pf_conv2d_tile
-// PRIORFLOW_CONV_GENERIC=1 forces the generic kernel (A/B comparisons, debugging)
-static bool pf_conv_force_generic() {
-    static const bool v = [] { const char* e = getenv("PRIORFLOW_CONV_GENERIC"); return e && e[0] == '1'; }();
-    return v;
-}
+// The product build compiles this file as four translation units in parallel (-DPF_CONV_PART=0..3, __graft_entry__.py):
+// each instantiates only the kernels its launcher names.  Without the macro (diagnostic builds: profiles/stamp_conv.py,
+// profiles/ablate_conv.sh) everything is one unit.
+#ifndef PF_CONV_PART
+#define PF_CONV_PART (-1)
+#endif
+#define PF_PART(k) (PF_CONV_PART == -1 || PF_CONV_PART == (k))
 
-static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8,
-                        ConvGroups& grp, ConvGeom& g, int& max_cout) {   // H8, W8: OUTPUT map size
-    if (!descs || ngroups < 1 || ngroups > MAX_GROUPS) return PF_ERR_BAD_ARG;
-    if (B <= 0 || H8 <= 0 || W8 <= 0) return PF_ERR_BAD_SHAPE;
-    max_cout = 0;
-    const pf_conv_desc& f = descs[0];
-    for (int i = 0; i < ngroups; ++i) {
-        const pf_conv_desc& d = descs[i];
-        if (!d.in0 || !d.weight || !d.bias || !d.out) return PF_ERR_BAD_ARG;
-        if (d.c0 <= 0 || d.c1 < 0 || (d.c1 > 0 && !d.in1)) return PF_ERR_BAD_ARG;
-        // same geometry in every group: one kernel, one K loop
-        if (d.kh != f.kh || d.kw != f.kw || d.c0 + d.c1 != f.c0 + f.c1) return PF_ERR_BAD_SHAPE;
-        // odd k: window [-k/2, k/2]; even k: [-k/2, k/2 - 1] (the space-to-depth form of the 7x7/2 stem)
-        if (d.kh < 1 || d.kw < 1 || d.kh > 7 || d.kw > 7 || d.cout <= 0) return PF_ERR_BAD_SHAPE;
-        // 16-byte loads: every channel offset / stride must be a multiple of 4 floats
-        if ((d.ld0 | d.off0 | d.c0 | d.c1) & 3) return PF_ERR_BAD_SHAPE;
-        if (d.c1 > 0 && (((d.ld1 | d.off1) & 3) || (d.c0 % KC) != 0)) return PF_ERR_BAD_SHAPE;
-        if (d.off0 < 0 || d.off0 + d.c0 > d.ld0 || (d.c1 > 0 && (d.off1 < 0 || d.off1 + d.c1 > d.ld1)))
-            return PF_ERR_BAD_ARG;
-        if (d.epilogue < PF_EPI_LINEAR || d.epilogue > PF_EPI_TANH_RELU) return PF_ERR_BAD_ARG;
-        if (d.stride != f.stride || (d.stride != 1 && d.stride != 2)) return PF_ERR_BAD_SHAPE;
-        if ((d.in_scale == nullptr) != (d.in_shift == nullptr)) return PF_ERR_BAD_ARG;
-        if (d.epilogue == PF_EPI_TANH_RELU && (d.cout != 256 || !d.aux_out || d.ld_aux < 128)) return PF_ERR_BAD_ARG;
-        if (d.precision != f.precision || (d.precision != PF_PREC_F32 && d.precision != PF_PREC_BF16X3))
-            return PF_ERR_BAD_ARG;
-        if (d.off_out < 0 ||
-            d.off_out + ((d.epilogue == PF_EPI_GRU_ZR || d.epilogue == PF_EPI_TANH_RELU) ? 128 : d.cout) > d.ld_out)
-            return PF_ERR_BAD_ARG;
-        if (d.epilogue == PF_EPI_GRU_ZR && (d.cout != 256 || !d.h || !d.aux_out || d.ld_aux < 128 || d.ld_h < 128))
-            return PF_ERR_BAD_ARG;
-        if (d.epilogue == PF_EPI_GRU_Q && (d.cout != 128 || !d.h || !d.z || d.ld_z < 128 || d.ld_h < 128))
-            return PF_ERR_BAD_ARG;
-        grp.d[i] = d;
-        if (d.cout > max_cout) max_cout = d.cout;
+#if PF_PART(0)      // generic kernel (stride 2, exact fp32, small problems); the wave-organisation rule
+int pf_conv_ws_choice(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout) {
+    return conv_ws_choice(grp, ngroups, g, max_cout);
+}
+int pf_conv_part0_launch(int tile_id, const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout,
+                         bool split, hipStream_t s) {
+    switch (tile_id) {
+        case 0: return launch_conv<4, 1, 1>(grp, ngroups, g, max_cout, split, s);
+        case 1: return launch_conv<2, 2, 1>(grp, ngroups, g, max_cout, split, s);
+        default: return launch_conv<2, 2, 2>(grp, ngroups, g, max_cout, split, s);
     }
-    for (int i = ngroups; i < MAX_GROUPS; ++i) grp.d[i] = descs[0];
-    g.H = H8; g.W = W8; g.N = H8 * W8; g.M = B * H8 * W8;
-    g.kh = f.kh; g.kw = f.kw; g.taps = f.kh * f.kw;
-    g.cin_pad = (f.c0 + f.c1 + KC - 1) / KC * KC;
-    g.nchunks = g.cin_pad / KC;
-    g.stride = f.stride; g.Hin = H8 * f.stride; g.Win = W8 * f.stride; g.Nin = g.Hin * g.Win;
-    return PF_OK;
 }
+#endif
+#if PF_PART(1)      // tile 3: halo / role-specialised kernels, 128 px x 64 channels
+int pf_conv_part1_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t s) {
+    return launch_conv_halo<1, 4>(grp, ngroups, g, max_cout, s);
+}
+#endif
+#if PF_PART(2)      // tile 4: 128 px x 128 channels
+int pf_conv_part2_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t s) {
+    return launch_conv_halo<2, 4>(grp, ngroups, g, max_cout, s);
+}
+#endif
+#if PF_PART(3)      // tile 5: 8-row halo kernel; the role-specialised 256 px x 64 channel tile of the 3x3 convs
+int pf_conv_part3_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t s) {
+    return launch_conv_halo<2, 8>(grp, ngroups, g, max_cout, s);
+}
+int pf_conv_ws256_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t s) {
+    return launch_conv_ws_t<2, 3, 3, 1>(grp, ngroups, g, max_cout, s);
+}
+#endif
 
-// Tile choice: the packed weights are zero-padded to a multiple of 128 output channels, so any
-// BN in {32,64,128} is legal.  Small problems (one 512x1024 pair = 8192 pixels per branch) need
-// the smaller tile to put >= 1 workgroup on each of the 256 CUs.
-// 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
-// 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3; any map size: edge tiles may be partial)
-// 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, enough pixels to fill the chip)
-static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
-    const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1) ||
-                            (g.kh == 4 && g.kw == 4) || (g.kh == 1 && g.kw == 1);
-    if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1 && !pf_conv_force_generic()) {
-        const long B = g.M / g.N;
-        const long tiles4 = B * ((g.H + 3) / 4) * ((g.W + 31) / 32), tiles8 = B * ((g.H + 7) / 8) * ((g.W + 31) / 32);
-        const long wgs128 = tiles4 * ngroups * ((max_cout + 127) / 128);
-        static const int force8 = [] { const char* e = getenv("PRIORFLOW_CONV_TH8"); return e ? atoi(e) : 0; }();   // A/B knob
-        if (force8 && g.kh == g.kw && g.kh > 1) return 5;
-        if (max_cout <= 64 && g.kh == g.kw && g.kh > 1 && tiles8 * ngroups >= 512) return 5;
-        return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
+#if PF_CONV_PART == -1
+int pf_conv_kernels_launch(int tile_id, const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout,
+                           bool split, hipStream_t s) {
+    switch (tile_id) {
+        case 0: case 1: case 2: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
+        case 3: return pf_conv_part1_launch(grp, ngroups, g, max_cout, s);
+        case 4: return pf_conv_part2_launch(grp, ngroups, g, max_cout, s);
+        default: return pf_conv_part3_launch(grp, ngroups, g, max_cout, s);
     }
-    const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;
-    if (max_cout <= 32) return 0;
-    if (max_cout <= 64 || m_tiles64 * ((max_cout + 127) / 128) < 512) return 1;
-    return 2;
 }
+#endif
 
-#ifdef PF_STAMPS
+#if defined(PF_STAMPS) && PF_CONV_PART == -1
 extern "C" int pf_conv_read_stamps(unsigned long long* out) {   // [8 waves][40 steps][before barrier, after barrier, 4 mid-step stamps, 2 ring-piece stamps]
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_stamp_buf), sizeof(unsigned long long) * 8 * 40 * 8);
 }
 #endif
-
-extern "C" int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
-    ConvGroups grp; ConvGeom g; int max_cout;
-    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
-    return rc != PF_OK ? rc : conv_tile(g, ngroups, max_cout, descs[0].precision);
-}
-
-extern "C" int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
-    ConvGroups grp; ConvGeom g; int max_cout;
-    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
-    if (rc != PF_OK) return rc;
-    const int tile = conv_tile(g, ngroups, max_cout, descs[0].precision);
-    return (tile == 3 || tile == 4) ? conv_ws_choice(grp, ngroups, g, max_cout) : 0;
-}
-
-extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream) {
-    ConvGroups grp; ConvGeom g; int max_cout;
-    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
-    if (rc != PF_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    const bool split = descs[0].precision == PF_PREC_BF16X3;
-    const int tile_id = conv_tile(g, ngroups, max_cout, descs[0].precision);
-    for (int i = 0; i < ngroups; ++i) {     // the input affine and the fused statistics are implemented by the halo kernel only
-        if (descs[i].in_scale && tile_id < 3) return PF_ERR_BAD_SHAPE;
-        if (descs[i].stats_out && (tile_id < 3 || descs[i].epilogue != PF_EPI_LINEAR)) return PF_ERR_BAD_SHAPE;
-    }
-    switch (tile_id) {
-        case 0: return launch_conv<4, 1, 1>(grp, ngroups, g, max_cout, split, s);
-        case 1: return launch_conv<2, 2, 1>(grp, ngroups, g, max_cout, split, s);
-        case 2: return launch_conv<2, 2, 2>(grp, ngroups, g, max_cout, split, s);
-        case 3: return launch_conv_halo<1, 4>(grp, ngroups, g, max_cout, s);
-        case 4: return launch_conv_halo<2, 4>(grp, ngroups, g, max_cout, s);
-        default: return launch_conv_halo<2, 8>(grp, ngroups, g, max_cout, s);
-    }
-}

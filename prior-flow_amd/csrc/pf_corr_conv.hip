@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "pf_common.h"
 #include "pf_elem.h"
+#include "pf_split.h"
 #include "../../include/priorflow_hip.h"
 
 namespace {
@@ -198,11 +199,22 @@ pf_combine_conv_kernel(const CombGroups groups, const int B, const int H, const 
         const float bias = d.bias[ch];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            float* o = d.out + (row0 + 32 * m + 4 * lh) * d.ld_out + d.off_out + ch;
+            const long prow = row0 + 32 * m + 4 * lh;
+            if (d.out != nullptr) {
+                float* o = d.out + prow * d.ld_out + d.off_out + ch;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pr = (r & 3) + 8 * (r >> 2);
-                if (row0 + 32 * m + 4 * lh + pr < rows) o[(long)pr * d.ld_out] = fmaxf(acc[m][t][r] + bias, 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    const int pr = (r & 3) + 8 * (r >> 2);
+                    if (prow + pr < rows) o[(long)pr * d.ld_out] = fmaxf(acc[m][t][r] + bias, 0.f);
+                }
+            }
+            if (d.out_split != nullptr) {              // split twin for the DMA-fed 3x3 that follows (convc2)
+                char* sp = pf_split_ptr(d.out_split, prow, d.lds_out, d.off_out + ch);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pr = (r & 3) + 8 * (r >> 2);
+                    if (prow + pr < rows) pf_split_store(sp + (long)pr * d.lds_out * 128, fmaxf(acc[m][t][r] + bias, 0.f));
+                }
             }
         }
     }
@@ -216,8 +228,9 @@ extern "C" int pf_dccl_combine_conv1x1(const pf_combine_conv_desc* descs, int ng
     CombGroups g;
     for (int i = 0; i < ngroups; ++i) {
         const pf_combine_conv_desc& d = descs[i];
-        if (!d.own || !d.raw || !d.g_back || !d.weight || !d.bias || !d.out) return PF_ERR_BAD_ARG;
-        if (d.cout != CC_COUT || d.ld < CC_CIN || (d.ld & 3) || d.off_out < 0 || d.off_out + d.cout > d.ld_out) return PF_ERR_BAD_SHAPE;
+        if (!d.own || !d.raw || !d.g_back || !d.weight || !d.bias || (!d.out && !d.out_split)) return PF_ERR_BAD_ARG;
+        if (d.cout != CC_COUT || d.ld < CC_CIN || (d.ld & 3) || d.off_out < 0 || (d.out && d.off_out + d.cout > d.ld_out)) return PF_ERR_BAD_SHAPE;
+        if (d.out_split && ((d.off_out & 31) || d.off_out + d.cout > d.lds_out * 32)) return PF_ERR_BAD_SHAPE;
         g.d[i] = d;
     }
     if (ngroups == 1) g.d[1] = g.d[0];

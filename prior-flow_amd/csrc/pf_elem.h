@@ -19,6 +19,24 @@
 #endif
 // scalar helpers
 // ----------------------------------------------------------------------------------------------
+// bf16 hi|lo split of one value (the operand format of the PF_PREC_BF16X3 GEMMs): hi = bf16_rne(x), lo = bf16_rne(x - hi).
+PF_HD unsigned short pf_bf16_rne(float f) {
+    union { float f; unsigned u; } v; v.f = f;
+    const unsigned r = v.u + 0x7FFFu + ((v.u >> 16) & 1u);     // round to nearest even (finite inputs)
+    return (unsigned short)(r >> 16);
+}
+PF_HD float pf_bf16_to_f32(unsigned short h) {
+    union { float f; unsigned u; } v; v.u = (unsigned)h << 16;
+    return v.f;
+}
+// element (row, ch) of a split twin [rows][lds chunks]{hi[32], lo[32]} (include/priorflow_hip.h, pf_conv_desc)
+PF_HD void pf_split_put(void* base, long row, int lds, int ch, float x) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(base) + (row * lds + (ch >> 5)) * 64 + (ch & 31);
+    const unsigned short hi = pf_bf16_rne(x);
+    o[0] = hi;
+    o[32] = pf_bf16_rne(x - pf_bf16_to_f32(hi));
+}
+
 // Python-style float remainder for b > 0 (`xgrid % W`, core/utils/utils.py:83; ATen: fmod, then +b when
 // the signs differ), bit for bit, without the device's (long, loop-based) fmodf:
 //   0 <= a < b            -> a                       (fmod is the identity)
@@ -723,6 +741,7 @@ struct PfDirectConvArgs {
     float* out; int ld_out, c_out_off, Cout;
     int B, H, W, KH, KW, relu;      // H, W: OUTPUT map
     int stride, nchw, Hin, Win;     // input map = stride x output; nchw: input is [B,Cin,Hin,Win] planes
+    void* out_split; int lds_out;   // optional split twin of `out` (same channel offset); `out` may then be null
 };
 PF_HD void pf_direct_conv_elem(long idx, const PfDirectConvArgs& a) {  // idx over B*N*Cout
     const long N = (long)a.H * a.W, Nin = (long)a.Hin * a.Win;
@@ -748,7 +767,8 @@ PF_HD void pf_direct_conv_elem(long idx, const PfDirectConvArgs& a) {  // idx ov
     }
     acc = acc + a.bias[co];
     if (a.relu) acc = fmaxf(acc, 0.f);
-    a.out[row * a.ld_out + a.c_out_off + co] = acc;
+    if (a.out) a.out[row * a.ld_out + a.c_out_off + co] = acc;
+    if (a.out_split) pf_split_put(a.out_split, row, a.lds_out, a.c_out_off + co, acc);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -787,15 +807,6 @@ PF_HD void pf_flow_out_elem(long idx, const PfFlowOutArgs& a) {   // idx over B*
 // fp32 -> bf16 hi|lo split rows (operand format of the PF_PREC_BF16X3 GEMMs):
 // out row = [C/32 chunks] x { bf16 hi[32], bf16 lo[32] }, hi = bf16_rne(x), lo = bf16_rne(x - hi).
 // ----------------------------------------------------------------------------------------------
-PF_HD unsigned short pf_bf16_rne(float f) {
-    union { float f; unsigned u; } v; v.f = f;
-    const unsigned r = v.u + 0x7FFFu + ((v.u >> 16) & 1u);     // round to nearest even (finite inputs)
-    return (unsigned short)(r >> 16);
-}
-PF_HD float pf_bf16_to_f32(unsigned short h) {
-    union { float f; unsigned u; } v; v.u = (unsigned)h << 16;
-    return v.f;
-}
 struct PfSplitArgs { const float* in; unsigned short* out; long rows; int C; };
 PF_HD void pf_split_bf16_elem(long idx, const PfSplitArgs& a) {   // idx over rows*C/4
     const int c4n = a.C / 4;
@@ -1019,6 +1030,8 @@ struct PfMotionPrepArgs {
     float* flow4_a;                          // [B*N][4]  flow_A | flow_B_A      (input of the 7x7 flow stems)
     float* flow2_b;                          // [B*N][2]  flow_B
     PfDst xa, xb;                            // GRU input tails: 4 columns (flow_A | flow_B_A) / 2 columns (flow_B)
+    void* xa_split; int xa_lds;              // optional split twins of the GRU input buffers (same channel offsets as xa / xb)
+    void* xb_split; int xb_lds;
     float* conf; int conf_ld;                // [B*N][conf_ld]: columns 0..3 flaw_A, 4..7 flaw_B_A
     int B, H, W;
 };

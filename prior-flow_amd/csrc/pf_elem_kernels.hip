@@ -1,6 +1,7 @@
 // __global__ wrappers + C-ABI launchers of the per-element kernels (gfx950).
 // The math lives in pf_elem.h; see include/priorflow_hip.h for the ABI contract.
 #include "pf_elem.h"
+#include "pf_split.h"
 
 namespace {
 
@@ -131,6 +132,15 @@ __global__ void __launch_bounds__(256) pf_motion_prep_kernel(const PfMotionPrepA
             d[0] = f.ua; d[1] = f.va; d[2] = f.uba; d[3] = f.vba;
         }
         pf_store_dst2(a.xb, row, f.ub, f.vb);
+        if (a.xa_split) {
+            const float v4[4] = {f.ua, f.va, f.uba, f.vba};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf_split_store(pf_split_ptr(a.xa_split, row, a.xa_lds, a.xa.c_off + i), v4[i]);
+        }
+        if (a.xb_split) {
+            pf_split_store(pf_split_ptr(a.xb_split, row, a.xb_lds, a.xb.c_off), f.ub);
+            pf_split_store(pf_split_ptr(a.xb_split, row, a.xb_lds, a.xb.c_off + 1), f.vb);
+        }
         // sample points of the two warps: coords1_A (:173) and coords0 + flow_B_A (:180)
         flows[tid][0] = a.c1a[(b * 2 + 0) * N + n]; flows[tid][1] = a.c1a[(b * 2 + 1) * N + n];
         flows[tid][2] = x + f.uba; flows[tid][3] = y + f.vba;
@@ -196,6 +206,7 @@ struct PfSmallConvArgs {
     const float* in; int ld_in, c_in_off, Cin; int nchw;      // channel-last rows, or NCHW planes
     const float* w; const float* bias;                        // [KH*KW*Cin][Cout]
     float* out; int ld_out, c_out_off, Cout;                  // channel-last
+    void* out_split; int lds_out;                             // optional split twin of `out` (pf_stem7x7c2_valu only)
     int B, H, W;                                              // INPUT spatial size
     int KH, KW, stride, relu;
     int Ho, Wo;                                               // output size (H/stride, W/stride)
@@ -383,20 +394,35 @@ __global__ void __launch_bounds__(128) pf_stem7x7c2_valu(const PfSmallConvMulti 
     }
     const int x = sx * 64 + lane;
     if (x < a.W) {
-        float* o = a.out + ((b * a.H + y) * (long)a.W + x) * a.ld_out + a.c_out_off + co0;
+        const long row = (b * a.H + y) * (long)a.W + x;
+        if (a.relu) {
 #pragma unroll
-        for (int i = 0; i < CPW; i += 4) {
-            float4 v;
-            v.x = acc[i]; v.y = acc[i + 1]; v.z = acc[i + 2]; v.w = acc[i + 3];
-            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4*>(o + i) = v;
+            for (int i = 0; i < CPW; ++i) acc[i] = fmaxf(acc[i], 0.f);
+        }
+        if (a.out != nullptr) {
+            float* o = a.out + row * a.ld_out + a.c_out_off + co0;
+#pragma unroll
+            for (int i = 0; i < CPW; i += 4) {
+                float4 v;
+                v.x = acc[i]; v.y = acc[i + 1]; v.z = acc[i + 2]; v.w = acc[i + 3];
+                *reinterpret_cast<float4*>(o + i) = v;
+            }
+        }
+        if (a.out_split != nullptr) {               // 8 consecutive channels: one 16-byte store per half
+            static_assert(CPW % 8 == 0, "");
+#pragma unroll
+            for (int i = 0; i < CPW; i += 8) {
+                const float v8[8] = {acc[i], acc[i + 1], acc[i + 2], acc[i + 3], acc[i + 4], acc[i + 5], acc[i + 6], acc[i + 7]};
+                pf_split_store_n<8>(pf_split_ptr(a.out_split, row, a.lds_out, a.c_out_off + co0 + i), v8);
+            }
         }
     }
 }
 
 bool stem7x7c2_ok(const PfSmallConvArgs& a) {
     return a.KH == 7 && a.KW == 7 && a.Cin == 2 && a.stride == 1 && !a.nchw && a.Cout % 64 == 0 && a.Ho == a.H && a.Wo == a.W &&
-           a.ld_out % 4 == 0 && a.c_out_off % 4 == 0 && ((uintptr_t)a.out) % 16 == 0;
+           (!a.out || (a.ld_out % 4 == 0 && a.c_out_off % 4 == 0 && ((uintptr_t)a.out) % 16 == 0)) &&
+           (!a.out_split || (a.c_out_off % 8 == 0 && ((uintptr_t)a.out_split) % 16 == 0));
 }
 
 int launch_stem7x7c2(const PfSmallConvMulti& m, int n, void* stream) {
@@ -866,11 +892,14 @@ static int pf_direct_conv_dispatch_n(const PfDirectConvArgs* ds, int n, long tot
             a.w = e.w; a.bias = e.bias; a.out = e.out; a.ld_out = e.ld_out; a.c_out_off = e.c_out_off; a.Cout = e.Cout;
             a.B = e.B; a.H = e.Hin; a.W = e.Win; a.KH = e.KH; a.KW = e.KW; a.stride = e.stride; a.relu = e.relu;
             a.Ho = e.H; a.Wo = e.W;
+            a.out_split = e.out_split; a.lds_out = e.lds_out;
         }
         for (int i = n; i < 4; ++i) m.p[i] = m.p[0];
         bool valu = true;
         for (int i = 0; i < n; ++i) valu = valu && stem7x7c2_ok(m.p[i]);
         if (valu) return launch_stem7x7c2(m, n, stream);
+        for (int i = 0; i < n; ++i)
+            if (m.p[i].out_split || !m.p[i].out) return PF_ERR_BAD_SHAPE;       // the MFMA form writes fp32 rows only
         return launch_small_conv(m, n, stream);
     }
     for (int i = 0; i < n; ++i) {
@@ -918,6 +947,7 @@ struct PfConfStemArgs {
     const float* w1; const float* b1;       // [9*8][32], [32]
     const float* w2; const float* b2;       // [9*32][16], [16]
     float* out; int ld_out, off_out;
+    void* out_split; int lds_out;
     int B, H, W;
 };
 __global__ void __launch_bounds__(256) pf_conf_stem_kernel(const PfConfStemArgs a) {
@@ -990,18 +1020,25 @@ __global__ void __launch_bounds__(256) pf_conf_stem_kernel(const PfConfStemArgs 
     const int y = y0 + oy, x = x0 + ox;
     if (y < a.H && x < a.W) {
         const float4 r = {fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
-        *reinterpret_cast<float4*>(a.out + (pix0 + (long)y * a.W + x) * a.ld_out + a.off_out + 4 * cg) = r;
+        const long row = pix0 + (long)y * a.W + x;
+        if (a.out != nullptr) *reinterpret_cast<float4*>(a.out + row * a.ld_out + a.off_out + 4 * cg) = r;
+        if (a.out_split != nullptr) {
+            const float v4[4] = {r.x, r.y, r.z, r.w};
+            pf_split_store_n<4>(pf_split_ptr(a.out_split, row, a.lds_out, a.off_out + 4 * cg), v4);
+        }
     }
 }
 
 extern "C" int pf_conf_stem(const float* in, int ld_in, int off_in, const float* w1, const float* b1,
                             const float* w2, const float* b2, float* out, int ld_out, int off_out,
-                            int B, int H8, int W8, void* stream) {
-    if (!in || !w1 || !b1 || !w2 || !b2 || !out) return PF_ERR_BAD_ARG;
+                            void* out_split, int lds_out, int B, int H8, int W8, void* stream) {
+    if (!in || !w1 || !b1 || !w2 || !b2 || (!out && !out_split)) return PF_ERR_BAD_ARG;
     if (B <= 0 || H8 <= 0 || W8 <= 0) return PF_ERR_BAD_SHAPE;
-    if (off_in < 0 || off_in + CS_CIN > ld_in || off_out < 0 || off_out + CS_OUT > ld_out) return PF_ERR_BAD_ARG;
-    if ((ld_in | off_in | ld_out | off_out) & 3) return PF_ERR_BAD_SHAPE;          // 16-byte rows
+    if (off_in < 0 || off_in + CS_CIN > ld_in || off_out < 0 || (out && off_out + CS_OUT > ld_out)) return PF_ERR_BAD_ARG;
+    if (out_split && off_out + CS_OUT > lds_out * 32) return PF_ERR_BAD_ARG;
+    if ((ld_in | off_in | off_out) & 3 || (out && (ld_out & 3))) return PF_ERR_BAD_SHAPE;          // 16-byte rows
     PfConfStemArgs a;
+    a.out_split = out_split; a.lds_out = lds_out;
     a.in = in; a.ld_in = ld_in; a.off_in = off_in; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.out = out; a.ld_out = ld_out; a.off_out = off_out; a.B = B; a.H = H8; a.W = W8;
     const long tiles = (long)B * ((H8 + CS_TH - 1) / CS_TH) * ((W8 + CS_TW - 1) / CS_TW);
@@ -1012,12 +1049,16 @@ extern "C" int pf_conf_stem(const float* in, int ld_in, int off_in, const float*
 extern "C" int pf_motion_prep(const float* c1a, const float* c1b, const float* g_w2c, const float* g_c2w,
                               const float* f1a, const float* f2a, float* flow4_a, float* flow2_b,
                               float* xa, int xa_ld, int xa_off, float* xb, int xb_ld, int xb_off,
+                              void* xa_split, int xa_lds, void* xb_split, int xb_lds,
                               float* conf, int conf_ld, int B, int H8, int W8, int C, void* stream) {
     if (!c1a || !c1b || !g_w2c || !g_c2w || !f1a || !f2a || !flow4_a || !flow2_b || !conf) return PF_ERR_BAD_ARG;
     if (B <= 0 || H8 <= 1 || W8 <= 1 || C != 256 || conf_ld < 8) return PF_ERR_BAD_SHAPE;
     if (xa && (xa_off < 0 || xa_off + 4 > xa_ld)) return PF_ERR_BAD_ARG;
     if (xb && (xb_off < 0 || xb_off + 2 > xb_ld)) return PF_ERR_BAD_ARG;
+    if (xa_split && (xa_off < 0 || xa_off + 4 > xa_lds * 32)) return PF_ERR_BAD_ARG;
+    if (xb_split && (xb_off < 0 || xb_off + 2 > xb_lds * 32)) return PF_ERR_BAD_ARG;
     PfMotionPrepArgs a;
+    a.xa_split = xa_split; a.xa_lds = xa_lds; a.xb_split = xb_split; a.xb_lds = xb_lds;
     a.c1a = c1a; a.c1b = c1b; a.g_w2c = g_w2c; a.g_c2w = g_c2w; a.f1 = f1a; a.f2 = f2a;
     a.flow4_a = flow4_a; a.flow2_b = flow2_b;
     a.xa = pf_dst(xa, xa_ld, xa_off); a.xb = pf_dst(xb, xb_ld, xb_off);
@@ -1029,5 +1070,5 @@ extern "C" int pf_motion_prep(const float* c1a, const float* c1b, const float* g
 }
 
 extern "C" const char* pf_version(void) {
-    return "priorflow-hip r2 gfx950 (bf16x3 / exact-fp32 MFMA implicit-GEMM convs, fused corr+pyramid, fused combine+1x1, HIP encoders, HIP training backward)";
+    return "priorflow-hip r3 gfx950 (bf16x3 / exact-fp32 MFMA implicit-GEMM convs, all-DMA convs on pre-split activations, fused corr+pyramid, fused combine+1x1, HIP encoders, HIP training backward)";
 }

@@ -64,6 +64,19 @@ def split_bf16(wp: torch.Tensor) -> torch.Tensor:
     return torch.cat([hi.reshape(shp), lo.reshape(shp)], dim=-2).contiguous()
 
 
+def split_twin(rows: int, channels: int, device) -> torch.Tensor:
+    """Zero-initialised split twin of a channel-last map [rows][channels]: bf16 [rows][ceil(channels/32)][2][32], per
+    32-channel chunk the hi halves then the lo halves (include/priorflow_hip.h, pf_conv_desc).  Channels past `channels`
+    stay zero: they are the zero padding of the K dimension."""
+    return torch.zeros(rows, (channels + 31) // 32, 2, 32, dtype=torch.bfloat16, device=device)
+
+
+def unsplit(twin: torch.Tensor, channels: int) -> torch.Tensor:
+    """hi + lo of a split twin as fp32 rows [rows][channels] (tests / debugging; 16 mantissa bits of the original)."""
+    v = twin[:, :, 0, :].float() + twin[:, :, 1, :].float()
+    return v.reshape(twin.shape[0], -1)[:, :channels].contiguous()
+
+
 def stem_s2d_weight(w: torch.Tensor) -> torch.Tensor:
     """7x7 stride-2 pad-3 weights [Cout,C,7,7] -> the equivalent 4x4 stride-1 weights [Cout,4C,4,4]
     over the 2x2 space-to-depth image (channel (py*2+px)*C + c, window rows Y-2..Y+1):
@@ -136,14 +149,26 @@ class Conv:
 
     def desc(self, in0, off0, c0, out, off_out, epilogue, in1=None, off1=0, c1=0, scale=1.0,
              h=None, z=None, aux=None, stride=1, in_scale=None, in_shift=None, in_relu=False,
-             stats=None) -> ConvDesc:
+             stats=None, in0s=None, in1s=None, outs=None, auxs=None) -> ConvDesc:
+        """in0s / in1s / outs / auxs: optional split twins (``split_twin``) of in0 / in1 / out / aux; with a twin given the
+        fp32 tensor may be None (operands: the all-DMA kernel reads only the twins; outputs: twin only)."""
         assert c0 + c1 == self.cin, (c0, c1, self.cin)
         d = ConvDesc()
-        d.in0, d.ld0, d.off0, d.c0 = in0.data_ptr(), in0.shape[-1], off0, c0
+        d.in0 = in0.data_ptr() if in0 is not None else None
+        d.ld0, d.off0, d.c0 = (in0.shape[-1] if in0 is not None else 0), off0, c0
         d.in1 = in1.data_ptr() if in1 is not None else None
         d.ld1, d.off1, d.c1 = (in1.shape[-1] if in1 is not None else 0), off1, c1
         d.weight, d.bias = self.w.data_ptr(), self.b.data_ptr()
-        d.out, d.ld_out, d.off_out, d.cout = out.data_ptr(), out.shape[-1], off_out, self.cout
+        d.out = out.data_ptr() if out is not None else None
+        d.ld_out, d.off_out, d.cout = (out.shape[-1] if out is not None else 0), off_out, self.cout
+        for name, t in (("in0_split", in0s), ("in1_split", in1s), ("out_split", outs), ("aux_split", auxs)):
+            if t is not None:
+                assert t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[2:] == (2, 32) and t.is_contiguous(), name
+                setattr(d, name, t.data_ptr())
+        d.lds0 = in0s.shape[1] if in0s is not None else 0
+        d.lds1 = in1s.shape[1] if in1s is not None else 0
+        d.lds_out = outs.shape[1] if outs is not None else 0
+        d.lds_aux = auxs.shape[1] if auxs is not None else 0
         d.kh, d.kw, d.epilogue, d.scale = self.kh, self.kw, epilogue, scale
         d.h = h.data_ptr() if h is not None else None
         d.ld_h = h.shape[-1] if h is not None else 0
@@ -158,7 +183,7 @@ class Conv:
         d.in_relu = int(in_relu)
         d.stats_out = stats.data_ptr() if stats is not None else None
         # the C struct holds raw pointers only: keep every tensor alive for as long as the descriptor is
-        d._keep = (in0, in1, out, h, z, aux, in_scale, in_shift, stats, self.w, self.b)
+        d._keep = (in0, in1, out, h, z, aux, in_scale, in_shift, stats, self.w, self.b, in0s, in1s, outs, auxs)
         return d
 
 
@@ -272,6 +297,26 @@ class Workspace:
         self.fh_a, self.fh_b, self.mh_a, self.mh_b = z(rows, 256), z(rows, 256), z(rows, 256), z(rows, 256)
         self.delta_a, self.delta_b = z(rows, 4), z(rows, 4)
         self.mask_a, self.mask_b = z(rows, 576), z(rows, 576)
+        # ---- split twins (bf16 hi|lo rows, include/priorflow_hip.h): every activation an MFMA conv of the update blocks
+        # consumes is written in this form by its producer, so both operands of those convs go global -> LDS by DMA.
+        # Only the hidden state keeps an fp32 copy as well (the GRU epilogues blend with it).
+        tw = lambda r, c: split_twin(r, c, device)  # noqa: E731
+        self.net0_ab_s = tw(2 * rows, 128)
+        self.net_a_s = [self.net0_ab_s[:rows], tw(rows, 128)]
+        self.net_b_s = [self.net0_ab_s[rows:], tw(rows, 128)]
+        self.x_ab_s = tw(2 * rows, 256)
+        self.x_a_s, self.x_b_s = self.x_ab_s[:rows], self.x_ab_s[rows:]
+        self.rh_a_s, self.rh_b_s = tw(rows, 128), tw(rows, 128)
+        self.c1_a_s, self.c1_b_s = tw(rows, 256), tw(rows, 256)
+        self.cat_a_s, self.cat_b_s = tw(rows, 272), tw(rows, 272)      # 9 chunks; cat_b's last chunk stays zero
+        self.t_a_s, self.t_ba_s, self.t_b_s = tw(rows, 128), tw(rows, 128), tw(rows, 128)
+
+    def sync_twins(self, lib: PfLib):
+        """Refresh the twins of the loop's INPUT state from the fp32 buffers (tests that fill net / x by hand)."""
+        lib.split_bf16(self.net0_ab, self.net0_ab_s)
+        lib.split_bf16(self.net_a[1], self.net_a_s[1])
+        lib.split_bf16(self.net_b[1], self.net_b_s[1])
+        lib.split_bf16(self.x_ab, self.x_ab_s)
 
     def nbytes(self) -> int:
         tot = 0
@@ -296,6 +341,12 @@ class Engine:
         self._b_pending = None      # event after branch B's deferred FlowHead tail (see iteration())
         # capture-order switches (bit mask; see motion_inputs): 1 chains, 2 head tails, 4 lookups: calling stream first
         self.order = int(os.environ.get("PRIORFLOW_ORDER", "15"))
+        # pre-split activations + all-DMA convs (bf16x3 only); PRIORFLOW_PRESPLIT=0 keeps the fp32-staged kernels (A/B knob:
+        # the results are bit-identical)
+        self.presplit_on = os.environ.get("PRIORFLOW_PRESPLIT", "1") != "0"
+
+    def presplit(self, P) -> bool:
+        return self.presplit_on and P["precision"] == PREC_BF16X3
 
     # ---- stage 0: view B images --------------------------------------------------------------
     def rotate_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
@@ -352,12 +403,16 @@ class Engine:
                 self._b_pending = None
 
     # -- the three independent chains of an iteration ---------------------------------------------
-    def _flow_chain_head(self, ws: Workspace):
+    def _flow_chain_head(self, ws: Workspace, ps: bool = False):
         """flows + flo_rotate + the two feature warps / groupwise correlations (:171-182) in ONE launch: produces
         flow4_a, flow2_b, the flow tails of x_a / x_b and conf_in.  flo_rotate(flow_B, W2C = grid(R_B2A^T) ==
         grid(R_A2B), C2W = grid(R_B2A)) (:179).  PRIORFLOW_FUSED_PREP=0 keeps the five separate launches (A/B knob;
         the results are bit-identical)."""
         lib = self.lib
+        if ps:          # the GRU-input tails go to the split twins of x_a / x_b only
+            lib.motion_prep(ws.c1a, ws.c1b, ws.g_a2b_8, ws.g_b2a_8, ws.f["f1a"], ws.f["f2a"], ws.flow4_a, ws.flow2_b,
+                            ws.conf_in, None, 252, None, 254, xa_split=ws.x_a_s, xb_split=ws.x_b_s)
+            return
         if os.environ.get("PRIORFLOW_FUSED_PREP", "1") != "0":
             lib.motion_prep(ws.c1a, ws.c1b, ws.g_a2b_8, ws.g_b2a_8, ws.f["f1a"], ws.f["f2a"], ws.flow4_a, ws.flow2_b,
                             ws.conf_in, ws.x_a, 252, ws.x_b, 254)
@@ -371,18 +426,24 @@ class Engine:
     def _flow_chain_tail(self, ws: Workspace, P, need_b: bool):
         """7x7 flow stems + 3x3 (core/update.py:187-191, :94-95) -> cat_a[128:256], cat_b[192:256]."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
+        ps = self.presplit(P)
 
         # the 7x7 stems of flow_A, flow_B_A (and flow_B) are independent and of one shape: one launch
-        stems = [(P["a.f1a"], ws.flow4_a, 0, ws.t_a), (P["a.f1b"], ws.flow4_a, 2, ws.t_ba)]
-        d = [P["a.f2a"].desc(ws.t_a, 0, 128, ws.cat_a, 128, EPI_RELU),
-             P["a.f2b"].desc(ws.t_ba, 0, 128, ws.cat_a, 192, EPI_RELU)]
+        stems = [(P["a.f1a"], ws.flow4_a, 0, ws.t_a, ws.t_a_s), (P["a.f1b"], ws.flow4_a, 2, ws.t_ba, ws.t_ba_s)]
+        f2 = [(P["a.f2a"], ws.t_a, ws.t_a_s, ws.cat_a, ws.cat_a_s, 128), (P["a.f2b"], ws.t_ba, ws.t_ba_s, ws.cat_a, ws.cat_a_s, 192)]
         if need_b:
-            stems.append((P["b.f1"], ws.flow2_b, 0, ws.t_b))
-            d.append(P["b.f2"].desc(ws.t_b, 0, 128, ws.cat_b, 192, EPI_RELU))
+            stems.append((P["b.f1"], ws.flow2_b, 0, ws.t_b, ws.t_b_s))
+            f2.append((P["b.f2"], ws.t_b, ws.t_b_s, ws.cat_b, ws.cat_b_s, 192))
         dc = stems[0][0]
         assert all((s[0].cin, s[0].cout, s[0].kh, s[0].kw) == (dc.cin, dc.cout, dc.kh, dc.kw) for s in stems)
-        lib.conv2d_direct_group([(x, off_in, c.w, c.b, out, 0) for c, x, off_in, out in stems],
-                                dc.cin, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
+        if ps:
+            lib.conv2d_direct_group([(x, off_in, c.w, c.b, None, 0, tw) for c, x, off_in, out, tw in stems],
+                                    dc.cin, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
+            d = [c.desc(None, 0, 128, None, off, EPI_RELU, in0s=ts, outs=cs) for c, t, ts, cat, cs, off in f2]
+        else:
+            lib.conv2d_direct_group([(x, off_in, c.w, c.b, out, 0) for c, x, off_in, out, tw in stems],
+                                    dc.cin, dc.cout, dc.kh, dc.kw, True, B, H8, W8)
+            d = [c.desc(t, 0, 128, cat, off, EPI_RELU) for c, t, ts, cat, cs, off in f2]
         lib.conv2d(d, B, H8, W8, ws.x_a)
 
     def _conf_chain(self, ws: Workspace, P):
@@ -394,7 +455,10 @@ class Engine:
         intermediate map stays in LDS."""
         c1, c2 = P["a.cf1"], P["a.cf2"]
         assert (c1.cin, c1.cout, c1.kh, c1.kw, c2.cin, c2.cout, c2.kh, c2.kw) == (8, 32, 3, 3, 32, 16, 3, 3)
-        self.lib.conf_stem(ws.conf_in, 0, c1.w, c1.b, c2.w, c2.b, ws.cat_a, 256, ws.B, ws.H8, ws.W8)
+        if self.presplit(P):
+            self.lib.conf_stem(ws.conf_in, 0, c1.w, c1.b, c2.w, c2.b, None, 256, ws.B, ws.H8, ws.W8, out_split=ws.cat_a_s)
+        else:
+            self.lib.conf_stem(ws.conf_in, 0, c1.w, c1.b, c2.w, c2.b, ws.cat_a, 256, ws.B, ws.H8, ws.W8)
 
     def _corr_chain(self, ws: Workspace, P, need_b: bool, fork_from=None):
         """DCCL lookups (K3+K4; :185-188) + 1x1 + 3x3 of the motion encoders -> cat_a[0:128], cat_b[0:192].
@@ -402,6 +466,7 @@ class Engine:
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
         # bf16x3: rotate-back + add + convc1 are ONE launch (pf_dccl_combine_conv1x1): corr_a / corr_b never exist
         fused = P["precision"] == PREC_BF16X3 and os.environ.get("PRIORFLOW_FUSED_COMBINE", "1") != "0"
+        ps = self.presplit(P)
 
         def look_a():
             lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
@@ -449,20 +514,30 @@ class Engine:
             if need_b:
                 self._await_b(torch.cuda.current_stream(), keep=True)
                 look_b()
+        c1o = (lambda t: None) if ps else (lambda t: t)       # presplit: convc1's output exists as a twin only
         if fused:
-            items = [(ws.own, ws.raw, ws.g_b2a_8, P["a.c1"], ws.c1_a, 0)]
+            items = [(ws.own, ws.raw, ws.g_b2a_8, P["a.c1"], c1o(ws.c1_a), 0, ws.c1_a_s if ps else None)]
             if need_b:
-                items.append((ws.own_b, ws.raw_b, ws.g_a2b_8, P["b.c1"], ws.c1_b, 0))
+                items.append((ws.own_b, ws.raw_b, ws.g_a2b_8, P["b.c1"], c1o(ws.c1_b), 0, ws.c1_b_s if ps else None))
             lib.dccl_combine_conv1x1(items, B, H8, W8)
         else:
-            d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
+            d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, c1o(ws.c1_a), 0, EPI_RELU, outs=ws.c1_a_s if ps else None)]
             if need_b:
-                d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, ws.c1_b, 0, EPI_RELU))
+                d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, c1o(ws.c1_b), 0, EPI_RELU, outs=ws.c1_b_s if ps else None))
             lib.conv2d(d, B, H8, W8, ws.x_a)
+        lib.conv2d(self._c2_descs(ws, P, need_b), B, H8, W8, ws.x_a)
+
+    def _c2_descs(self, ws: Workspace, P, need_b: bool):
+        """convc2 (3x3 256 -> 128 / 192) of both motion encoders -> cat_a[0:128], cat_b[0:192]."""
+        if self.presplit(P):
+            d = [P["a.c2"].desc(None, 0, 256, None, 0, EPI_RELU, in0s=ws.c1_a_s, outs=ws.cat_a_s)]
+            if need_b:
+                d.append(P["b.c2"].desc(None, 0, 256, None, 0, EPI_RELU, in0s=ws.c1_b_s, outs=ws.cat_b_s))
+            return d
         d = [P["a.c2"].desc(ws.c1_a, 0, 256, ws.cat_a, 0, EPI_RELU)]
         if need_b:
             d.append(P["b.c2"].desc(ws.c1_b, 0, 256, ws.cat_b, 0, EPI_RELU))
-        lib.conv2d(d, B, H8, W8, ws.x_a)
+        return d
 
     def prep_and_lookup(self, ws: Workspace, need_b: bool):
         """flows, flo_rotate and the DCCL lookups of one iteration, single stream (tests)."""
@@ -479,7 +554,7 @@ class Engine:
         tails of x_a, x_b from coords1 and the pyramids.  Three concurrent chains when side streams exist."""
         if not self.forks & 2:
             self._await_b(torch.cuda.current_stream())
-            self._flow_chain_head(ws)
+            self._flow_chain_head(ws, self.presplit(P))
             self._corr_chain(ws, P, need_b)
             self._flow_chain_tail(ws, P, need_b)
             self._conf_chain(ws, P)
@@ -499,7 +574,7 @@ class Engine:
         else:
             s1.wait_stream(main)
         with torch.cuda.stream(s1):
-            self._flow_chain_head(ws)
+            self._flow_chain_head(ws, self.presplit(P))
             head_done = torch.cuda.Event()
             head_done.record(s1)
             self._flow_chain_tail(ws, P, need_b)
@@ -524,45 +599,57 @@ class Engine:
         def conv(descs):
             lib.conv2d(descs, B, H8, W8, like)
 
+        ps = self.presplit(P)
         if not inputs_ready:
             # motion encoders (core/update.py:183-201, :91-99) from corr_x / flows / conf_in
-            d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, ws.c1_a, 0, EPI_RELU)]
+            d = [P["a.c1"].desc(ws.corr_a, 0, CORR_CH, None if ps else ws.c1_a, 0, EPI_RELU, outs=ws.c1_a_s if ps else None)]
             if need_b:
-                d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, ws.c1_b, 0, EPI_RELU))
+                d.append(P["b.c1"].desc(ws.corr_b, 0, CORR_CH, None if ps else ws.c1_b, 0, EPI_RELU,
+                                        outs=ws.c1_b_s if ps else None))
             conv(d)
-            d = [P["a.c2"].desc(ws.c1_a, 0, 256, ws.cat_a, 0, EPI_RELU)]
-            if need_b:
-                d.append(P["b.c2"].desc(ws.c1_b, 0, 256, ws.cat_b, 0, EPI_RELU))
-            conv(d)
+            conv(self._c2_descs(ws, P, need_b))
             self._flow_chain_tail(ws, P, need_b)
             self._conf_stem(ws, P)
-        d = [P["a.out"].desc(ws.cat_a, 0, 272, ws.x_a, 128, EPI_RELU)]
-        if need_b:
-            d.append(P["b.out"].desc(ws.cat_b, 0, 272, ws.x_b, 128, EPI_RELU))
+        if ps:
+            d = [P["a.out"].desc(None, 0, 272, None, 128, EPI_RELU, in0s=ws.cat_a_s, outs=ws.x_a_s)]
+            if need_b:
+                d.append(P["b.out"].desc(None, 0, 272, None, 128, EPI_RELU, in0s=ws.cat_b_s, outs=ws.x_b_s))
+        else:
+            d = [P["a.out"].desc(ws.cat_a, 0, 272, ws.x_a, 128, EPI_RELU)]
+            if need_b:
+                d.append(P["b.out"].desc(ws.cat_b, 0, 272, ws.x_b, 128, EPI_RELU))
         conv(d)
 
         # SepConvGRU (core/update.py:46-60): z|r fused GEMM with sigmoid + r*h epilogue, then q
         # with the tanh + blend epilogue; horizontal (1x5) then vertical (5x1)
-        branches = [("a", ws.net_a, ws.x_a, ws.z_a, ws.rh_a)]
+        branches = [("a", ws.net_a, ws.x_a, ws.z_a, ws.rh_a, ws.net_a_s, ws.x_a_s, ws.rh_a_s)]
         if need_b:
-            branches.append(("b", ws.net_b, ws.x_b, ws.z_b, ws.rh_b))
+            branches.append(("b", ws.net_b, ws.x_b, ws.z_b, ws.rh_b, ws.net_b_s, ws.x_b_s, ws.rh_b_s))
         c = cur
         for tag in ("1", "2"):
-            conv([P[f"{t}.zr{tag}"].desc(net[c], 0, 128, zb, 0, EPI_GRU_ZR, in1=x, off1=0, c1=256,
-                                          h=net[c], aux=rh) for t, net, x, zb, rh in branches])
-            conv([P[f"{t}.q{tag}"].desc(rh, 0, 128, net[c ^ 1], 0, EPI_GRU_Q, in1=x, off1=0, c1=256,
-                                         h=net[c], z=zb) for t, net, x, zb, rh in branches])
+            if ps:      # operands as twins; z stays fp32 (epilogue operand of q), r*h exists as a twin only, h' in both forms
+                conv([P[f"{t}.zr{tag}"].desc(None, 0, 128, zb, 0, EPI_GRU_ZR, off1=0, c1=256, h=net[c], in0s=ns[c], in1s=xs,
+                                              auxs=rhs) for t, net, x, zb, rh, ns, xs, rhs in branches])
+                conv([P[f"{t}.q{tag}"].desc(None, 0, 128, net[c ^ 1], 0, EPI_GRU_Q, off1=0, c1=256, h=net[c], z=zb,
+                                             in0s=rhs, in1s=xs, outs=ns[c ^ 1]) for t, net, x, zb, rh, ns, xs, rhs in branches])
+            else:
+                conv([P[f"{t}.zr{tag}"].desc(net[c], 0, 128, zb, 0, EPI_GRU_ZR, in1=x, off1=0, c1=256,
+                                              h=net[c], aux=rh) for t, net, x, zb, rh, ns, xs, rhs in branches])
+                conv([P[f"{t}.q{tag}"].desc(rh, 0, 128, net[c ^ 1], 0, EPI_GRU_Q, in1=x, off1=0, c1=256,
+                                             h=net[c], z=zb) for t, net, x, zb, rh, ns, xs, rhs in branches])
             c ^= 1
         assert c == cur
 
         # heads (core/update.py:13-14, :124-136): the 3x3 128->256 stems share their input `net`
-        d = [P["a.fh1"].desc(ws.net_a[c], 0, 128, ws.fh_a, 0, EPI_RELU)]
+        na, nb = (None, None) if ps else (ws.net_a[c], ws.net_b[c])
+        nas, nbs = (ws.net_a_s[c], ws.net_b_s[c]) if ps else (None, None)
+        d = [P["a.fh1"].desc(na, 0, 128, ws.fh_a, 0, EPI_RELU, in0s=nas)]
         if need_b:
-            d.append(P["b.fh1"].desc(ws.net_b[c], 0, 128, ws.fh_b, 0, EPI_RELU))
+            d.append(P["b.fh1"].desc(nb, 0, 128, ws.fh_b, 0, EPI_RELU, in0s=nbs))
         if mask_a:
-            d.append(P["a.m0"].desc(ws.net_a[c], 0, 128, ws.mh_a, 0, EPI_RELU))
+            d.append(P["a.m0"].desc(na, 0, 128, ws.mh_a, 0, EPI_RELU, in0s=nas))
         if mask_b and need_b:
-            d.append(P["b.m0"].desc(ws.net_b[c], 0, 128, ws.mh_b, 0, EPI_RELU))
+            d.append(P["b.m0"].desc(nb, 0, 128, ws.mh_b, 0, EPI_RELU, in0s=nbs))
         conv(d)
         # FlowHead.conv2 (256 -> 2) + coords1 += delta_flow in one wave-per-pixel kernel
         d = []
@@ -720,9 +807,11 @@ class EncoderPlan:
         b["part"] = z(Bn * 1024 * 128 * 2, dt=torch.float64)       # [image][<= 1024 tiles or 128 chunks][C][2]
         self._bufs = b
 
-    def run(self, images: torch.Tensor, out: torch.Tensor, epilogue: int, aux: Optional[torch.Tensor] = None):
+    def run(self, images: torch.Tensor, out: torch.Tensor, epilogue: int, aux: Optional[torch.Tensor] = None,
+            outs: Optional[torch.Tensor] = None, auxs: Optional[torch.Tensor] = None):
         """images: NCHW [Bn,3,H,W] in [-1,1]; out: channel-last [Bn*N, ld] (fnet: 256 features;
-        cnet with EPI_TANH_RELU: out = net [.,128], aux = x buffer [.,256] whose first 128 columns get inp)."""
+        cnet with EPI_TANH_RELU: out = net [.,128], aux = x buffer [.,256] whose first 128 columns get inp).
+        outs / auxs: optional split twins of out / aux (with auxs given, aux may be None)."""
         lib = self.lib
         Bn, _, H, W = images.shape
         self._alloc(Bn, H, W)
@@ -767,5 +856,5 @@ class EncoderPlan:
                 lib.norm_act(y2, s2, t2, o, Bn, Np, cout, res=x)
             x = o
         # final 1x1 conv 128 -> 256 (core/extractor.py:151)
-        d = self.final.desc(x, 0, 128, out, 0, epilogue, aux=aux)
+        d = self.final.desc(x, 0, 128, out, 0, epilogue, aux=aux, outs=outs, auxs=auxs)
         lib.conv2d([d], Bn, h, w, x)

@@ -115,6 +115,9 @@ class PriOr_RAFT(nn.Module):
         image2 = 2 * (image2 / 255.0) - 1.0
         image1_b, image2_b = eng.rotate_images(ws, image1, image2)
         cplan, fplan = self._encoder_plans()       # both precisions run on the HIP library: there is no PyTorch-ROCm branch
+        # context features: net (fp32 + split twin) and inp (first 128 columns of the GRU input x; twin only when the
+        # update blocks run on pre-split activations)
+        ctx = dict(outs=ws.net0_ab_s, auxs=ws.x_ab_s) if eng.presplit(self._weights()) else dict(aux=ws.x_ab)
         ws.img_c[:B].copy_(image1); ws.img_c[B:].copy_(image1_b)
         ws.img_f[:B].copy_(image1); ws.img_f[B:2 * B].copy_(image2)
         ws.img_f[2 * B:3 * B].copy_(image1_b); ws.img_f[3 * B:].copy_(image2_b)
@@ -131,19 +134,19 @@ class PriOr_RAFT(nn.Module):
                 fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
                 s1.wait_event(ev)
                 with torch.cuda.stream(s1):
-                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
                 cur.wait_stream(s1)
             else:
                 s1.wait_stream(cur)
                 s2.wait_stream(cur)
                 with torch.cuda.stream(s1):
-                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
                 with torch.cuda.stream(s2):
                     fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
                 cur.wait_stream(s1)
                 cur.wait_stream(s2)
         else:
-            cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, aux=ws.x_ab)
+            cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
             fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
 
     def _streams(self):
@@ -216,7 +219,7 @@ class PriOr_RAFT(nn.Module):
             static_i1 = image1.clone()
             static_i2 = image2.clone()
             static_out = [torch.empty(ws.B, 2, ws.H, ws.W, dtype=torch.float32, device=image1.device)]
-            # warm-up on a side stream (MIOpen picks its kernels, lazy inits happen here)
+            # warm-up on a side stream (lazy initialisations -- function attributes, module loads -- happen here)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):

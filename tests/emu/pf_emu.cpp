@@ -126,8 +126,8 @@ extern "C" int pf_warp_gcorr(const float* f1, const float* f2, const float* coor
 // host statement of the fused confidence stem: two direct convolutions through a temporary
 extern "C" int pf_conf_stem(const float* in, int ld_in, int off_in, const float* w1, const float* b1,
                             const float* w2, const float* b2, float* out, int ld_out, int off_out,
-                            int B, int H8, int W8, void*) {
-    if (!in || !w1 || !b1 || !w2 || !b2 || !out) return PF_ERR_BAD_ARG;
+                            void* out_split, int lds_out, int B, int H8, int W8, void*) {
+    if (!in || !w1 || !b1 || !w2 || !b2 || (!out && !out_split)) return PF_ERR_BAD_ARG;
     if (B <= 0 || H8 <= 0 || W8 <= 0) return PF_ERR_BAD_SHAPE;
     const long N = (long)H8 * W8;
     float* mid = new float[(size_t)B * N * 32];
@@ -148,7 +148,9 @@ extern "C" int pf_conf_stem(const float* in, int ld_in, int off_in, const float*
                     const float* s = src + (b * N + (long)yy * W8 + xx) * lds + offs;
                     for (int ci = 0; ci < cin; ++ci) acc = fmaf(s[ci], w[(t * cin + ci) * cout + co], acc);
                 }
-                dst[row * ldd + offd + co] = acc > 0.f ? acc : 0.f;
+                const float r = acc > 0.f ? acc : 0.f;
+                if (!layer || out) dst[row * ldd + offd + co] = r;
+                if (layer && out_split) pf_split_put(out_split, row, lds_out, off_out + co, r);
             }
         }
     }
@@ -159,6 +161,7 @@ extern "C" int pf_conf_stem(const float* in, int ld_in, int off_in, const float*
 extern "C" int pf_motion_prep(const float* c1a, const float* c1b, const float* g_w2c, const float* g_c2w,
                               const float* f1a, const float* f2a, float* flow4_a, float* flow2_b,
                               float* xa, int xa_ld, int xa_off, float* xb, int xb_ld, int xb_off,
+                              void* xa_split, int xa_lds, void* xb_split, int xb_lds,
                               float* conf, int conf_ld, int B, int H8, int W8, int C, void*) {
     if (!c1a || !c1b || !g_w2c || !g_c2w || !f1a || !f2a || !flow4_a || !flow2_b || !conf) return PF_ERR_BAD_ARG;
     if (B <= 0 || H8 <= 1 || W8 <= 1 || C != 256 || conf_ld < 8) return PF_ERR_BAD_SHAPE;
@@ -177,6 +180,11 @@ extern "C" int pf_motion_prep(const float* c1a, const float* c1b, const float* g
         flow2_b[row * 2] = f.ub; flow2_b[row * 2 + 1] = f.vb;
         if (a.xa.ptr) { float* d = a.xa.ptr + row * a.xa.ld + a.xa.c_off; d[0] = f.ua; d[1] = f.va; d[2] = f.uba; d[3] = f.vba; }
         pf_store_dst2(a.xb, row, f.ub, f.vb);
+        if (xa_split) {
+            const float v4[4] = {f.ua, f.va, f.uba, f.vba};
+            for (int i = 0; i < 4; ++i) pf_split_put(xa_split, row, xa_lds, xa_off + i, v4[i]);
+        }
+        if (xb_split) { pf_split_put(xb_split, row, xb_lds, xb_off, f.ub); pf_split_put(xb_split, row, xb_lds, xb_off + 1, f.vb); }
         for (int wsel = 0; wsel < 2; ++wsel) {
             const float x = wsel == 0 ? c1a[(b * 2 + 0) * N + n] : (float)(n % W8) + f.uba;
             const float y = wsel == 0 ? c1a[(b * 2 + 1) * N + n] : (float)(n / W8) + f.vba;

@@ -1,6 +1,9 @@
 """Child process of tests/test_hip_kernels.py::test_conv_roles_kernel_matches_symmetric_kernel_bitwise:
    python tests/run_conv_case.py OUT.pt      (PRIORFLOW_CONV_WS picks the kernel form; it is read once per process)
-Runs seeded bf16x3 convolutions of the update blocks' shapes through pf_conv2d and saves the outputs."""
+Runs seeded bf16x3 convolutions of the update blocks' shapes through pf_conv2d and saves the outputs.
+PF_CASE_SPLIT=1: the operands are handed over as split twins only (pf_split_bf16 of the same fp32 inputs; the fp32 pointers
+are NULL) and every output is requested in both forms -- the all-DMA kernel; `twin_ok` records that each output twin equals
+pf_split_bf16 of the fp32 output bit for bit."""
 import os
 import sys
 
@@ -10,7 +13,7 @@ import torch
 
 from prior_flow_amd import _lib
 from prior_flow_amd._lib import EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_RELU, PREC_BF16X3
-from prior_flow_amd.engine import Conv, pack_mfma
+from prior_flow_amd.engine import Conv, pack_mfma, split_twin
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
@@ -27,7 +30,14 @@ def conv(cin, cout, kh, kw):
     return Conv(wp, bp, kh, kw, cin, cout, PREC_BF16X3)
 
 
-out, roles = {}, {}
+out, roles, twin_ok = {}, {}, {}
+SPLIT = os.environ.get("PF_CASE_SPLIT", "0") == "1"
+
+
+def twin_of(t):
+    return lib.split_bf16(t, split_twin(t.shape[0], t.shape[1], dev))
+
+
 for B, H8, W8 in ((1, 64, 128), (2, 22, 40), (4, 64, 128)):      # full tiles; ragged both ways; enough pixels for the 256-px tile
     N = B * H8 * W8
     x = rnd(N, 320)
@@ -39,15 +49,32 @@ for B, H8, W8 in ((1, 64, 128), (2, 22, 40), (4, 64, 128)):      # full tiles; r
         cv = [conv(cin, cout, kh, kw) for _ in range(2)]           # two groups, like branch A / branch B
         y = [torch.zeros(N, 256, device=dev) for _ in range(2)]
         aux = [torch.zeros(N, 128, device=dev) for _ in range(2)]
+        kx = [dict() for _ in range(2)]
+        xi, hi = x, h
+        if SPLIT:
+            xs, hs = twin_of(x), twin_of(h)
+            ys = [split_twin(N, 256, dev) for _ in range(2)]
+            auxs = [split_twin(N, 128, dev) for _ in range(2)]
+            xi = hi = None
         if epi == EPI_GRU_ZR:
-            descs = [cv[i].desc(h, 0, 128, y[i], 0, epi, in1=x, off1=0, c1=256, h=h, aux=aux[i]) for i in range(2)]
+            if SPLIT:
+                kx = [dict(in0s=hs, in1s=xs, outs=ys[i], auxs=auxs[i]) for i in range(2)]
+            descs = [cv[i].desc(hi, 0, 128, y[i], 0, epi, in1=xi, off1=0, c1=256, h=h, aux=aux[i], **kx[i]) for i in range(2)]
         elif epi == EPI_GRU_Q:
-            descs = [cv[i].desc(h, 0, 128, y[i], 64 * i, epi, in1=x, off1=0, c1=256, h=h, z=z) for i in range(2)]
+            if SPLIT:
+                kx = [dict(in0s=hs, in1s=xs, outs=ys[i]) for i in range(2)]
+            descs = [cv[i].desc(hi, 0, 128, y[i], 64 * i, epi, in1=xi, off1=0, c1=256, h=h, z=z, **kx[i]) for i in range(2)]
         else:
-            descs = [cv[i].desc(x, 32 * i, cin, y[i], 0, epi) for i in range(2)]
+            if SPLIT:
+                kx = [dict(in0s=xs, outs=ys[i]) for i in range(2)]
+            descs = [cv[i].desc(xi, 32 * i, cin, y[i], 0, epi, **kx[i]) for i in range(2)]
         lib.conv2d(descs, B, H8, W8, x)
         torch.cuda.synchronize()
         key = f"{name}@{B}x{H8}x{W8}"
         out[key] = torch.cat(y + aux, 1).cpu()
         roles[key] = lib.conv2d_roles(descs, B, H8, W8)
-torch.save({"out": out, "roles": roles}, sys.argv[1])
+        if SPLIT:
+            # columns a launch does not write are zero in both forms, so whole buffers compare
+            twin_ok[key] = all(torch.equal(twin_of(y[i]), ys[i]) for i in range(2)) and \
+                (epi != EPI_GRU_ZR or all(torch.equal(twin_of(aux[i]), auxs[i]) for i in range(2)))
+torch.save({"out": out, "roles": roles, "twin_ok": twin_ok}, sys.argv[1])

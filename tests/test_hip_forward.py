@@ -320,3 +320,29 @@ def test_graph_replays_are_bitwise_stable_at_small_sizes(params, size):
         m = build(True, True)
         bad = sum(int(not torch.equal(m(i1, i2, iters=12, test_mode=True), ref)) for _ in range(24))
     assert bad == 0, f"{bad} of 24 graph replays differ from the single-stream result at {size}"
+
+
+@pytest.mark.parametrize("size,batch", [((256, 512), 1), ((160, 360), 2)])
+def test_presplit_path_is_bitwise_the_fp32_staged_path(params, size, batch, monkeypatch):
+    """The default bf16x3 forward keeps the update blocks' activations as bf16 hi|lo split twins written by the producers'
+    epilogues and runs their convs on the all-DMA kernel (pf_conv_dma_kernel); PRIORFLOW_PRESPLIT=0 keeps fp32 activations
+    and the register-staged kernels.  Same operand bits, same accumulation order: the flows are equal bit for bit
+    (full tiles and a ragged map, graph-captured and eager)."""
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+
+    def run(presplit, graph):
+        monkeypatch.setenv("PRIORFLOW_PRESPLIT", presplit)
+        m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+        m.load_state_dict(params, strict=True)
+        m = m.cuda().eval()
+        m.use_graph = graph
+        with torch.no_grad():
+            return m(i1, i2, iters=4, test_mode=True).clone()
+
+    i1, i2 = gc.synthetic_pair(batch, *size, seed=3)
+    i1, i2 = i1.cuda(), i2.cuda()
+    ref = run("0", False)
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0.1
+    for graph in (False, True):
+        got = run("1", graph)
+        assert torch.equal(got, ref), (graph, float((got - ref).abs().max()))

@@ -303,11 +303,15 @@ def test_corr_pyramid_vs_reference_golden(lib, dev):
 
 
 # ---- update blocks through the engine -----------------------------------------------------------
+@pytest.mark.parametrize("presplit", ["1", "0"])
 @pytest.mark.parametrize("prec", PRECISIONS)
-def test_update_blocks_vs_reference_golden(lib, dev, params, prec):
+def test_update_blocks_vs_reference_golden(lib, dev, params, prec, presplit, monkeypatch):
+    """presplit=1 (default, bf16x3): every MFMA conv of the blocks reads split twins through the all-DMA kernel and the
+    GRU input / motion features exist as twins only; presplit=0: the fp32-staged kernels."""
     import argparse
-    from prior_flow_amd.engine import Engine, Workspace, pack_update_blocks
+    from prior_flow_amd.engine import Engine, Workspace, pack_update_blocks, unsplit
     from prior_flow_amd.prior_raft import PriOr_RAFT
+    monkeypatch.setenv("PRIORFLOW_PRESPLIT", presplit)
     model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
     model.load_state_dict(params)
     model = model.to(dev)
@@ -324,13 +328,22 @@ def test_update_blocks_vs_reference_golden(lib, dev, params, prec):
     ws.flow2_b.copy_(up(ui["flow_a"]))
     ws.corr_a.copy_(up(ui["corr"])); ws.corr_b.copy_(up(ui["corr"]))
     ws.conf_in[:, :4] = up(ui["flaw_a"]); ws.conf_in[:, 4:] = up(ui["flaw_ba"])
+    ps = eng.presplit(P)
+    assert ps == (presplit == "1" and prec != "fp32")
+    if ps:
+        ws.sync_twins(lib)
     cur = eng.update_blocks(ws, P, 0, need_b=True, mask_a=True, mask_b=True)
     torch.cuda.synchronize()
     ga, gb = gc.load("update_A"), gc.load("update_B")
     back = lambda rows: kc.uncl(rows.cpu(), 1, H8, W8)
     tol = 3e-5 if prec == "fp32" else 2e-4
-    kc.check(back(ws.x_a[:, 128:]), ga["motion"], tol, "motion features A")
-    kc.check(back(ws.x_b[:, 128:]), gb["motion"], tol, "motion features B")
+    xa, xb = (unsplit(ws.x_a_s, 256), unsplit(ws.x_b_s, 256)) if ps else (ws.x_a, ws.x_b)
+    kc.check(back(xa[:, 128:]), ga["motion"], tol, "motion features A")
+    kc.check(back(xb[:, 128:]), gb["motion"], tol, "motion features B")
+    if ps:      # the hidden state exists in both forms: the twin is the split of the fp32 rows, bit for bit
+        from prior_flow_amd.engine import split_twin
+        for net, tw in ((ws.net_a[cur], ws.net_a_s[cur]), (ws.net_b[cur], ws.net_b_s[cur])):
+            assert torch.equal(lib.split_bf16(net.contiguous(), split_twin(net.shape[0], 128, dev)), tw)
     kc.check(back(ws.net_a[cur]), ga["net"], tol, "net A")
     kc.check(back(ws.net_b[cur]), gb["net"], tol, "net B")
     kc.check(back(ws.delta_a[:, :2]), ga["delta"], tol, "delta A")
@@ -539,3 +552,25 @@ def test_conv_roles_kernel_matches_symmetric_kernel_bitwise(tmp_path):
         assert torch.isfinite(ref).all() and ref.abs().max() > 0.05, key
         for ws in ("1", "2"):
             assert torch.equal(res[ws]["out"][key], ref), (key, ws, (res[ws]["out"][key] - ref).abs().max().item())
+
+
+@pytest.mark.gpu
+def test_conv_dma_kernel_matches_symmetric_kernel_bitwise(tmp_path):
+    """pf_conv_dma_kernel (operands handed over as split twins, both by LDS-DMA) against the symmetric halo kernel on the
+    same fp32 inputs: the twins hold the bits the fp32 kernels make while staging and the MFMA order per accumulator is the
+    same, so every fp32 output is equal bit for bit; and every output twin equals pf_split_bf16 of the fp32 output."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for tag, env in (("ref", dict(PRIORFLOW_CONV_WS="0")), ("dma", dict(PF_CASE_SPLIT="1"))):
+        path = str(tmp_path / f"{tag}.pt")
+        subprocess.run([sys.executable, os.path.join(here, "run_conv_case.py"), path], check=True,
+                       env=dict(os.environ, **env), timeout=600)
+        res[tag] = torch.load(path)
+    assert set(res["ref"]["roles"].values()) == {0}
+    assert set(res["dma"]["roles"].values()) == {17, 18}, res["dma"]["roles"]         # both tiles of the DMA kernel ran
+    assert all(res["dma"]["twin_ok"].values()), res["dma"]["twin_ok"]
+    for key, ref in res["ref"]["out"].items():
+        got = res["dma"]["out"][key]
+        assert torch.equal(got, ref), (key, (got - ref).abs().max().item())
