@@ -197,6 +197,9 @@ typedef struct pf_conv_desc {
     const void* in1_split; int lds1;
     void* out_split; int lds_out;
     void* aux_split; int lds_aux;
+    /* with in0_split: a block of at least 128 * max(lds0, lds1) zero bytes (16-byte aligned) -- what the all-DMA kernel
+     * reads for the zero padding around the map (an LDS-DMA copies memory; it cannot write a constant) */
+    const void* zeros; int zeros_bytes;
 } pf_conv_desc;
 
 /* The tail of DCCL.__call__ fused with the first motion-encoder convolution (core/corr.py:138,

@@ -55,6 +55,7 @@ class ConvDesc(C.Structure):
         ("in1_split", _fp), ("lds1", _i),
         ("out_split", _fp), ("lds_out", _i),
         ("aux_split", _fp), ("lds_aux", _i),
+        ("zeros", _fp), ("zeros_bytes", _i),
     ]
 
 

@@ -94,11 +94,12 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision
 // PRIORFLOW_CONV_DMA=0 (A/B knob) sends every launch to the register-staged kernels, which need the fp32 operands.
 static int conv_dma_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, int tile_id) {
     static const bool on = [] { const char* e = getenv("PRIORFLOW_CONV_DMA"); return !(e && e[0] == '0'); }();
-    if (!on || !grp.d[0].in0_split || (tile_id != 3 && tile_id != 4)) return 0;
+    if (!on || !grp.d[0].in0_split || tile_id < 3) return 0;
     const bool shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1);
     if (!shape || g.stride != 1) return 0;
     for (int i = 0; i < ngroups; ++i)
         if (grp.d[i].stats_out != nullptr || grp.d[i].in_scale != nullptr) return 0;
+    if (tile_id == 5) return 2;            // Cout <= 64 on a big map (3x3 by conv_tile's rule): the 256 px x 64 channel tile
     const long wgs256 = (long)(g.M / g.N) * ((g.H + 7) / 8) * ((g.W + 31) / 32) * ngroups * ((max_cout + 63) / 64);
     return (g.kh == 3 && max_cout > 64 && wgs256 >= 256) ? 2 : 1;
 }

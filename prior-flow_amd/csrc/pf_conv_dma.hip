@@ -17,7 +17,7 @@
 // LDS images (unpadded 128-byte rows: a DMA instruction writes 1 KiB lane-linear).  The 16-byte pieces of row r sit at
 // piece ^ ((r >> 1) & 7): applied to the per-lane SOURCE address of the DMA and to the fragment reads, conflict-free for
 // ds_read_b128 at any row shift (a tap reads rows shifted by ky*HW + kx).
-//   halo  [2 buffers][HALO_ROWS][128 B]   chunk c in buffer c & 1; rows outside the image read a 128-byte zero block
+//   halo  [2 buffers][HALO_ROWS][128 B]   chunk c in buffer c & 1; rows outside the image read pf_conv_desc.zeros
 //   ring  [4 slots][BN][128 B]            weight tile of step s in slot s & 3
 //
 // Protocol (L = loader waves, M = MFMA waves; barrier(s) opens step s for both):
@@ -37,11 +37,17 @@
 namespace {
 using namespace pfconv;
 
-__device__ __attribute__((aligned(128))) const unsigned pf_dma_zeros[32] = {};      // what a halo row outside the image reads
-
 // pieces of the next chunk's halo issued at tap t: [hbeg(t), hbeg(t+1))
 template <int HP, int HSTEPS>
 constexpr int hbeg_(int t) { return t >= HSTEPS ? HP : HP * t / HSTEPS; }
+
+#ifdef PF_DMA_STAMPS      // diagnostic build only (profiles/microbench_conv_dma.py): s_memtime stamps of workgroup 0, per wave and K-step
+__device__ unsigned long long pf_dma_stamp_buf[8 * 64 * 4 + 4];
+#define PF_DSTAMP(slot) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (blockIdx.x == 0 && lane == 0 && stamp_s < 64) pf_dma_stamp_buf[(wave * 64 + stamp_s) * 4 + (slot)] = t_; } while (0)
+#else
+#define PF_DSTAMP(slot) do {} while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -50,7 +56,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 #endif
 }
 __device__ __forceinline__ void wg_barrier() {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PF_DMA_ABL_NO_BARRIER)
     asm volatile("s_barrier" ::: "memory");
 #endif
 }
@@ -101,23 +107,27 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
         // ================================ loader waves ================================
         const int lw = wave - 4;
         const int lrow = lane >> 3, lpc = lane & 7;
+        // The loaders' stream is a handful of DMA issues per step, but every one of them gates the whole workgroup at the
+        // next barrier, and as the younger wave of its SIMD a loader only gets the issue slots its MFMA partner leaves
+        // (stamps: 150 cycles per DMA instruction, 600-1 100 per step).  Static priority for this half, no per-step flips.
+        __builtin_amdgcn_s_setprio(3);
         // halo: piece j of this wave covers halo rows (lw*HP + j)*8 + lrow; per-lane source offsets in either segment
-        unsigned a_off0[HP], a_off1[HP], a_in = 0;
+        const char* const seg0 = reinterpret_cast<const char*>(d.in0_split) + (long)(d.off0 >> 5) * 128;
+        const char* const seg1 = reinterpret_cast<const char*>(d.in1_split) + (long)(d.off1 >> 5) * 128;
+        long a_off0[HP], a_off1[HP];
 #pragma unroll
         for (int j = 0; j < HP; ++j) {
             const int hr = (lw * HP + j) * 8 + lrow;
             const int yy = y0 + hr / HW - ph, xx = x0 + hr % HW - pw;
             const bool in = hr < HH * HW && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-            const long pix = in ? pix0 + (long)yy * g.W + xx : 0;
-            const unsigned pc = (unsigned)((lpc ^ ((hr >> 1) & 7)) * 16);
-            a_off0[j] = (unsigned)(pix * d.lds0 * 128) + pc;
-            a_off1[j] = (unsigned)(pix * d.lds1 * 128) + pc;
-            a_in |= in ? (1u << j) : 0u;
+            // rows outside the image read the caller's block of zeros (pf_conv_desc.zeros, at least one row of the widest
+            // operand): a piece's source is `uniform base + per-lane offset` either way, no select at issue time
+            const long pix = pix0 + (long)yy * g.W + xx;
+            const long pc = (long)((lpc ^ ((hr >> 1) & 7)) * 16);
+            a_off0[j] = (in ? pix * d.lds0 * 128 : reinterpret_cast<const char*>(d.zeros) - seg0) + pc;
+            a_off1[j] = (in ? pix * d.lds1 * 128 : reinterpret_cast<const char*>(d.zeros) - seg1) + pc;
         }
-        const char* const seg0 = reinterpret_cast<const char*>(d.in0_split) + (long)(d.off0 >> 5) * 128;
-        const char* const seg1 = reinterpret_cast<const char*>(d.in1_split) + (long)(d.off1 >> 5) * 128;
         const int c0chunks = d.c1 > 0 ? d.c0 >> 5 : nchunks;          // chunks of segment 0 (the whole K when there is one segment)
-        const char* const zsrc = reinterpret_cast<const char*>(pf_dma_zeros) + lpc * 16;
         // weights: piece j covers tile rows (lw*WP + j)*8 + lrow
         unsigned b_goff[WP];
 #pragma unroll
@@ -144,7 +154,7 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
             const char* base = s0 ? seg0 + (long)chunk * 128 : seg1 + (long)(chunk - c0chunks) * 128;
             static_for<decltype(J0)::value, decltype(J1)::value>([&](auto J) __attribute__((always_inline)) {
                 constexpr int j = decltype(J)::value;
-                const char* src = ((a_in >> j) & 1u) ? base + (s0 ? a_off0[j] : a_off1[j]) : zsrc;
+                const char* src = base + (s0 ? a_off0[j] : a_off1[j]);
 #if defined(__HIP_DEVICE_COMPILE__)
                 lds_void* dst = (lds_void*)(smem + buf * HALO_BYTES + (lw * HP + j) * 1024);
                 __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
@@ -162,6 +172,14 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
         wait_vmcnt<0>();
         wg_barrier();                                                                  // barrier(P)
         int slot3 = 3;                                                                 // (s + 3) & 3
+#ifdef PF_DMA_STAMPS
+        int stamp_s = 0;
+        if (blockIdx.x == 0 && tid == 256) {
+            unsigned long long t0, r0;
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+            pf_dma_stamp_buf[8 * 64 * 4 + 0] = t0; pf_dma_stamp_buf[8 * 64 * 4 + 1] = r0;
+        }
+#endif
         for (int c = 0; c < nchunks; ++c) {
             const bool ih = c + 1 < nchunks;
             static_for<0, TAPS>([&](auto T) __attribute__((always_inline)) {
@@ -169,21 +187,37 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
                 constexpr int tap3 = (tap + 3) % TAPS, dc3 = (tap + 3) / TAPS;
                 constexpr int h0 = hbeg_<HP, HSTEPS>(tap), h1 = hbeg_<HP, HSTEPS>(tap + 1);
                 constexpr int hc = h1 - h0, hp = tap > 0 ? h0 - hbeg_<HP, HSTEPS>(tap - 1) : 0;
+                PF_DSTAMP(0);
                 wg_barrier();                                                          // barrier(s)
+                PF_DSTAMP(1);
                 const bool iw = c + dc3 < nchunks;
+#ifndef PF_DMA_ABL_NO_DMA          // timing-only ablations (profiles/microbench_conv_dma.py); never defined in the product build
                 if (iw) dma_W(c + dc3, tap3, slot3);
                 if constexpr (hc > 0) {
                     if (ih) dma_H(c + 1, (c + 1) & 1, std::integral_constant<int, h0>{}, std::integral_constant<int, h1>{});
                 }
+#endif
+                PF_DSTAMP(2);
                 if (iw) {
                     if (ih) wait_vmcnt<hp + WP + hc>();
                     else wait_vmcnt<WP>();
                 } else {
                     wait_vmcnt<0>();
                 }
+                PF_DSTAMP(3);
+#ifdef PF_DMA_STAMPS
+                ++stamp_s;
+#endif
                 slot3 = (slot3 + 1) & 3;
             });
         }
+#ifdef PF_DMA_STAMPS
+        if (blockIdx.x == 0 && tid == 256) {
+            unsigned long long t0, r0;
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+            pf_dma_stamp_buf[8 * 64 * 4 + 2] = t0; pf_dma_stamp_buf[8 * 64 * 4 + 3] = r0;
+        }
+#endif
         return;                                             // the epilogue belongs to the MFMA waves (no barrier in it)
     }
 
@@ -204,21 +238,31 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
     // fragments, double buffered in registers: [set][...][piece]; pieces 0,1 = hi K-halves, 2,3 = lo K-halves
     bf16x8 fa[2][2][4], fb[2][NT][4];
     unsigned a_addr[2] = {0, 0}, b_addr = 0;
+    // A fragment of tap (ky, kx), M-tile m: halo row hr = arow0 + (ky + m) * HW + kx, piece P0 at hr*128 + ((P0 ^ swz(hr)) << 4).
+    // These TAPS * 2 offsets are computed once (stamps of the first version: the dependent add / bfe / xor / shift-add chain in
+    // front of a fragment read, inside one MFMA gap, stretched a 768-cycle step to 1 050); per step one add (buffer) and
+    // three XORs (pieces P0+1, P0+4, P0+5) per M-tile remain, all independent.
+    unsigned a_base[TAPS][2];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const unsigned hr = arow0 + (unsigned)((tp / KW + m) * HW + tp % KW);
+            a_base[tp][m] = (hr << 7) + ((P0 ^ ((hr >> 1) & 7u)) << 4);
+        }
     constexpr int NP = 8 + 4 * NT;                          // fragment reads per step
     constexpr int NM = 12 * NT;                             // MFMAs per step
     constexpr int FETCH_GAPS = NM - 2;
-    auto fetch_piece = [&](auto SET, auto P, unsigned halo_off, int ky, int kx, unsigned slot_off) __attribute__((always_inline)) {
-        constexpr int set = decltype(SET)::value, p = decltype(P)::value;
+    auto fetch_piece = [&](auto SET, auto P, unsigned halo_off, auto TAP, unsigned slot_off) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value, p = decltype(P)::value, tp = decltype(TAP)::value;
         if constexpr (p < 8) {
             constexpr int m = p / 4, k = p % 4;
-            if constexpr (k == 0) {                         // piece P0 of halo row hr: hr*128 + ((P0 ^ swz(hr)) << 4)
-                unsigned hr = arow0 + (unsigned)((ky + m) * HW + kx);
-                // (opaque: these addresses are loop invariant per (tap, m, buffer) and hipcc would hoist all 4 * 2 * 2 * TAPS of
-                // them out of the K loop -- 100+ VGPRs, spilled)
+            if constexpr (k == 0) {
+                unsigned a0 = halo_off + a_base[tp][m];
 #if defined(__HIP_DEVICE_COMPILE__)       // (the host pass parses kernel bodies too: device-only constraints / builtins are fenced)
-                asm volatile("" : "+v"(hr));
+                asm volatile("" : "+v"(a0));             // opaque: hipcc would otherwise hoist the XOR variants of every (tap, buffer) too
 #endif
-                a_addr[m] = halo_off + (hr << 7) + ((P0 ^ ((hr >> 1) & 7u)) << 4);
+                a_addr[m] = a0;
             }
             constexpr unsigned x = (k & 1) * 16u + (k >> 1) * 64u;          // pieces P0+1, P0+4, P0+5: XOR on the piece bits
             fa[set][m][k] = *reinterpret_cast<const bf16x8*>(smem + (a_addr[m] ^ x));
@@ -230,31 +274,46 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
         }
     };
     wg_barrier();                                           // barrier(P): the loader waves' prologue is in LDS
-    static_for<0, NP>([&](auto P) { fetch_piece(std::integral_constant<int, 0>{}, P, 0u, 0, 0, 0u); });
+    static_for<0, NP>([&](auto P) { fetch_piece(std::integral_constant<int, 0>{}, P, 0u, std::integral_constant<int, 0>{}, 0u); });
     int slot1 = 1;                                          // (s + 1) & 3
+#ifdef PF_DMA_STAMPS
+    int stamp_s = 0;
+#endif
     auto mstep = [&](auto U, int chunk) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         constexpr int tap = u % TAPS, cur = u & 1;
-        constexpr int ntap = (tap + 1) % TAPS, nky = ntap / KW, nkx = ntap % KW;
+        constexpr int ntap = (tap + 1) % TAPS;
         const int nchunk = (tap == TAPS - 1) ? chunk + 1 : chunk;
         const unsigned halo_off = (unsigned)((nchunk & 1) * HALO_BYTES), slot_off = (unsigned)(slot1 * SLOT_BYTES);
         using NXT = std::integral_constant<int, cur ^ 1>;
+        PF_DSTAMP(0);
         wg_barrier();                 // barrier(s): slot (s+1)&3 and the halo of step s+1 are complete
+        PF_DSTAMP(1);
         static_for<0, NM>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             constexpr int idx = i % (2 * NT), m = idx / NT, t = idx % NT, j = i / (2 * NT), ks = j / 3, pass = j % 3;
+#ifdef PF_DMA_ABL_NO_MFMA
+            if constexpr (pass == 0)                      // keep the fragment reads alive, no matrix work
+                asm volatile("" :: "v"(fa[cur][m][ks]), "v"(fa[cur][m][2 + ks]), "v"(fb[cur][t][ks]), "v"(fb[cur][t][2 + ks]));
+#else
             if constexpr (pass == 0)
                 acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][m][2 + ks], fb[cur][t][ks], acc[m][t], 0, 0, 0);
             else if constexpr (pass == 1)
                 acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][m][ks], fb[cur][t][2 + ks], acc[m][t], 0, 0, 0);
             else
                 acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][m][ks], fb[cur][t][ks], acc[m][t], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#ifndef PF_DMA_ABL_NO_READS
             static_for<0, NP>([&](auto P) __attribute__((always_inline)) {
-                if constexpr (decltype(P)::value * FETCH_GAPS / NP == i) fetch_piece(NXT{}, P, halo_off, nky, nkx, slot_off);
+                if constexpr (decltype(P)::value * FETCH_GAPS / NP == i) fetch_piece(NXT{}, P, halo_off, std::integral_constant<int, ntap>{}, slot_off);
             });
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
+#ifdef PF_DMA_STAMPS
+        ++stamp_s;
+#endif
         slot1 = (slot1 + 1) & 3;
     };
     {
@@ -264,17 +323,32 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
         if (nchunks & 1)
             static_for<0, TAPS>([&](auto U) { mstep(U, nchunks - 1); });
     }
+    PF_DSTAMP(0);                                           // (stamp row nsteps: end of the K loop)
     const bool ragged = (g.W % TW) != 0 || (g.H % TH) != 0;
-    static_for<0, 2>([&](auto M) __attribute__((always_inline)) {      // (a runtime-indexed acc[m] would put the accumulators in scratch)
-        constexpr int m = decltype(M)::value;
+    long p0[2], plim[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
         const int wy = 2 * wy2 + m;
         const bool row_ok = y0 + wy < g.H;
         const int xlim = row_ok ? g.W - x0 - 4 * lh : 0;
-        const long p0 = pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh;
-        if (ragged) tile_epilogue<NT, true>(d, acc[m], n0 + 32 * NT * wn, li, p0, p0 + (xlim > 0 ? xlim : 0));
-        else tile_epilogue<NT, false>(d, acc[m], n0 + 32 * NT * wn, li, p0, 0);
-    });
+        p0[m] = pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh;
+        plim[m] = p0[m] + (xlim > 0 ? xlim : 0);
+    }
+    if (ragged) tile_epilogue_pair<NT, true>(d, acc, n0 + 32 * NT * wn, li, p0, plim);
+    else tile_epilogue_pair<NT, false>(d, acc, n0 + 32 * NT * wn, li, p0, plim);
+#ifdef PF_DMA_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PF_DSTAMP(1);                                           // (stamp row nsteps, slot 1: epilogue stores retired)
+#endif
 }
+
+#ifdef PF_DMA_STAMPS
+}  // namespace
+extern "C" int pf_conv_dma_read_stamps(unsigned long long* out) {   // [8 waves][64 steps][4] + {memtime, realtime} x {loop start, loop end}
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_dma_stamp_buf), sizeof(unsigned long long) * (8 * 64 * 4 + 4));
+}
+namespace {
+#endif
 
 template <int NT, int KH, int KW, int WN>
 int launch_conv_dma_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
@@ -300,12 +374,8 @@ int launch_conv_dma_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int
 
 int pf_conv_dma_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, int nt, int roles,
                        hipStream_t stream) {
-    for (int i = 0; i < ngroups; ++i) {
-        // 32-bit byte offsets into the split twins (the largest map of the path, 32 pairs at 640x1280, needs 0.6 GB)
-        const long rows = (long)g.M;
-        if (rows * grp.d[i].lds0 * 128 >= (1L << 32) || (grp.d[i].c1 > 0 && rows * grp.d[i].lds1 * 128 >= (1L << 32)))
-            return PF_ERR_BAD_SHAPE;
-    }
+    for (int i = 0; i < ngroups; ++i)
+        if (!grp.d[i].zeros || grp.d[i].zeros_bytes < 128 * (grp.d[i].lds0 > grp.d[i].lds1 ? grp.d[i].lds0 : grp.d[i].lds1)) return PF_ERR_BAD_ARG;
     if (roles == 2) {
         if (g.kh == 3 && g.kw == 3) return launch_conv_dma_t<2, 3, 3, 1>(grp, ngroups, g, max_cout, stream);
         return PF_ERR_BAD_SHAPE;

@@ -138,6 +138,113 @@ __device__ __forceinline__ void tile_epilogue_t(const pf_conv_desc& d, const f32
     }
 }
 
+// The same epilogue for the TWO pixel rows of an MFMA wave of the role-specialised kernels (acc[m][t], rows p0[m]), with
+// every operand load of both rows -- bias, and h / z of the GRU kinds -- issued BEFORE the first store.  The per-tile
+// form above alternates loads and stores, and since `out` may alias `h` as far as the compiler knows, each tile's loads
+// wait behind the previous tile's stores: up to four dependent global round trips (s_memtime stamps of
+// pf_conv_dma_kernel: 7 300 cycles from the end of the K loop to the last store retired, a tenth of a GRU launch).
+template <int NT, bool CHECK, bool FAST>
+__device__ __forceinline__ void tile_epilogue_pair_t(const pf_conv_desc& d, const f32x16 (&acc)[2][NT], int jb, int li,
+                                                     const long (&p0)[2], const long (&plimit)[2]) {
+    const int epi = d.epilogue;
+    constexpr auto roff = [](int r) constexpr { return (r & 3) + 8 * (r >> 2); };
+    // compile-time indices throughout (static_for): a runtime-indexed register array would live in scratch
+    float bias[NT];
+    f32x16 hv[2][NT], zv[2][NT];
+    static_for<0, NT>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        const int jt = jb + 32 * t, j = jt + li;
+        const bool jok = j < d.cout;
+        bias[t] = jok ? d.bias[j] : 0.f;
+        const bool need_h = jok && ((epi == PF_EPI_GRU_ZR && jt >= 128) || epi == PF_EPI_GRU_Q);
+        const bool need_z = jok && epi == PF_EPI_GRU_Q;
+        const int hc = epi == PF_EPI_GRU_ZR ? j - 128 : j;
+        static_for<0, 2>([&](auto M) __attribute__((always_inline)) {
+            constexpr int m = decltype(M)::value;
+            if (need_h) {
+                const float* hp = d.h + p0[m] * d.ld_h + hc;
+                static_for<0, 16>([&](auto R) __attribute__((always_inline)) {
+                    constexpr int r = decltype(R)::value;
+                    hv[m][t][r] = (!CHECK || p0[m] + roff(r) < plimit[m]) ? hp[(long)roff(r) * d.ld_h] : 0.f;
+                });
+            }
+            if (need_z) {
+                const float* zp = d.z + p0[m] * d.ld_z + j;
+                static_for<0, 16>([&](auto R) __attribute__((always_inline)) {
+                    constexpr int r = decltype(R)::value;
+                    zv[m][t][r] = (!CHECK || p0[m] + roff(r) < plimit[m]) ? zp[(long)roff(r) * d.ld_z] : 0.f;
+                });
+            }
+        });
+    });
+    static_for<0, 2>([&](auto M) __attribute__((always_inline)) {
+        constexpr int m = decltype(M)::value;
+        const long pm = p0[m], pl = plimit[m];
+        auto put = [&](const f32x16& v, float* base, int ld, int col, void* sbase, int lds) __attribute__((always_inline)) {
+            if (base != nullptr) {
+                float* o = base + pm * ld + col;
+                static_for<0, 16>([&](auto R) __attribute__((always_inline)) {
+                    constexpr int r = decltype(R)::value;
+                    if (!CHECK || pm + roff(r) < pl) o[(long)roff(r) * ld] = v[r];
+                });
+            }
+            if (sbase != nullptr) {
+                char* sp = reinterpret_cast<char*>(sbase) + ((pm * lds + (col >> 5)) * 128 + 2 * (col & 31));
+                const long rs = (long)lds * 128;
+                static_for<0, 16>([&](auto R) __attribute__((always_inline)) {
+                    constexpr int r = decltype(R)::value;
+                    if (!CHECK || pm + roff(r) < pl) pf_store_split(sp + roff(r) * rs, v[r]);
+                });
+            }
+        };
+        static_for<0, NT>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+            const int jt = jb + 32 * t, j = jt + li;
+            if (j < d.cout) {
+                f32x16 v;
+                const float b = bias[t];
+                if (epi == PF_EPI_LINEAR) {
+                    static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = (acc[m][t][r] + b) * d.scale; });
+                    put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
+                } else if (epi == PF_EPI_RELU) {
+                    static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = fmaxf(acc[m][t][r] + b, 0.f); });
+                    put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
+                } else if (epi == PF_EPI_GRU_ZR) {
+                    if (jt < 128) {
+                        static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = pf_sigmoid<FAST>(acc[m][t][r] + b); });
+                        put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
+                    } else {
+                        static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = pf_sigmoid<FAST>(acc[m][t][r] + b) * hv[m][t][r]; });
+                        put(v, d.aux_out, d.ld_aux, j - 128, d.aux_split, d.lds_aux);
+                    }
+                } else if (epi == PF_EPI_TANH_RELU) {
+                    if (jt < 128) {
+                        static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = pf_tanh<FAST>(acc[m][t][r] + b); });
+                        put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
+                    } else {
+                        static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = fmaxf(acc[m][t][r] + b, 0.f); });
+                        put(v, d.aux_out, d.ld_aux, j - 128, d.aux_split, d.lds_aux);
+                    }
+                } else {   // PF_EPI_GRU_Q
+                    static_for<0, 16>([&](auto R) {
+                        constexpr int r = decltype(R)::value;
+                        v[r] = (1.f - zv[m][t][r]) * hv[m][t][r] + zv[m][t][r] * pf_tanh<FAST>(acc[m][t][r] + b);
+                    });
+                    put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
+                }
+            }
+        });
+    });
+}
+
+template <int NT, bool CHECK>
+__device__ __forceinline__ void tile_epilogue_pair(const pf_conv_desc& d, const f32x16 (&acc)[2][NT], int jb, int li,
+                                                   const long (&p0)[2], const long (&plimit)[2]) {
+    const bool gated = d.epilogue == PF_EPI_GRU_ZR || d.epilogue == PF_EPI_GRU_Q || d.epilogue == PF_EPI_TANH_RELU;
+    if (gated && d.precision == PF_PREC_F32) tile_epilogue_pair_t<NT, CHECK, false>(d, acc, jb, li, p0, plimit);
+    else tile_epilogue_pair_t<NT, CHECK, true>(d, acc, jb, li, p0, plimit);
+}
+
 template <int NT, bool CHECK>
 __device__ __forceinline__ void tile_epilogue(const pf_conv_desc& d, const f32x16 (&acc)[NT], int jb, int li,
                                               long p0, long plimit) {

@@ -71,6 +71,17 @@ def split_twin(rows: int, channels: int, device) -> torch.Tensor:
     return torch.zeros(rows, (channels + 31) // 32, 2, 32, dtype=torch.bfloat16, device=device)
 
 
+_ZERO_BLOCKS: Dict[str, torch.Tensor] = {}
+
+
+def _zero_block(device) -> torch.Tensor:
+    """4 KB of zeros per device: pf_conv_desc.zeros (the zero padding around the map, read by the all-DMA conv kernel)."""
+    key = str(device)
+    if key not in _ZERO_BLOCKS:
+        _ZERO_BLOCKS[key] = torch.zeros(1024, dtype=torch.float32, device=device)
+    return _ZERO_BLOCKS[key]
+
+
 def unsplit(twin: torch.Tensor, channels: int) -> torch.Tensor:
     """hi + lo of a split twin as fp32 rows [rows][channels] (tests / debugging; 16 mantissa bits of the original)."""
     v = twin[:, :, 0, :].float() + twin[:, :, 1, :].float()
@@ -165,6 +176,10 @@ class Conv:
             if t is not None:
                 assert t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[2:] == (2, 32) and t.is_contiguous(), name
                 setattr(d, name, t.data_ptr())
+        zb = None
+        if in0s is not None:           # the zero padding of an all-DMA launch is read from memory
+            zb = _zero_block(in0s.device)
+            d.zeros, d.zeros_bytes = zb.data_ptr(), zb.numel() * 4
         d.lds0 = in0s.shape[1] if in0s is not None else 0
         d.lds1 = in1s.shape[1] if in1s is not None else 0
         d.lds_out = outs.shape[1] if outs is not None else 0
@@ -183,7 +198,7 @@ class Conv:
         d.in_relu = int(in_relu)
         d.stats_out = stats.data_ptr() if stats is not None else None
         # the C struct holds raw pointers only: keep every tensor alive for as long as the descriptor is
-        d._keep = (in0, in1, out, h, z, aux, in_scale, in_shift, stats, self.w, self.b, in0s, in1s, outs, auxs)
+        d._keep = (in0, in1, out, h, z, aux, in_scale, in_shift, stats, self.w, self.b, in0s, in1s, outs, auxs, zb)
         return d
 
 

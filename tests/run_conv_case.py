@@ -38,13 +38,15 @@ def twin_of(t):
     return lib.split_bf16(t, split_twin(t.shape[0], t.shape[1], dev))
 
 
-for B, H8, W8 in ((1, 64, 128), (2, 22, 40), (4, 64, 128)):      # full tiles; ragged both ways; enough pixels for the 256-px tile
+for B, H8, W8 in ((1, 64, 128), (2, 22, 40), (4, 64, 128), (8, 64, 128)):      # full tiles; ragged both ways; enough pixels for the 256-px tile; for tile 5
     N = B * H8 * W8
     x = rnd(N, 320)
     h = rnd(N, 128)
     z = torch.rand(N, 128, generator=g).to(dev)
     cases = {"relu3x3_256": (256, 256, 3, 3, EPI_RELU), "lin3x3_192": (128, 192, 3, 3, EPI_LINEAR),
              "zr1x5": (384, 256, 1, 5, EPI_GRU_ZR), "q5x1": (384, 128, 5, 1, EPI_GRU_Q), "lin1x5_96": (96, 128, 1, 5, EPI_LINEAR)}
+    if B == 8:      # 64 output channels on a big map: pf_conv2d_tile 5 (8-row tile) -- the flow stems' 3x3 at batch
+        cases = {"relu3x3_64": (128, 64, 3, 3, EPI_RELU)}
     for name, (cin, cout, kh, kw, epi) in cases.items():
         cv = [conv(cin, cout, kh, kw) for _ in range(2)]           # two groups, like branch A / branch B
         y = [torch.zeros(N, 256, device=dev) for _ in range(2)]

@@ -545,9 +545,10 @@ def test_conv_roles_kernel_matches_symmetric_kernel_bitwise(tmp_path):
         env = dict(os.environ, PRIORFLOW_CONV_WS=ws)
         subprocess.run([sys.executable, os.path.join(here, "run_conv_case.py"), path], check=True, env=env, timeout=600)
         res[ws] = torch.load(path)
-    assert set(res["0"]["roles"].values()) == {0}
-    assert set(res["1"]["roles"].values()) == {1}
-    assert 2 in res["2"]["roles"].values() and 1 in res["2"]["roles"].values()       # both tiles of the default are exercised
+    roles = {ws: {k: v for k, v in res[ws]["roles"].items() if not k.startswith("relu3x3_64")} for ws in res}   # (tile 5: symmetric kernel only)
+    assert set(roles["0"].values()) == {0}
+    assert set(roles["1"].values()) == {1}
+    assert 2 in roles["2"].values() and 1 in roles["2"].values()       # both tiles of the default are exercised
     for key, ref in res["0"]["out"].items():
         assert torch.isfinite(ref).all() and ref.abs().max() > 0.05, key
         for ws in ("1", "2"):
