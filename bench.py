@@ -15,11 +15,13 @@ the parent makes NO GPU call, starts N fresh child processes of this script with
 127.0.0.1, relays rank 0's JSON line and exits with the worst child status.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (MFMA implicit-GEMM conv of the update blocks): algorithmic FLOPs of
-                its launches in one forward / their HIP-event time, vs the dense bf16 MFMA peak (bf16x3
-                mode: 3 MFMA FLOPs per algorithmic FLOP, reported as mfma_pipe_util) or the fp32 MFMA peak;
-  roofline_corr the fused correlation-volume + pyramid build (north_star's HBM target):
-                algorithmic bytes / HIP-event time vs 8 TB/s;
+  roofline      the kernel with the largest summed time of one forward, WHATEVER its kind (every library launch is timed
+                with HIP events in a single-stream eager pass): an MFMA conv -> algorithmic FLOPs / time vs the dense bf16
+                MFMA peak (bf16x3 mode issues 3 MFMA FLOPs per algorithmic FLOP: mfma_pipe_util) or the fp32 MFMA peak;
+                a lookup / corr build -> algorithmic bytes (SURVEY.md 8(d)) / time vs 8 TB/s;
+  roofline_conv / roofline_corr / roofline_lookup / roofline_combine
+                the same object for the dominant MFMA conv, the fused correlation-volume + pyramid build (north_star's
+                HBM target), the DCCL lookup and the fused rotate-back + 1x1; kernels_by_time: the top launches by time;
   cpu_baseline  the CPU oracle (oracle/priorflow_oracle.py, the checker -- never the product)
                 timed on the host cores on the same pair, rank 0 at N=1 only, plus the EPE of
                 the GPU flow against it (`parity`);
@@ -39,10 +41,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
+torch = None     # imported by main() AFTER the self-launch decision: the launching parent never loads torch / the HIP runtime
 
 H, W, ITERS = 512, 1024, 12
-PMC_FILE = "r2_pmc_traffic.json"   # rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py); not re-measured per run
+PMC_FILE = "r3_pmc_traffic.json"   # rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py); not re-measured per run
+STATS_FILE = "r3_final_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this command (graph replay)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
@@ -113,55 +116,96 @@ def pmc_traffic(kernel_substr):
     return None
 
 
+def replay_stats(kernel_substr):
+    """Average duration of a kernel INSIDE the graph replay (where the side streams' kernels share the chip), from the
+    committed rocprofv3 --kernel-trace --stats summary of this command (profiles/STATS_FILE); None when absent."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", STATS_FILE)
+    try:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if kernel_substr in row.get("Name", ""):
+                    return round(float(row["AverageNs"]) / 1e3, 1)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def traffic_fields(kernel_substr):
+    """`traffic` (+ a loud note when the committed PMC passes have no entry for this kernel, e.g. after a rename)."""
+    t = pmc_traffic(kernel_substr)
+    out = {"traffic": t, "traffic_note": "HBM-side bytes/launch from the committed PMC passes (profiles/%s): counters cannot be "
+                                         "read inside this process" % PMC_FILE}
+    if t is None:
+        out["traffic_error"] = "profiles/%s has no entry matching %r -- re-run profiles/pmc_traffic.py" % (PMC_FILE, kernel_substr)
+        log("WARNING: " + out["traffic_error"])
+    return out
+
+
 def profile_kernels(model, i1, i2):
-    """One eager forward with HIP events around every MFMA-conv and corr-build launch."""
+    """One eager, single-stream forward with HIP events around EVERY library launch.  Returns the roofline objects of the bench
+    line: `roofline` is the kernel with the largest summed time over the whole forward (whatever its kind), plus the named
+    ones (`roofline_conv`: the MFMA conv with the largest summed time, `roofline_corr`, `roofline_lookup`) and the table of
+    all kinds by time.  `avg_launch_us` is the kernel ALONE on the chip (one stream, event gap subtracted); `in_replay_us`,
+    where the committed profile has the kernel, is its average inside the captured multi-stream forward."""
     lib = model._lib()
-    recs = []          # (kind, tile, work, start_event, end_event)
-    orig_conv, orig_corr, orig_corr3 = lib.conv2d, lib.corr_pyramid, lib.corr_pyramid_bf16x3
+    recs = []          # (kind, name, work, start_event, end_event)
+    B = i1.shape[0]
 
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
-    def conv2d(descs, B, H8, W8, like):
-        flops = sum(2.0 * B * H8 * W8 * d.cout * d.kh * d.kw * (d.c0 + d.c1) for d in descs)
-        tile = lib.conv2d_tile(descs, B, H8, W8)
+    def conv_name(descs, Bc, H8, W8):
+        tile = lib.conv2d_tile(descs, Bc, H8, W8)
         d0 = descs[0]
-        roles = lib.conv2d_roles(descs, B, H8, W8) if tile in (3, 4) else 0
+        roles = lib.conv2d_roles(descs, Bc, H8, W8) if tile in (3, 4, 5) else 0
         if roles >= 16:    # pre-split operands: the all-DMA kernel, <NT, KH, KW, WN> exactly as rocprof names it
             r = roles - 16
-            tile = "pf_conv_dma_kernel<%d, %d, %d, %d>" % (2 if (tile == 4 or r == 2) else 1, d0.kh, d0.kw, 3 - r)
-        elif roles:        # role-specialised waves: <NT, KH, KW, WN> exactly as rocprof names it
-            tile = "pf_conv_ws_kernel<%d, %d, %d, %d>" % (2 if (tile == 4 or roles == 2) else 1, d0.kh, d0.kw, 3 - roles)
-        elif tile >= 3:    # halo kernel: the instantiation is <NT, KH, KW, AFFINE, TH> exactly as rocprof names it
-            tile = "pf_conv_halo_kernel<%d, %d, %d, %s, %d>" % (
+            return "pf_conv_dma_kernel<%d, %d, %d, %d>" % (2 if (tile >= 4 or r == 2) else 1, d0.kh, d0.kw, 3 - r)
+        if roles:          # role-specialised waves
+            return "pf_conv_ws_kernel<%d, %d, %d, %d>" % (2 if (tile == 4 or roles == 2) else 1, d0.kh, d0.kw, 3 - roles)
+        if tile >= 3:      # halo kernel <NT, KH, KW, AFFINE, TH>
+            return "pf_conv_halo_kernel<%d, %d, %d, %s, %d>" % (
                 1 if tile == 3 else 2, d0.kh, d0.kw, "true" if d0.in_scale else "false", 8 if tile == 5 else 4)
-        else:
-            tile = TILE_NAMES[tile].split(" ")[0][:-1] + (", true>" if d0.precision == 1 else ", false>")
-        s, e = ev(), ev()
-        s.record()
-        orig_conv(descs, B, H8, W8, like)
-        e.record()
-        recs.append(("conv", tile, flops, s, e))
+        return TILE_NAMES[tile].split(" ")[0][:-1] + (", true>" if d0.precision == 1 else ", false>")
 
-    def corr_pyramid(f1, f2, levels, B, H8, W8):
-        n, c = H8 * W8, f1.shape[-1]
-        nbytes = B * (4.0 * n * n * 85.0 / 64.0 + 2.0 * 4.0 * n * c)      # SURVEY.md §8(d)
-        s, e = ev(), ev()
-        s.record()
-        orig_corr(f1, f2, levels, B, H8, W8)
-        e.record()
-        recs.append(("corr", -1, nbytes, s, e))
+    def wrap(attr, kind, name_fn, work_fn):
+        orig = getattr(lib, attr)
 
-    def corr_pyramid_bf16x3(f1s, f2s, levels, B, H8, W8, c):
+        def f(*a, **k):
+            s, e = ev(), ev()
+            s.record()
+            r = orig(*a, **k)
+            e.record()
+            recs.append((kind, name_fn(*a, **k), work_fn(*a, **k), s, e))
+            return r
+        setattr(lib, attr, f)
+        return attr, orig
+
+    def corr_bytes(Bc, H8, W8, c):
         n = H8 * W8
-        nbytes = B * (4.0 * n * n * 85.0 / 64.0 + 2.0 * 4.0 * n * c)      # SURVEY.md §8(d)
-        s, e = ev(), ev()
-        s.record()
-        orig_corr3(f1s, f2s, levels, B, H8, W8, c)
-        e.record()
-        recs.append(("corr", -1, nbytes, s, e))
+        return Bc * (4.0 * n * n * 85.0 / 64.0 + 2.0 * 4.0 * n * c)      # SURVEY.md 8(d)
 
-    lib.conv2d, lib.corr_pyramid, lib.corr_pyramid_bf16x3 = conv2d, corr_pyramid, corr_pyramid_bf16x3
+    px = lambda c: c.shape[0] * c.shape[2] * c.shape[3]  # noqa: E731  (coords [B,2,H8,W8] -> pixels)
+    saved = [
+        wrap("conv2d", "conv", lambda d, Bc, H8, W8, like: conv_name(d, Bc, H8, W8),
+             lambda d, Bc, H8, W8, like: sum(2.0 * Bc * H8 * W8 * x.cout * x.kh * x.kw * (x.c0 + x.c1) for x in d)),
+        wrap("corr_pyramid", "corr", lambda *a: "pf_corr_kernel", lambda f1, f2, lv, Bc, H8, W8: corr_bytes(Bc, H8, W8, f1.shape[-1])),
+        wrap("corr_pyramid_bf16x3", "corr", lambda *a: "pf_corr_kernel", lambda f1, f2, lv, Bc, H8, W8, c: corr_bytes(Bc, H8, W8, c)),
+        # SURVEY.md 8(d), one branch: own 10x10 patch x 4 B x 4 levels read + 324 x 4 B written; cross <= 81 x 4 taps x 4 B x 4
+        # levels read + 324 x 4 B written = 9 376 B per pixel (76.8 MB at 64x128)
+        wrap("dccl_lookup", "lookup", lambda *a, **k: "pf_lookup", lambda coords, *a, **k: px(coords) * (1600.0 + 1296.0 + 5184.0 + 1296.0)),
+        # own row + 4 raw rows read (324 fp32 each), 256 channels written (4 B in either form), per branch
+        wrap("dccl_combine_conv1x1", "combine", lambda *a: "pf_combine_conv_kernel",
+             lambda items, Bc, H8, W8: len(items) * Bc * H8 * W8 * (5 * 1296.0 + 1024.0)),
+        wrap("motion_prep", "other", lambda *a, **k: "pf_motion_prep_kernel", lambda *a, **k: 0.0),
+        wrap("conv2d_direct_group", "other", lambda *a, **k: "pf_stem7x7c2_valu", lambda *a, **k: 0.0),
+        wrap("conf_stem", "other", lambda *a, **k: "pf_conf_stem_kernel", lambda *a, **k: 0.0),
+        wrap("flow_head_out", "other", lambda *a, **k: "pf_flow_out_strip", lambda *a, **k: 0.0),
+        wrap("norm_act", "other", lambda *a, **k: "pf_norm_act_vec", lambda *a, **k: 0.0),
+        wrap("channel_stats_final", "other", lambda *a, **k: "pf_stats_final", lambda *a, **k: 0.0),
+        wrap("channel_stats", "other", lambda *a, **k: "pf_stats_partial+final", lambda *a, **k: 0.0),
+    ]
     was, was_streams = model.use_graph, model.use_streams
     model.use_graph = False
     model.use_streams = False          # one stream: an event interval must contain exactly one kernel
@@ -179,54 +223,67 @@ def profile_kernels(model, i1, i2):
         with torch.no_grad():
             for _ in range(2):          # second pass is the measured one (caches warm)
                 recs.clear()
-                # park the GPU for ~15 ms so the host enqueues the whole eager forward ahead of it:
+                # park the GPU so the host enqueues the whole eager forward ahead of it:
                 # the HIP-event intervals then contain kernel time only, not host launch gaps
                 torch.cuda._sleep(int(30e6))
                 model(i1, i2, iters=ITERS, test_mode=True)
                 torch.cuda.synchronize()
     finally:
-        lib.conv2d, lib.corr_pyramid, lib.corr_pyramid_bf16x3 = orig_conv, orig_corr, orig_corr3
+        for attr, orig in saved:
+            setattr(lib, attr, orig)
         model.use_graph, model.use_streams = was, was_streams
-    by_tile = {}
-    corr_t, corr_b, corr_n = 0.0, 0.0, 0
-    for kind, tile, work, s, e in recs:
+    by = {}            # (kind, name) -> [work, ms, launches]
+    for kind, name, work, s, e in recs:
         ms = max(s.elapsed_time(e) - gap_ms, 1e-4)
-        if kind == "conv":
-            t = by_tile.setdefault(tile, [0.0, 0.0, 0])
-            t[0] += work; t[1] += ms; t[2] += 1
-        else:
-            corr_b += work; corr_t += ms; corr_n += 1
-    dom = max(by_tile, key=lambda k: by_tile[k][1])
-    fl, ms, n = by_tile[dom]
-    all_fl = sum(v[0] for v in by_tile.values())
-    all_ms = sum(v[1] for v in by_tile.values())
-    achieved = fl / (ms * 1e-3) / 1e12
+        t = by.setdefault((kind, name), [0.0, 0.0, 0])
+        t[0] += work; t[1] += ms; t[2] += 1
     from prior_flow_amd._lib import PREC_BF16X3
     split = model._weights()["precision"] == PREC_BF16X3
-    peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-    roofline = {"kernel": str(dom) + (" bf16x3" if split else " fp32"), "bound": "mfma",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4),
-                # the 3-pass split issues 3 bf16 MFMA FLOPs per algorithmic FLOP: pipe utilisation
-                "mfma_issue_tflops": round(achieved * (3 if split else 1), 2),
-                "mfma_pipe_util": round(achieved * (3 if split else 1) / peak, 4),
-                "traffic": pmc_traffic(str(dom)), "traffic_note": "HBM-side bytes/launch from the committed PMC passes (profiles/%s): counters cannot be read inside this process" % PMC_FILE,
-                "launches_per_forward": n, "avg_launch_us": round(ms / n * 1e3, 1),
-                "event_gap_us_subtracted": round(gap_ms * 1e3, 2),
-                "gflop_per_forward": round(fl / 1e9, 1),
-                "all_conv_kernels": {"gflop": round(all_fl / 1e9, 1), "ms": round(all_ms, 3),
-                                     "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}}
-    gbps = corr_b / (corr_t * 1e-3) / 1e9
-    roofline_corr = {"kernel": "pf_corr_kernel<fused pool, %s> (corr volume + 4-level pyramid)" % ("bf16x3" if split else "fp32"),
-                     "bound": "hbm",
-                     "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                     "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("pf_corr_kernel"),
-                     "traffic_note": "HBM-side bytes/launch from the committed PMC passes (profiles/%s)" % PMC_FILE,
-                     "launches_per_forward": corr_n, "avg_launch_us": round(corr_t / corr_n * 1e3, 1),
-                     "mb_per_launch": round(corr_b / corr_n / 1e6, 1),
-                     "note": ("34.4 GFLOP/launch: 3-pass bf16 MFMA + 373 MB of once-written output" if split else
-                              "exact-fp32 MFMA makes this kernel compute-bound (34.4 GFLOP per launch)")}
-    return roofline, roofline_corr
+    peak_mfma = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    how = "avg_launch_us: the kernel alone on the chip (single-stream eager pass, HIP events, dispatch gap subtracted); " \
+          "in_replay_us: its rocprofv3 average inside the captured multi-stream forward (profiles/%s)" % STATS_FILE
+
+    def obj(kind, name):
+        work, ms, n = by[(kind, name)]
+        o = {"kernel": name, "launches_per_forward": n, "avg_launch_us": round(ms / n * 1e3, 1), "in_replay_us": replay_stats(name),
+             "ms_per_forward": round(ms, 3), "timing": how, "event_gap_us_subtracted": round(gap_ms * 1e3, 2)}
+        if kind == "conv":
+            ach = work / (ms * 1e-3) / 1e12
+            o.update({"kernel": name + (" bf16x3" if split else " fp32"), "bound": "mfma", "achieved": round(ach, 2), "peak": peak_mfma,
+                      "unit": "TFLOP/s", "frac": round(ach / peak_mfma, 4),
+                      # the 3-pass split issues 3 bf16 MFMA FLOPs per algorithmic FLOP: pipe utilisation
+                      "mfma_issue_tflops": round(ach * (3 if split else 1), 2),
+                      "mfma_pipe_util": round(ach * (3 if split else 1) / peak_mfma, 4),
+                      "gflop_per_forward": round(work / 1e9, 1)})
+        elif work > 0:
+            gbps = work / (ms * 1e-3) / 1e9
+            o.update({"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                      "frac": round(gbps / PEAK_HBM_GBPS, 4), "mb_per_launch": round(work / n / 1e6, 1),
+                      "bytes": "algorithmic bytes per launch (SURVEY.md 8(d))"})
+        else:
+            o.update({"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None})
+        o.update(traffic_fields(name))
+        return o
+
+    order = sorted(by, key=lambda k: -by[k][1])
+    convs = [k for k in order if k[0] == "conv"]
+    out = {"roofline": obj(*order[0])}
+    out["roofline"]["chosen_as"] = "the kernel with the largest summed time of the forward, all kinds"
+    if convs:
+        out["roofline_conv"] = obj(*convs[0])
+        all_fl = sum(by[k][0] for k in convs)
+        all_ms = sum(by[k][1] for k in convs)
+        out["roofline_conv"]["all_conv_kernels"] = {"gflop": round(all_fl / 1e9, 1), "ms": round(all_ms, 3),
+                                                    "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
+    for kind, key in (("corr", "roofline_corr"), ("lookup", "roofline_lookup"), ("combine", "roofline_combine")):
+        ks = [k for k in order if k[0] == kind]
+        if ks:
+            out[key] = obj(*ks[0])
+    if "roofline_corr" in out:
+        out["roofline_corr"]["note"] = ("34.4 GFLOP/launch: 3-pass bf16 MFMA + 373 MB of once-written output" if split else
+                                        "exact-fp32 MFMA makes this kernel compute-bound (34.4 GFLOP per launch)")
+    out["kernels_by_time"] = [{"kernel": k[1], "kind": k[0], "launches": by[k][2], "ms": round(by[k][1], 3)} for k in order[:12]]
+    return out
 
 
 def cpu_baseline(params, i1, i2, flow_gpu):
@@ -287,13 +344,32 @@ def fp32_reference_point(params, device, i1, i2, ref_cpu, steps=5):
     return out
 
 
+def visible_gpus() -> int:
+    """GPUs this process would see, WITHOUT touching the HIP runtime (on this pool a process that has initialised the GPU must
+    not fork + exec children): the visibility masks first, else the KFD topology (a node with simd_count > 0 is a GPU)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(path):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes; this parent
-    never touches the GPU -- torch.cuda.device_count() does not initialise it) and relay their output."""
+    never touches the GPU -- not even to count devices, see visible_gpus) and relay their output."""
     import socket
     import subprocess
     n = args.gpus
-    have = torch.cuda.device_count()
+    have = visible_gpus()
     rehearsal = os.environ.get("PRIORFLOW_BENCH_BACKEND", "nccl") != "nccl"     # gloo: ranks may share a card
     if have < n and not (rehearsal and have >= 1):
         print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
@@ -301,6 +377,10 @@ def self_launch(args) -> int:
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
+    dump = os.environ.get("PRIORFLOW_BENCH_PARENT_MAPS")        # tests: which shared objects has the launching parent mapped?
+    if dump:
+        with open("/proc/self/maps") as f, open(dump, "w") as o:
+            o.write("\n".join(sorted({ln.split()[-1] for ln in f if ".so" in ln})))
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -317,7 +397,10 @@ def init_ranks(world: int, rank: int, device):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = os.environ.get("PRIORFLOW_BENCH_BACKEND", "nccl")       # nccl == RCCL on ROCm
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    if backend == "nccl":      # bind the communicator to this rank's device eagerly: a bad rendezvous fails here, not in a barrier
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     probe = torch.ones(1, device=device if backend == "nccl" else "cpu")
     dist.all_reduce(probe)                                             # first collective: builds the communicator
     assert int(probe.item()) == world, f"all-reduce over {world} ranks returned {probe.item()}"
@@ -328,6 +411,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    global torch
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -397,17 +482,21 @@ def main():
             "dtype": ("bf16x3 split MFMA, f32 accumulate/storage" if model._weights()["precision"] == 1 else "f32"),
             "data": "synthetic",
             "config": {"workload": f"PriOr-RAFT forward, {args.batch} synthetic 512x1024 ERP pair(s) per GPU per step, "
-                                   "iters=12, test_mode (BASELINE.json configs[1])",
+                                   "iters=12, test_mode (BASELINE.json " + ("configs[1]" if args.batch == 1 else
+                                   "configs[2]" if args.batch == 32 else f"configs[1] at batch {args.batch}") + ")",
                        "pairs_per_gpu_per_step": args.batch, "height": H, "width": W, "iters": ITERS,
                        "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"
                                       + (f"; timing barrier / max over {backend}" if dist is not None else ""),
+                       # what the communicator really saw (a SCALE record shows RCCL spanning N ranks, or that it was a gloo rehearsal)
+                       "collective_backend": backend, "rccl_world": world if backend == "nccl" else None,
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
                        "weights": "deterministic closed-form fill (no checkpoints offline)",
                        "hip_graph": bool(model.use_graph),
                        "encoders": "libpriorflow_hip.so (HIP kernels, both precisions)"},
         }
         try:
             log("per-kernel HIP-event pass")
-            result["roofline"], result["roofline_corr"] = profile_kernels(model, i1, i2)
+            result.update(profile_kernels(model, i1, i2))
         except Exception as exc:  # measured extras must not hide the headline number
             result["roofline"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:

@@ -22,8 +22,9 @@ in BOTH directions, of every heavy operator:
 No convolution, normalisation or GEMM of a training step runs on PyTorch-ROCm kernels (STATS["torch"] stays 0 for the
 reference's configuration: BatchNorm frozen, train_flow.py:107-108).  What torch still does is plumbing on device
 tensors: ReLU / tanh / sigmoid forward, torch.cat / slicing / transposes, the zero-stuffing copy of a stride-2
-gradient, and autograd's own bookkeeping.  A BatchNorm left in training mode (batch statistics) is the one operator
-without a HIP backward: it falls back to F.batch_norm and is counted in STATS["torch"].
+gradient, and autograd's own bookkeeping.  A BatchNorm left in training mode (batch statistics, the `chairs` stage) runs on
+pf_channel_stats / pf_norm_bwd over the whole batch (HipBatchNormTrain); a convolution geometry without a HIP pair raises
+PfError -- there is no PyTorch-ROCm convolution or normalisation fallback (STATS["torch"] only counts what a test injects).
 There is no CPU path: every tensor must live on a ROCm device and ``_lib.load()`` raises when the HIP library
 is missing.  ``args.mixed_precision`` (CUDA autocast + GradScaler in the reference, train_flow.py:112,131-139) has no
 counterpart here: the convolutions run the 3-pass bf16 split with fp32 accumulation and fp32 storage, which needs no
@@ -39,7 +40,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
+import torch.nn.functional as F          # F.pad only (layout plumbing): no convolution / normalisation goes through torch
 
 from . import _lib
 from ._lib import EPI_LINEAR, PREC_BF16X3
@@ -299,11 +300,59 @@ class HipFrozenBatchNorm(torch.autograd.Function):
         return _nchw(dx, B, H, W), dgamma, dbeta, None, None, None
 
 
+class HipBatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm2d in training mode (batch statistics; the reference's `chairs` stage leaves BatchNorm unfrozen,
+    train_flow.py:107-108).  The statistics run over the whole batch, i.e. the channel-last rows [B*H*W][C] are ONE image of
+    B*H*W pixels for pf_channel_stats (forward) and for pf_norm_bwd's InstanceNorm branch (backward:
+    dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat))); d gamma = sum g * xhat and d beta = sum g come from the same
+    kernel's per-channel sums.  The module's running statistics are updated like torch does (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, module):
+        lib = _lib.load()
+        B, Cc, H, W = x.shape
+        n = B * H * W
+        xr = _rows(x.detach())
+        scale = torch.empty(1, Cc, dtype=torch.float32, device=x.device)       # rstd
+        shift = torch.empty(1, Cc, dtype=torch.float32, device=x.device)       # -mean * rstd
+        nblk = 128
+        part = torch.empty(nblk * Cc * 2, dtype=torch.float64, device=x.device)
+        lib.channel_stats(xr, 1, n, Cc, scale, shift, part, nblk, eps=module.eps)
+        STATS["hip"] += 1
+        with torch.no_grad():
+            if module.track_running_stats and module.running_mean is not None:
+                mean = -shift[0] / scale[0]
+                var = 1.0 / (scale[0] * scale[0]) - module.eps
+                mom = module.momentum if module.momentum is not None else 1.0 / float(module.num_batches_tracked + 1)
+                module.running_mean.mul_(1.0 - mom).add_(mom * mean)
+                module.running_var.mul_(1.0 - mom).add_(mom * var * (n / max(n - 1, 1)))
+                module.num_batches_tracked += 1
+        g_ = gamma.detach()
+        ctx.save_for_backward(xr, scale, shift, g_)
+        ctx.shape = x.shape
+        s = (g_ * scale[0]).view(1, -1, 1, 1)
+        t = (beta.detach() + g_ * shift[0]).view(1, -1, 1, 1)
+        return x * s + t
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        xr, scale, shift, gamma = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        n = B * H * W
+        gr = _rows(g)
+        coef = lib.norm_bwd_sums(gr, xr, scale, shift, 1, n, Cc)              # [1, C, 2]: mean g, mean g * xhat
+        dx = torch.empty_like(xr)
+        lib.norm_bwd((gr * gamma.view(1, Cc)).contiguous(), xr, scale, shift, False, True, dx, 1, n, Cc)
+        STATS["hip"] += 2
+        return _nchw(dx, B, H, W), coef[0, :, 1] * n, coef[0, :, 0] * n, None
+
+
 _TAPE = threading.local()       # .gates: id(conv module) -> (token, WeightGrad) of the forward being recorded
 
 
 def conv2d(x: torch.Tensor, m: nn.Conv2d) -> torch.Tensor:
-    """nn.Conv2d.forward of module ``m``: the HIP pair when the geometry is covered, PyTorch-ROCm otherwise."""
+    """nn.Conv2d.forward of module ``m`` on the HIP pair that covers its geometry (PfError when none does)."""
     kh, kw = m.kernel_size
     hip = (m.stride == (1, 1) and (kh, kw) in ((3, 3), (1, 5), (5, 1), (1, 1)) and m.padding == (kh // 2, kw // 2)
            and x.shape[1] % 4 == 0 and m.bias is not None and m.dilation == (1, 1) and m.groups == 1)
@@ -323,8 +372,11 @@ def conv2d(x: torch.Tensor, m: nn.Conv2d) -> torch.Tensor:
     if plain and kh == kw and kh * kw <= 52 and x.shape[1] <= 4 and m.stride in ((1, 1), (2, 2)) \
             and m.weight.shape[0] % 4 == 0 and not x.requires_grad:
         return HipSmallConv.apply(x, m.weight, m.bias, m.stride[0])
-    STATS["torch"] += 1
-    return F.conv2d(x, m.weight, m.bias, stride=m.stride, padding=m.padding)
+    # No second backend inside the product path: a geometry none of the three HIP pairs covers is an error, not a silent
+    # PyTorch-ROCm convolution (every nn.Conv2d of PriOr-RAFT is covered: tests/test_hip_train_step.py).
+    raise _lib.PfError(f"training forward: no HIP kernel pair for Conv2d(kernel={m.kernel_size}, stride={m.stride}, "
+                       f"padding={m.padding}, dilation={m.dilation}, groups={m.groups}, bias={m.bias is not None}) on "
+                       f"{tuple(x.shape)} input")
 
 
 class PyramidGrad:
@@ -573,8 +625,9 @@ def _norm(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
     if isinstance(m, nn.BatchNorm2d):
         if not m.training and m.weight is not None:          # frozen statistics (freeze_bn): the reference's configuration
             return HipFrozenBatchNorm.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps)
-        STATS["torch"] += 1                                   # batch statistics: the one operator left on PyTorch-ROCm
-        return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, m.training, m.momentum, m.eps)
+        if m.training and m.weight is not None:               # batch statistics (the `chairs` stage)
+            return HipBatchNormTrain.apply(x, m.weight, m.bias, m)
+        raise _lib.PfError("BatchNorm2d without affine parameters has no HIP path (the reference's encoders always carry them)")
     raise _lib.PfError(f"unsupported norm layer {type(m).__name__}")
 
 

@@ -24,6 +24,11 @@ from .modules import BasicEncoder, build_tree, state_dict_shapes  # noqa: F401
 
 
 class PriOr_RAFT(nn.Module):
+    """``args.mixed_precision`` is accepted and has no effect: the reference wraps its encoders and update blocks in CUDA
+    autocast (core/prior_raft.py:133,146,190) and scales the loss (train_flow.py:112,136-139); here every GEMM-shaped op runs
+    the 3-pass bf16 split with fp32 accumulation and storage (or exact fp32, ``PRIORFLOW_PRECISION=fp32``), which needs neither.
+    ``args.dropout`` is honoured by the training forward."""
+
     def __init__(self, args):
         super().__init__()
         self.args = args

@@ -211,9 +211,11 @@ SYNC_CHECK_EVERY = 500      # steps between replica checksum comparisons (16-byt
 
 def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criterion: uniform_loss,
                image1: torch.Tensor, image2: torch.Tensor, flow_gt: torch.Tensor, valid: torch.Tensor,
-               iters: int = 12, gamma: float = 0.8, clip: float = 1.0, group=None):
+               iters: int = 12, gamma: float = 0.8, clip: float = 1.0, group=None, add_noise: bool = False):
     """One optimisation step, the loop body of train_flow.py:120-141 (without GradScaler: fp32 / bf16x3 math
-    needs no loss scaling): zero_grad, GT rotation, forward of both branches, sequence loss of both, backward,
+    needs no loss scaling, so `--mixed_precision` has nothing to switch): zero_grad, GT rotation, [`add_noise`
+    (train_flow.py:127-130): Gaussian noise of a standard deviation drawn uniformly from [0, 5) -- numpy's global
+    generator, like the reference -- added to both images, clamped to [0, 255]], forward of both branches, sequence loss of both, backward,
     [one SUM all-reduce of the flat gradient buffer when torch.distributed runs with more than one rank --
     RCCL over xGMI, replacing DataParallel's reduce_add (train_flow.py:96)], clip, AdamW, scheduler.
     ``model`` may be the bare module or an ``nn.DataParallel``-style wrapper exposing ``.module``.
@@ -221,6 +223,11 @@ def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criteri
     net = getattr(model, "module", model)
     optimizer.zero_grad()
     flow_gt_b, valid_b = rotate_gt(flow_gt)
+    if add_noise:
+        import numpy as np
+        stdv = float(np.random.uniform(0.0, 5.0))
+        image1 = (image1 + stdv * torch.randn(*image1.shape, device=image1.device)).clamp(0.0, 255.0)
+        image2 = (image2 + stdv * torch.randn(*image2.shape, device=image2.device)).clamp(0.0, 255.0)
     preds_a, preds_b = net(image1, image2, iters=iters)
     loss_a, metrics_a = criterion(preds_a, flow_gt, valid, gamma, extro_info="A-")
     seeds = list(criterion.grads)

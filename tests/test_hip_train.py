@@ -68,3 +68,38 @@ def test_train_mode_forward_needs_a_device():
     i1, i2 = gc.synthetic_pair(1, 128, 256)
     with pytest.raises(_lib.PfError):
         m(i1, i2, iters=2)
+
+
+def test_batchnorm_batch_statistics_on_hip_matches_torch():
+    """BatchNorm2d left in training mode (the reference's `chairs` stage, train_flow.py:107-108) runs on pf_channel_stats /
+    pf_norm_bwd over the whole batch: output, input / gamma / beta gradients and the running statistics against torch's own
+    batch_norm; and the training forward refuses a convolution geometry it has no HIP pair for instead of calling torch."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from prior_flow_amd import autograd as ag
+    from prior_flow_amd._lib import PfError
+    torch.manual_seed(3)
+    x = (torch.randn(3, 64, 24, 40, device="cuda") * 2.0 + 0.5).requires_grad_(True)
+    bn = nn.BatchNorm2d(64).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    ref = nn.BatchNorm2d(64).cuda().train()
+    ref.load_state_dict(bn.state_dict())
+    w = torch.randn_like(x)
+    ag.STATS["hip"] = ag.STATS["torch"] = 0
+    y = ag._norm(bn, x)
+    (y * w).sum().backward()
+    gx, gw, gb = x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()
+    x.grad = None
+    y2 = F.batch_norm(x, ref.running_mean, ref.running_var, ref.weight, ref.bias, True, ref.momentum, ref.eps)
+    (y2 * w).sum().backward()
+    assert ag.STATS["torch"] == 0 and ag.STATS["hip"] >= 3
+    assert float((y - y2).abs().max()) < 2e-5
+    assert float((gx - x.grad).abs().max()) < 2e-4 * float(x.grad.abs().max() + 1)
+    assert float((gw - ref.weight.grad).abs().max()) < 2e-3 * float(ref.weight.grad.abs().max())
+    assert float((gb - ref.bias.grad).abs().max()) < 2e-3 * float(ref.bias.grad.abs().max())
+    assert float((bn.running_mean - ref.running_mean).abs().max()) < 1e-5
+    assert float((bn.running_var - ref.running_var).abs().max()) < 1e-4
+    conv = nn.Conv2d(64, 64, 3, padding=2, dilation=2).cuda()
+    with pytest.raises(PfError):
+        ag.conv2d(x.detach(), conv)

@@ -112,3 +112,32 @@ def test_bench_self_launch_refuses_without_enough_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "--gpus 64 but only" in r.stderr, (r.returncode, r.stderr[-300:])
+
+
+def test_bench_launching_parent_never_loads_torch_or_hip(tmp_path):
+    """The parent of `python bench.py --gpus N` counts GPUs from the visibility masks / the KFD topology and must not map torch
+    or libamdhip64 (a process that initialised the GPU must not fork + exec on the pool's boxes).  Here the two gloo ranks die
+    at once (no GPU in this container); what is checked is the parent's own list of mapped shared objects."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    maps = tmp_path / "maps.txt"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HIP_VISIBLE_DEVICES="0", PRIORFLOW_BENCH_BACKEND="gloo", PRIORFLOW_BENCH_PARENT_MAPS=str(maps))
+    subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu-baseline"],
+                   env=env, capture_output=True, text=True, timeout=600)
+    mapped = maps.read_text()
+    assert "libamdhip64" not in mapped and "libtorch" not in mapped and "libc" in mapped, mapped[-400:]
+
+
+def test_bench_counts_gpus_without_hip(monkeypatch):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert bench.visible_gpus() >= 0          # KFD topology (none in the build container)
