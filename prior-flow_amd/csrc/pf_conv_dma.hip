@@ -41,14 +41,6 @@ using namespace pfconv;
 template <int HP, int HSTEPS>
 constexpr int hbeg_(int t) { return t >= HSTEPS ? HP : HP * t / HSTEPS; }
 
-#ifdef PF_DMA_STAMPS      // diagnostic build only (profiles/microbench_conv_dma.py): s_memtime stamps of workgroup 0, per wave and K-step
-__device__ unsigned long long pf_dma_stamp_buf[8 * 64 * 4 + 4];
-#define PF_DSTAMP(slot) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-    if (blockIdx.x == 0 && lane == 0 && stamp_s < 64) pf_dma_stamp_buf[(wave * 64 + stamp_s) * 4 + (slot)] = t_; } while (0)
-#else
-#define PF_DSTAMP(slot) do {} while (0)
-#endif
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -60,6 +52,10 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_barrier" ::: "memory");
 #endif
 }
+
+// One unit of work: output-channel tile `ntile` of pixel tile `tile` of convolution `grp`.
+struct DmaItem { int grp, tile, ntile; };
+
 
 template <int NT, int KH, int KW, int WN>
 __global__ void __launch_bounds__(512, 2)
@@ -76,164 +72,208 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
     extern __shared__ __attribute__((aligned(128))) char smem[];
     constexpr int RING = 2 * HALO_BYTES;                    // byte offset of the weight ring
 
-    int grp_i, ntile_i, tile_i;                             // XCD-aware work mapping: see pf_conv_halo_kernel
-    {
-        const unsigned nwg = gridDim.x, orig = blockIdx.x;
-        const unsigned xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
-        const unsigned q = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
-        ntile_i = (int)(q % (unsigned)g.ntn);
-        const unsigned r = q / (unsigned)g.ntn;
-        tile_i = (int)(r % (unsigned)g.ntiles);
-        grp_i = (int)(r / (unsigned)g.ntiles);
-    }
-    pf_conv_desc d = groups.d[0];
-    if (grp_i == 1) d = groups.d[1];
-    else if (grp_i == 2) d = groups.d[2];
-    else if (grp_i == 3) d = groups.d[3];
-    const int n0 = ntile_i * BN;
-    if (n0 >= d.cout) return;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
-    const int x0 = (tile_i % tiles_x) * TW;
-    const int y0 = ((tile_i / tiles_x) % tiles_y) * TH;
-    const long pix0 = (long)(tile_i / (tiles_x * tiles_y)) * g.N;
     constexpr int ph = KH / 2, pw = KW / 2;
     const int nchunks = g.nchunks;
+
+    // ---- the workgroup's items (PERSISTENT: the grid is at most one workgroup per CU) ------------------------------------
+    // Work sequence q = (group, pixel tile in raster order, output-channel tile), channel tile fastest, cut into 8 contiguous
+    // ranges -- one per XCD, like pf_conv_halo_kernel's XCD-aware grid: workgroups that read the same or overlapping halos share
+    // an L2.  The workgroups of an XCD (blockIdx % 8) walk its range with stride = their number.  Items of a group whose Cout
+    // ends before the channel tile are skipped by both roles alike.  The K loop runs THROUGH item boundaries: chunk / step /
+    // ring-slot / halo-buffer counters simply continue, the loaders prefetch the next item's first halo and weight tiles
+    // during the last steps of the current one, and the MFMA waves' epilogue stores drain under the next item's MFMAs.
+    const unsigned total = (unsigned)g.ntiles * (unsigned)g.ntn * (unsigned)g.ngroups;
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3;
+    const unsigned wg_x = (nwg >> 3) + ((nwg & 7) > xcd ? 1u : 0u);                        // workgroups on this XCD
+    const unsigned qd = total >> 3, rem = total & 7;
+    const unsigned q_begin = xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd, q_count = qd + (xcd < rem ? 1u : 0u);
+    // The descriptors through the kernel-argument segment (they are its first bytes): a wave-uniform run-time group index then
+    // is a scalar load -- indexing the by-value `groups` argument would put the struct in scratch memory.
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) pf_conv_desc* desc_ptr;            // constant address space: s_load
+    const desc_ptr gdesc = (desc_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const pf_conv_desc* const gdesc = &groups.d[0];
+#endif
+    // next non-empty item of this workgroup at or after position j (in units of wg_x); false when exhausted
+    auto next_item = [&](unsigned& j, DmaItem& it) -> bool {
+        for (; j < q_count; j += wg_x) {
+            const unsigned q = q_begin + j;
+            const unsigned r = fd_div(q, g.d_ntn);
+            it.ntile = (int)(q - r * (unsigned)g.ntn);
+            it.grp = (int)fd_div(r, g.d_ntiles);
+            it.tile = (int)(r - (unsigned)it.grp * (unsigned)g.ntiles);
+            if (it.ntile * BN < gdesc[it.grp].cout) { j += wg_x; return true; }
+        }
+        return false;
+    };
+    // pixel-tile origin of an item
+    auto tile_origin = [&](const DmaItem& it, int& x0, int& y0, long& pix0) __attribute__((always_inline)) {
+        const unsigned ty_ = fd_div((unsigned)it.tile, g.d_tx);                          // tile / tiles_x
+        x0 = (int)((unsigned)it.tile - ty_ * (unsigned)tiles_x) * TW;
+        const unsigned im = fd_div(ty_, g.d_ty);                                        // image
+        y0 = (int)(ty_ - im * (unsigned)tiles_y) * TH;
+        pix0 = (long)im * g.N;
+    };
 
     if (wave >= 4) {
         // ================================ loader waves ================================
         const int lw = wave - 4;
         const int lrow = lane >> 3, lpc = lane & 7;
         // The loaders' stream is a handful of DMA issues per step, but every one of them gates the whole workgroup at the
-        // next barrier, and as the younger wave of its SIMD a loader only gets the issue slots its MFMA partner leaves
-        // (stamps: 150 cycles per DMA instruction, 600-1 100 per step).  Static priority for this half, no per-step flips.
+        // next barrier, and as the younger wave of its SIMD a loader only gets the issue slots its MFMA partner leaves.
+        // Static priority for this half, no per-step flips.
         __builtin_amdgcn_s_setprio(3);
-        // halo: piece j of this wave covers halo rows (lw*HP + j)*8 + lrow; per-lane source offsets in either segment
-        const char* const seg0 = reinterpret_cast<const char*>(d.in0_split) + (long)(d.off0 >> 5) * 128;
-        const char* const seg1 = reinterpret_cast<const char*>(d.in1_split) + (long)(d.off1 >> 5) * 128;
-        long a_off0[HP], a_off1[HP];
-#pragma unroll
-        for (int j = 0; j < HP; ++j) {
+        // Loader state of the item in flight: source offsets of this lane in every halo piece (either segment), weight row
+        // offsets, segment / weight bases.  ONE set, switched to the next item at the two points where the current item's values
+        // die: the halo offsets at the start of the item's LAST chunk (its last halo was issued during the chunk before; what is
+        // issued during the last chunk is the next item's chunk 0), the weight offsets at the first step whose tile s+3 lies in
+        // the next item.  (A second set selected per item ends up in scratch memory -- and a scratch load's vmcnt(0) would drain
+        // the DMA queue.)  Item-independent per-piece constants are computed once.
+        int h_dyx[HP]; long h_pc[HP];                      // (dy << 16 | dx & 0xffff), or INT_MIN for a row past the halo; piece offset
+        static_for<0, HP>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
             const int hr = (lw * HP + j) * 8 + lrow;
-            const int yy = y0 + hr / HW - ph, xx = x0 + hr % HW - pw;
-            const bool in = hr < HH * HW && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-            // rows outside the image read the caller's block of zeros (pf_conv_desc.zeros, at least one row of the widest
-            // operand): a piece's source is `uniform base + per-lane offset` either way, no select at issue time
-            const long pix = pix0 + (long)yy * g.W + xx;
-            const long pc = (long)((lpc ^ ((hr >> 1) & 7)) * 16);
-            a_off0[j] = (in ? pix * d.lds0 * 128 : reinterpret_cast<const char*>(d.zeros) - seg0) + pc;
-            a_off1[j] = (in ? pix * d.lds1 * 128 : reinterpret_cast<const char*>(d.zeros) - seg1) + pc;
-        }
-        const int c0chunks = d.c1 > 0 ? d.c0 >> 5 : nchunks;          // chunks of segment 0 (the whole K when there is one segment)
-        // weights: piece j covers tile rows (lw*WP + j)*8 + lrow
-        unsigned b_goff[WP];
-#pragma unroll
-        for (int j = 0; j < WP; ++j) {
-            const int r = (lw * WP + j) * 8 + lrow;
-            b_goff[j] = (unsigned)(((long)(n0 + r) * TAPS * nchunks) * 128) + (unsigned)((lpc ^ ((r >> 1) & 7)) * 16);
-        }
-        const char* const wbytes = reinterpret_cast<const char*>(d.weight);
+            h_dyx[j] = hr < HH * HW ? (int)(((unsigned)(hr / HW - ph) << 16) | ((unsigned)(hr % HW - pw) & 0xffffu)) : (int)0x80000000;
+            h_pc[j] = (long)((lpc ^ ((hr >> 1) & 7)) * 16);
+        });
+        long a0[HP], a1[HP];
+        unsigned bg[WP];
+        const char* seg0 = nullptr; const char* seg1 = nullptr; const char* wb = nullptr;
+        int c0s = 0;
+        auto set_halo = [&](const DmaItem& it) __attribute__((always_inline)) {
+            const auto& dd = gdesc[it.grp];
+            const void* in0s = dd.in0_split; const void* in1s = dd.in1_split; const void* zeros = dd.zeros;
+            const int off0 = dd.off0, off1 = dd.off1, c0 = dd.c0, c1 = dd.c1;
+            const long rs0 = (long)dd.lds0 * 128, rs1 = (long)dd.lds1 * 128;
+            int x0, y0; long pix0;
+            tile_origin(it, x0, y0, pix0);
+            seg0 = reinterpret_cast<const char*>(in0s) + (long)(off0 >> 5) * 128;
+            seg1 = reinterpret_cast<const char*>(in1s) + (long)(off1 >> 5) * 128;
+            c0s = c1 > 0 ? c0 >> 5 : nchunks;                     // chunks of segment 0 (the whole K when there is one segment)
+            const long z0 = reinterpret_cast<const char*>(zeros) - seg0, z1 = reinterpret_cast<const char*>(zeros) - seg1;
+            static_for<0, HP>([&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value;
+                const int yy = y0 + (h_dyx[j] >> 16), xx = x0 + (int)(short)(h_dyx[j] & 0xffff);
+                const bool in = h_dyx[j] != (int)0x80000000 && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                // rows outside the image read the caller's block of zeros (pf_conv_desc.zeros, at least one row of the widest
+                // operand): a piece's source is `uniform base + per-lane offset` either way, no select at issue time
+                const long pix = pix0 + (long)yy * g.W + xx;
+                a0[j] = (in ? pix * rs0 : z0) + h_pc[j];
+                a1[j] = (in ? pix * rs1 : z1) + h_pc[j];
+            });
+        };
+        auto set_w = [&](const DmaItem& it) __attribute__((always_inline)) {
+            wb = reinterpret_cast<const char*>(gdesc[it.grp].weight);
+            const int n0 = it.ntile * BN;
+            static_for<0, WP>([&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value;
+                const int r = (lw * WP + j) * 8 + lrow;
+                bg[j] = (unsigned)(((long)(n0 + r) * TAPS * nchunks) * 128) + (unsigned)((lpc ^ ((r >> 1) & 7)) * 16);
+            });
+        };
         typedef __attribute__((address_space(3))) void lds_void;
         auto dma_W = [&](int chunk, int tap, int slot) __attribute__((always_inline)) {
-            const char* wp = wbytes + ((long)tap * nchunks + chunk) * 128;            // wave-uniform
-#pragma unroll
-            for (int j = 0; j < WP; ++j) {
+            const char* wp = wb + ((long)tap * nchunks + chunk) * 128;                // wave-uniform
+            static_for<0, WP>([&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value;
 #if defined(__HIP_DEVICE_COMPILE__)
                 lds_void* dst = (lds_void*)(smem + RING + slot * SLOT_BYTES + (lw * WP + j) * 1024);
-                __builtin_amdgcn_global_load_lds(wp + b_goff[j], dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(wp + bg[j], dst, 16, 0, 0);
 #else
                 (void)wp; (void)slot;
 #endif
-            }
-        };
-        auto dma_H = [&](int chunk, int buf, auto J0, auto J1) __attribute__((always_inline)) {
-            const bool s0 = chunk < c0chunks;                                        // wave-uniform: a chunk lies in ONE segment
-            const char* base = s0 ? seg0 + (long)chunk * 128 : seg1 + (long)(chunk - c0chunks) * 128;
-            static_for<decltype(J0)::value, decltype(J1)::value>([&](auto J) __attribute__((always_inline)) {
-                constexpr int j = decltype(J)::value;
-                const char* src = base + (s0 ? a_off0[j] : a_off1[j]);
-#if defined(__HIP_DEVICE_COMPILE__)
-                lds_void* dst = (lds_void*)(smem + buf * HALO_BYTES + (lw * HP + j) * 1024);
-                __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-#else
-                (void)src; (void)buf;
-#endif
             });
         };
+        auto dma_H = [&](int chunk, int buf, auto J0, auto J1) __attribute__((always_inline)) {
+            // a chunk lies in ONE segment (wave-uniform): two straight-line versions
+            if (chunk < c0s) {
+                const char* base = seg0 + (long)chunk * 128;
+                static_for<decltype(J0)::value, decltype(J1)::value>([&](auto J) __attribute__((always_inline)) {
+                    constexpr int j = decltype(J)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    lds_void* dst = (lds_void*)(smem + buf * HALO_BYTES + (lw * HP + j) * 1024);
+                    __builtin_amdgcn_global_load_lds(base + a0[j], dst, 16, 0, 0);
+#else
+                    (void)base; (void)buf;
+#endif
+                });
+            } else {
+                const char* base = seg1 + (long)(chunk - c0s) * 128;
+                static_for<decltype(J0)::value, decltype(J1)::value>([&](auto J) __attribute__((always_inline)) {
+                    constexpr int j = decltype(J)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    lds_void* dst = (lds_void*)(smem + buf * HALO_BYTES + (lw * HP + j) * 1024);
+                    __builtin_amdgcn_global_load_lds(base + a1[j], dst, 16, 0, 0);
+#else
+                    (void)base; (void)buf;
+#endif
+                });
+            }
+        };
         using I0 = std::integral_constant<int, 0>;
-        // prologue: halo 0 and weight tiles 0, 1, 2; everything landed before the first fetch
-        dma_H(0, 0, I0{}, std::integral_constant<int, HP>{});
+        unsigned j = wslot;
+        DmaItem it, nit;
+        if (!next_item(j, it)) return;                                                 // (the MFMA waves leave the same way)
+        bool have_next = next_item(j, nit);
+        // prologue: weight tiles 0, 1, 2 and halo 0 of the first item (the weights first: their addresses are the cheaper ones);
+        // everything landed before the first fetch
+        set_w(it);
         dma_W(0, 0, 0);
         dma_W(1 / TAPS, 1 % TAPS, 1);
         dma_W(2 / TAPS, 2 % TAPS, 2);
+        set_halo(it);
+        dma_H(0, 0, I0{}, std::integral_constant<int, HP>{});
         wait_vmcnt<0>();
         wg_barrier();                                                                  // barrier(P)
-        int slot3 = 3;                                                                 // (s + 3) & 3
-#ifdef PF_DMA_STAMPS
-        int stamp_s = 0;
-        if (blockIdx.x == 0 && tid == 256) {
-            unsigned long long t0, r0;
-            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
-            pf_dma_stamp_buf[8 * 64 * 4 + 0] = t0; pf_dma_stamp_buf[8 * 64 * 4 + 1] = r0;
+        int slot3 = 3;                                                                 // (s + 3) & 3 of the global step counter
+        int gc = 0;                                                                    // global chunk counter (halo buffer = gc & 1)
+        for (bool have = true; have;) {
+            for (int c = 0; c < nchunks; ++c, ++gc) {
+                const bool more_c = c + 1 < nchunks;
+                const bool ih = more_c || have_next;                                   // a next chunk exists (here or in the next item)
+                if (!more_c && have_next) set_halo(nit);                               // the item's own halo offsets are dead from here
+                static_for<0, TAPS>([&](auto T) __attribute__((always_inline)) {
+                    constexpr int tap = decltype(T)::value;
+                    constexpr int tap3 = (tap + 3) % TAPS, dc3 = (tap + 3) / TAPS;
+                    constexpr int h0 = hbeg_<HP, HSTEPS>(tap), h1 = hbeg_<HP, HSTEPS>(tap + 1);
+                    constexpr int hc = h1 - h0, hp = tap > 0 ? h0 - hbeg_<HP, HSTEPS>(tap - 1) : 0;
+                    wg_barrier();                                                      // barrier(s)
+                    const bool in_cur = c + dc3 < nchunks;
+                    const bool iw = in_cur || have_next;
+                    if constexpr (tap == TAPS - 3) {                                   // first step whose tile s + 3 is in the next item
+                        if (!more_c && have_next) set_w(nit);
+                    }
+                    if (iw) dma_W(in_cur ? c + dc3 : c + dc3 - nchunks, tap3, slot3);
+                    if constexpr (hc > 0) {
+                        if (ih) dma_H(more_c ? c + 1 : 0, (gc + 1) & 1, std::integral_constant<int, h0>{}, std::integral_constant<int, h1>{});
+                    }
+                    if (iw) {
+                        if (ih) wait_vmcnt<hp + WP + hc>();
+                        else wait_vmcnt<WP>();
+                    } else {
+                        wait_vmcnt<0>();
+                    }
+                    slot3 = (slot3 + 1) & 3;
+                });
+            }
+            have = have_next;
+            if (have) have_next = next_item(j, nit);
         }
-#endif
-        for (int c = 0; c < nchunks; ++c) {
-            const bool ih = c + 1 < nchunks;
-            static_for<0, TAPS>([&](auto T) __attribute__((always_inline)) {
-                constexpr int tap = decltype(T)::value;
-                constexpr int tap3 = (tap + 3) % TAPS, dc3 = (tap + 3) / TAPS;
-                constexpr int h0 = hbeg_<HP, HSTEPS>(tap), h1 = hbeg_<HP, HSTEPS>(tap + 1);
-                constexpr int hc = h1 - h0, hp = tap > 0 ? h0 - hbeg_<HP, HSTEPS>(tap - 1) : 0;
-                PF_DSTAMP(0);
-                wg_barrier();                                                          // barrier(s)
-                PF_DSTAMP(1);
-                const bool iw = c + dc3 < nchunks;
-#ifndef PF_DMA_ABL_NO_DMA          // timing-only ablations (profiles/microbench_conv_dma.py); never defined in the product build
-                if (iw) dma_W(c + dc3, tap3, slot3);
-                if constexpr (hc > 0) {
-                    if (ih) dma_H(c + 1, (c + 1) & 1, std::integral_constant<int, h0>{}, std::integral_constant<int, h1>{});
-                }
-#endif
-                PF_DSTAMP(2);
-                if (iw) {
-                    if (ih) wait_vmcnt<hp + WP + hc>();
-                    else wait_vmcnt<WP>();
-                } else {
-                    wait_vmcnt<0>();
-                }
-                PF_DSTAMP(3);
-#ifdef PF_DMA_STAMPS
-                ++stamp_s;
-#endif
-                slot3 = (slot3 + 1) & 3;
-            });
-        }
-#ifdef PF_DMA_STAMPS
-        if (blockIdx.x == 0 && tid == 256) {
-            unsigned long long t0, r0;
-            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
-            pf_dma_stamp_buf[8 * 64 * 4 + 2] = t0; pf_dma_stamp_buf[8 * 64 * 4 + 3] = r0;
-        }
-#endif
-        return;                                             // the epilogue belongs to the MFMA waves (no barrier in it)
+        return;                                             // the epilogues belong to the MFMA waves (no barrier in them)
     }
 
     // ================================== MFMA waves ==================================
     const int wy2 = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;     // pixel rows 2*wy2, 2*wy2 + 1; channel part wn
     f32x16 acc[2][NT];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
-    // fragment addressing (byte offsets into smem).  A: halo row of M-tile m at tap (0, 0); B: this lane's 4 pieces of tile 0.
+    // fragment addressing (byte offsets into smem).  A: halo row of M-tile m at tap (0, 0); B: this lane's piece P0 of tile 0
+    // (the four pieces of a lane differ in the piece bits only: base ^ {0, 16, 64, 80}).  None of it depends on the item.
     const unsigned arow0 = (unsigned)((2 * wy2) * HW + li);
     const unsigned P0 = 2u * lh;
-    // (the four pieces of a lane differ in the piece bits only: base ^ {0, 16, 64, 80})
     const unsigned b_off = (unsigned)(32 * NT * wn + li) * 128 + ((P0 ^ (((unsigned)(32 * NT * wn + li) >> 1) & 7u)) << 4);
     // fragments, double buffered in registers: [set][...][piece]; pieces 0,1 = hi K-halves, 2,3 = lo K-halves
     bf16x8 fa[2][2][4], fb[2][NT][4];
@@ -243,13 +283,22 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
     // front of a fragment read, inside one MFMA gap, stretched a 768-cycle step to 1 050); per step one add (buffer) and
     // three XORs (pieces P0+1, P0+4, P0+5) per M-tile remain, all independent.
     unsigned a_base[TAPS][2];
+    auto set_a_base = [&]() __attribute__((always_inline)) {
+        // recomputed per item from an opaque copy of the row: 2 * TAPS registers that are NOT live across the epilogue (with the
+        // accumulators and the GRU operands it otherwise spills)
+        unsigned ar = arow0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(ar));
+#endif
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp)
+        for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const unsigned hr = arow0 + (unsigned)((tp / KW + m) * HW + tp % KW);
-            a_base[tp][m] = (hr << 7) + ((P0 ^ ((hr >> 1) & 7u)) << 4);
-        }
+            for (int m = 0; m < 2; ++m) {
+                const unsigned hr = ar + (unsigned)((tp / KW + m) * HW + tp % KW);
+                a_base[tp][m] = (hr << 7) + ((P0 ^ ((hr >> 1) & 7u)) << 4);
+            }
+    };
+    set_a_base();
     constexpr int NP = 8 + 4 * NT;                          // fragment reads per step
     constexpr int NM = 12 * NT;                             // MFMAs per step
     constexpr int FETCH_GAPS = NM - 2;
@@ -273,22 +322,21 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
             fb[set][t][k] = *reinterpret_cast<const bf16x8*>(smem + (b_addr ^ x) + t * 4096);
         }
     };
+    unsigned jm = wslot;
+    DmaItem it;
+    if (!next_item(jm, it)) return;
     wg_barrier();                                           // barrier(P): the loader waves' prologue is in LDS
-    static_for<0, NP>([&](auto P) { fetch_piece(std::integral_constant<int, 0>{}, P, 0u, std::integral_constant<int, 0>{}, 0u); });
-    int slot1 = 1;                                          // (s + 1) & 3
-#ifdef PF_DMA_STAMPS
-    int stamp_s = 0;
-#endif
-    auto mstep = [&](auto U, int chunk) __attribute__((always_inline)) {
+    static_for<0, NP>([&](auto P) __attribute__((always_inline)) { fetch_piece(std::integral_constant<int, 0>{}, P, 0u, std::integral_constant<int, 0>{}, 0u); });
+    int slot1 = 1;                                          // (s + 1) & 3 of the global step counter
+    int gc = 0;                                             // global chunk counter
+    auto mstep = [&](auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         constexpr int tap = u % TAPS, cur = u & 1;
         constexpr int ntap = (tap + 1) % TAPS;
-        const int nchunk = (tap == TAPS - 1) ? chunk + 1 : chunk;
-        const unsigned halo_off = (unsigned)((nchunk & 1) * HALO_BYTES), slot_off = (unsigned)(slot1 * SLOT_BYTES);
+        // the halo of step s + 1: this chunk's buffer, or the next chunk's (of this item or the next one) after the last tap
+        const unsigned halo_off = (unsigned)(((tap == TAPS - 1 ? gc + 1 : gc) & 1) * HALO_BYTES), slot_off = (unsigned)(slot1 * SLOT_BYTES);
         using NXT = std::integral_constant<int, cur ^ 1>;
-        PF_DSTAMP(0);
         wg_barrier();                 // barrier(s): slot (s+1)&3 and the halo of step s+1 are complete
-        PF_DSTAMP(1);
         static_for<0, NM>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             constexpr int idx = i % (2 * NT), m = idx / NT, t = idx % NT, j = i / (2 * NT), ks = j / 3, pass = j % 3;
@@ -304,51 +352,62 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
                 acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][m][ks], fb[cur][t][ks], acc[m][t], 0, 0, 0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-#ifndef PF_DMA_ABL_NO_READS
             static_for<0, NP>([&](auto P) __attribute__((always_inline)) {
                 if constexpr (decltype(P)::value * FETCH_GAPS / NP == i) fetch_piece(NXT{}, P, halo_off, std::integral_constant<int, ntap>{}, slot_off);
             });
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
-#ifdef PF_DMA_STAMPS
-        ++stamp_s;
-#endif
         slot1 = (slot1 + 1) & 3;
+        if constexpr (tap == TAPS - 1) ++gc;
     };
-    {
-        int c2 = 0;
-        for (; c2 + 1 < nchunks; c2 += 2)
-            static_for<0, 2 * TAPS>([&](auto U) { mstep(U, c2 + decltype(U)::value / TAPS); });
-        if (nchunks & 1)
-            static_for<0, TAPS>([&](auto U) { mstep(U, nchunks - 1); });
-    }
-    PF_DSTAMP(0);                                           // (stamp row nsteps: end of the K loop)
     const bool ragged = (g.W % TW) != 0 || (g.H % TH) != 0;
-    long p0[2], plim[2];
+    bool have = true;
+    while (have) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int wy = 2 * wy2 + m;
-        const bool row_ok = y0 + wy < g.H;
-        const int xlim = row_ok ? g.W - x0 - 4 * lh : 0;
-        p0[m] = pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh;
-        plim[m] = p0[m] + (xlim > 0 ? xlim : 0);
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+        {
+            int c2 = 0;
+            for (; c2 + 1 < nchunks; c2 += 2)
+                static_for<0, 2 * TAPS>([&](auto U) __attribute__((always_inline)) { mstep(U); });
+            if (nchunks & 1)
+                static_for<0, TAPS>([&](auto U) __attribute__((always_inline)) { mstep(U); });
+        }
+        // ---- epilogue of this item (stores are not waited for: they drain under the next item's MFMAs) ----
+        const auto& dd = gdesc[it.grp];
+        pf_conv_desc d;                      // the fields the epilogue reads (scalar loads)
+        d.bias = dd.bias; d.out = dd.out; d.ld_out = dd.ld_out; d.off_out = dd.off_out; d.cout = dd.cout;
+        d.epilogue = dd.epilogue; d.scale = dd.scale; d.h = dd.h; d.ld_h = dd.ld_h; d.z = dd.z; d.ld_z = dd.ld_z;
+        d.aux_out = dd.aux_out; d.ld_aux = dd.ld_aux; d.precision = dd.precision;
+        d.out_split = dd.out_split; d.lds_out = dd.lds_out; d.aux_split = dd.aux_split; d.lds_aux = dd.lds_aux;
+        const int n0 = it.ntile * BN;
+        int x0, y0; long pix0;
+        tile_origin(it, x0, y0, pix0);
+        long p0[2], plim[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int wy = 2 * wy2 + m;
+            const bool row_ok = y0 + wy < g.H;
+            const int xlim = row_ok ? g.W - x0 - 4 * lh : 0;
+            p0[m] = pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh;
+            plim[m] = p0[m] + (xlim > 0 ? xlim : 0);
+        }
+        if (ragged) tile_epilogue_pair<NT, true>(d, acc, n0 + 32 * NT * wn, li, p0, plim);
+        else tile_epilogue_pair<NT, false>(d, acc, n0 + 32 * NT * wn, li, p0, plim);
+        have = next_item(jm, it);
+        // The fragments of the next item's first step were fetched during this item's last step, but keeping them (64 VGPRs)
+        // alive across the epilogue (accumulators + GRU operands) does not fit the register file: fetch them again -- their
+        // halo buffer and ring slot were retired before barrier(s_last) and nothing rewrites them before barrier(s_last + 2).
+        if (have) {
+            set_a_base();
+            const unsigned hoff = (unsigned)((gc & 1) * HALO_BYTES), soff = (unsigned)(((slot1 + 3) & 3) * SLOT_BYTES);
+            static_for<0, NP>([&](auto P) __attribute__((always_inline)) { fetch_piece(std::integral_constant<int, 0>{}, P, hoff, std::integral_constant<int, 0>{}, soff); });
+        }
     }
-    if (ragged) tile_epilogue_pair<NT, true>(d, acc, n0 + 32 * NT * wn, li, p0, plim);
-    else tile_epilogue_pair<NT, false>(d, acc, n0 + 32 * NT * wn, li, p0, plim);
-#ifdef PF_DMA_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PF_DSTAMP(1);                                           // (stamp row nsteps, slot 1: epilogue stores retired)
-#endif
 }
-
-#ifdef PF_DMA_STAMPS
-}  // namespace
-extern "C" int pf_conv_dma_read_stamps(unsigned long long* out) {   // [8 waves][64 steps][4] + {memtime, realtime} x {loop start, loop end}
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_dma_stamp_buf), sizeof(unsigned long long) * (8 * 64 * 4 + 4));
-}
-namespace {
-#endif
 
 template <int NT, int KH, int KW, int WN>
 int launch_conv_dma_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, hipStream_t stream) {
@@ -361,7 +420,20 @@ int launch_conv_dma_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int
     gg.ntiles = B * ((g.H + TH - 1) / TH) * ((g.W + 31) / 32);
     gg.ntn = (max_cout + BN - 1) / BN;
     gg.xcd_map = 1;
-    const dim3 grid((unsigned)((long)gg.ntiles * gg.ntn * ngroups));
+    gg.ngroups = ngroups;
+    gg.d_ntn = fd_make((unsigned)gg.ntn); gg.d_ntiles = fd_make((unsigned)gg.ntiles);
+    gg.d_tx = fd_make((unsigned)((g.W + 31) / 32)); gg.d_ty = fd_make((unsigned)((g.H + TH - 1) / TH));
+    // persistent: at most one workgroup per CU (the kernel's LDS footprint admits no second one), each walking its share of
+    // the work sequence; PRIORFLOW_DMA_WGS (A/B knob) overrides the cap, 0 = one workgroup per item
+    static const int cus = [] {
+        const char* e = getenv("PRIORFLOW_DMA_WGS");
+        if (e) return atoi(e);
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n;
+    }();
+    const long items = (long)gg.ntiles * gg.ntn * ngroups;
+    const dim3 grid((unsigned)((cus > 0 && items > cus) ? cus : items));
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&pf_conv_dma_kernel<NT, KH, KW, WN>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

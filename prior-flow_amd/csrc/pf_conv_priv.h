@@ -19,8 +19,26 @@ constexpr int MAX_GROUPS = 4;
 
 struct ConvGroups { pf_conv_desc d[MAX_GROUPS]; };
 
+// n / d for a run-time d fixed per launch, without the ~25-instruction division expansion: t = mulhi(n, m);
+// q = (t + ((n - t) >> s1)) >> s2  (round-up method; exact for every 32-bit n).  Host: fd_make(d).
+struct FastDiv { unsigned m, s1, s2; };
+inline FastDiv fd_make(unsigned d) {
+    FastDiv f{0u, 0u, 0u};
+    if (d <= 1) return f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.m = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+    f.s1 = 1; f.s2 = s - 1;
+    return f;
+}
+__device__ __forceinline__ unsigned fd_div(unsigned n, const FastDiv& f) {
+    const unsigned t = __umulhi(n, f.m);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 struct ConvGeom { int M, H, W, N; int taps, nchunks, cin_pad, kh, kw; int stride, Hin, Win, Nin;
-                  int ntn, ntiles, xcd_map; };   // halo kernels: output-channel tiles, pixel tiles (all images), XCD-aware 1-D grid
+                  int ntn, ntiles, xcd_map;      // halo kernels: output-channel tiles, pixel tiles (all images), XCD-aware 1-D grid
+                  int ngroups; FastDiv d_ntn, d_ntiles, d_tx, d_ty; };   // pf_conv_dma_kernel: work-sequence decode
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -53,6 +71,35 @@ __device__ __forceinline__ void pf_store_split(char* p, float v) {
     const __bf16 lo = (__bf16)(v - (float)hi);
     *reinterpret_cast<__bf16*>(p) = hi;
     *reinterpret_cast<__bf16*>(p + 64) = lo;
+}
+
+// 16 accumulator rows of one output channel per lane -> split twin, TWO channels per store.  In the accumulator layout a
+// lane owns one channel, so the natural twin store is a 2-byte store per value and half (32 per tile, 64-byte segments): the
+// stamps / traces of the first pre-split build showed those stores costing more than the fp32 rows they replace (the fused
+// combine + 1x1 went from 41 to 60 us).  Here lanes 2c / 2c+1 swap half of their rows (one DPP quad permute per pair of rows):
+// the even lane ends up with channels (2c, 2c+1) of rows 0..7, the odd lane with the same channels of rows 8..15, each pair
+// converted with one packed cvt and stored as ONE dword per half -- 16 stores per tile, same bits.
+// `sp`: address of the hi half of this lane's EVEN channel at row p0; rs: row stride in bytes; CHECK: rows >= plimit are dead.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool CHECK, class V>
+__device__ __forceinline__ void pf_store_split_pairs(char* sp, long rs, const V& v, bool odd, long p0, long plimit) {
+    static_for<0, 8>([&](auto K) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;
+        const float send = odd ? v[k] : v[k + 8];
+        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+        const f32x2 ab = {odd ? recv : v[k], odd ? v[k + 8] : recv};            // (even channel, odd channel) of this lane's row
+        constexpr int ro = (k & 3) + 8 * (k >> 2);                              // row offset of accumulator register k; k + 8 is 16 rows further
+        const long row = ro + (odd ? 16 : 0);
+        const bf16x2 hi = __builtin_convertvector(ab, bf16x2);
+        const f32x2 rest = ab - __builtin_convertvector(hi, f32x2);
+        const bf16x2 lo = __builtin_convertvector(rest, bf16x2);
+        if (!CHECK || p0 + row < plimit) {
+            char* q = sp + row * rs;
+            *reinterpret_cast<bf16x2*>(q) = hi;
+            *reinterpret_cast<bf16x2*>(q + 64) = lo;
+        }
+    });
 }
 
 // Fused epilogue of a wave's NT 32x32 accumulators.  acc[t][r] is output channel jb + 32 t + li

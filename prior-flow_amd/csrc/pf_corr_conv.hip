@@ -16,6 +16,7 @@
 #include "pf_common.h"
 #include "pf_elem.h"
 #include "pf_split.h"
+#include "pf_conv_priv.h"
 #include "../../include/priorflow_hip.h"
 
 namespace {
@@ -208,13 +209,12 @@ pf_combine_conv_kernel(const CombGroups groups, const int B, const int H, const 
                     if (prow + pr < rows) o[(long)pr * d.ld_out] = fmaxf(acc[m][t][r] + bias, 0.f);
                 }
             }
-            if (d.out_split != nullptr) {              // split twin for the DMA-fed 3x3 that follows (convc2)
-                char* sp = pf_split_ptr(d.out_split, prow, d.lds_out, d.off_out + ch);
+            if (d.out_split != nullptr) {              // split twin for the DMA-fed 3x3 that follows (convc2): two channels per store
+                float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pr = (r & 3) + 8 * (r >> 2);
-                    if (prow + pr < rows) pf_split_store(sp + (long)pr * d.lds_out * 128, fmaxf(acc[m][t][r] + bias, 0.f));
-                }
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[m][t][r] + bias, 0.f);
+                char* sp = pf_split_ptr(d.out_split, prow, d.lds_out, (d.off_out + ch) & ~1);
+                pfconv::pf_store_split_pairs<true>(sp, (long)d.lds_out * 128, v, (ch & 1) != 0, prow, rows);
             }
         }
     }
