@@ -150,6 +150,8 @@ int pf_conf_stem(const float* in, int ld_in, int off_in, const float* w1, const 
 #define PF_EPI_GRU_Q 3    /* q = tanh(.); out = (1-z)*h + z*q                              */
 #define PF_EPI_TANH_RELU 4 /* cout [0,128): out = tanh(.); [128,256): aux_out = relu(.)
                             * (net / inp split of the context features, core/prior_raft.py:136-142) */
+#define PF_EPI_RELU_RES 5  /* out = relu(res + relu(acc + bias)), res = h[.., j] (ld_h): the tail of a ResidualBlock whose
+                            * norm2 is an eval-mode BatchNorm folded into the weights (core/extractor.py:41-47) */
 
 /* Arithmetic of pf_conv2d (pf_conv_desc.precision); the weight buffer format follows it. */
 #define PF_PREC_F32 0     /* exact fp32 MFMA; weights fp32 [Cout_pad][KH*KW][Cin_pad]                 */

@@ -169,6 +169,14 @@ __device__ __forceinline__ void tile_epilogue_t(const pf_conv_desc& d, const f32
                 for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[t][r] + bias, 0.f);
                 put(v, d.aux_out, d.ld_aux, j - 128, d.aux_split, d.lds_aux);
             }
+        } else if (epi == PF_EPI_RELU_RES) {
+            const float* hp = d.h + p0 * d.ld_h + j;
+            float hv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[r] = live(r) ? hp[(long)roff(r) * d.ld_h] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(hv[r] + fmaxf(acc[t][r] + bias, 0.f), 0.f);
+            put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
         } else {   // PF_EPI_GRU_Q:  h' = (1 - z) h + z tanh(v)
             const float* zp = d.z + p0 * d.ld_z + j;
             const float* hp = d.h + p0 * d.ld_h + j;
@@ -203,7 +211,7 @@ __device__ __forceinline__ void tile_epilogue_pair_t(const pf_conv_desc& d, cons
         const int jt = jb + 32 * t, j = jt + li;
         const bool jok = j < d.cout;
         bias[t] = jok ? d.bias[j] : 0.f;
-        const bool need_h = jok && ((epi == PF_EPI_GRU_ZR && jt >= 128) || epi == PF_EPI_GRU_Q);
+        const bool need_h = jok && ((epi == PF_EPI_GRU_ZR && jt >= 128) || epi == PF_EPI_GRU_Q || epi == PF_EPI_RELU_RES);
         const bool need_z = jok && epi == PF_EPI_GRU_Q;
         const int hc = epi == PF_EPI_GRU_ZR ? j - 128 : j;
         static_for<0, 2>([&](auto M) __attribute__((always_inline)) {
@@ -272,6 +280,9 @@ __device__ __forceinline__ void tile_epilogue_pair_t(const pf_conv_desc& d, cons
                         static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = fmaxf(acc[m][t][r] + b, 0.f); });
                         put(v, d.aux_out, d.ld_aux, j - 128, d.aux_split, d.lds_aux);
                     }
+                } else if (epi == PF_EPI_RELU_RES) {
+                    static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = fmaxf(hv[m][t][r] + fmaxf(acc[m][t][r] + b, 0.f), 0.f); });
+                    put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
                 } else {   // PF_EPI_GRU_Q
                     static_for<0, 16>([&](auto R) {
                         constexpr int r = decltype(R)::value;

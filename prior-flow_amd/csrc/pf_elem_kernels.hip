@@ -864,7 +864,14 @@ int launch_upsample_bwd(const PfUpsampleBwdArgs& a, long total, void* stream) {
 #ifdef PF_LOOKUP_WAVES
 #define PF_LOOKUP_LAUNCH(a, total, stream) launch_lookup(a, total, stream)
 #else
-#define PF_LOOKUP_LAUNCH(a, total, stream) pf_launch_elem<PfLookupArgs, pf_lookup_elem>(a, total, stream)
+// the wave-cooperative window kernel (pf_lookup.hip) takes the launch unless PRIORFLOW_LOOKUP_WIN=0; pf_lookup_elem is the
+// scalar statement it is bit-identical to (and what the host emulation runs)
+int pf_lookup_win_launch(const PfLookupArgs& a, void* stream);
+static int pf_lookup_dispatch(const PfLookupArgs& a, long total, void* stream) {
+    const int rc = pf_lookup_win_launch(a, stream);
+    return rc == -100 ? pf_launch_elem<PfLookupArgs, pf_lookup_elem>(a, total, stream) : rc;
+}
+#define PF_LOOKUP_LAUNCH(a, total, stream) pf_lookup_dispatch(a, total, stream)
 #endif
 #define PF_REGION_SUM_LAUNCH(a, stream) launch_region_sums(a, stream)
 #define PF_SEQ_LOSS_LAUNCH(a, stream) launch_seq_loss(a, stream)

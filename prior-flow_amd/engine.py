@@ -24,7 +24,7 @@ import torch
 
 import os
 
-from ._lib import (EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_RELU, PREC_BF16X3, PREC_F32,
+from ._lib import (EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_RELU, EPI_RELU_RES, PREC_BF16X3, PREC_F32,
                    ConvDesc, PfError, PfLib)
 
 CORR_CH = 324
@@ -136,6 +136,20 @@ class Conv:
         w, b = pack_mfma(mod.weight, mod.bias, cin_to)
         return Conv(w, b, mod.weight.shape[2], mod.weight.shape[3], max(mod.weight.shape[1], cin_to),
                     mod.weight.shape[0], precision)
+
+    @staticmethod
+    def folded(mod, bn, precision=PREC_F32, weight: Optional[torch.Tensor] = None) -> "Conv":
+        """conv followed by an eval-mode BatchNorm as ONE convolution: BN(conv(x)) = conv'(x) with w' = w * s[cout],
+        b' = b * s + t, s = gamma / sqrt(running_var + eps), t = beta - running_mean * s (core/extractor.py:41-47,112-147 with
+        norm_fn='batch' in eval mode, core/prior_raft.py:43-48).  `weight`: an already re-laid-out kernel of `mod`
+        (the space-to-depth form of the 7x7 stem) with the same output channels."""
+        w = (mod.weight if weight is None else weight).detach().float()
+        sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+        sh = (bn.bias - bn.running_mean * sc).detach().float()
+        wf = w * sc.view(-1, 1, 1, 1)
+        bf = mod.bias.detach().float() * sc + sh
+        wp, bp = pack_mfma(wf, bf)
+        return Conv(wp, bp, wf.shape[2], wf.shape[3], wf.shape[1], wf.shape[0], precision)
 
     @staticmethod
     def dgrad_of(weight: torch.Tensor, precision=PREC_F32) -> "Conv":
@@ -766,6 +780,20 @@ class EncoderPlan:
         self.final = Conv.of(enc.conv2, precision)             # 1x1 128 -> 256
         self._bn_cache: Dict[int, tuple] = {}
         self._bufs = None
+        # cnet in bf16x3 mode: every BatchNorm (eval) is folded into the convolution in front of it, ReLU and the residual add
+        # move into the conv epilogues (PF_EPI_RELU / PF_EPI_RELU_RES), and the stride-1 3x3 convs read split twins through the
+        # all-DMA kernel -- no normalisation pass, no statistics kernel, no input affine.  PRIORFLOW_FOLD_BN=0: the unfolded plan.
+        self.fold = (self.kind == "batch" and precision == PREC_BF16X3 and os.environ.get("PRIORFLOW_FOLD_BN", "1") != "0"
+                     and os.environ.get("PRIORFLOW_PRESPLIT", "1") != "0")
+        if self.fold:
+            self.f_stem = Conv.folded(enc.conv1, enc.norm1, precision, weight=stem_s2d_weight(enc.conv1.weight))
+            self.f_blocks = []
+            for blk_mod, item in zip([b for layer in (enc.layer1, enc.layer2, enc.layer3) for b in layer], self.blocks):
+                f = {"stride": item["stride"], "cin": item["cin"], "cout": item["cout"],
+                     "c1": Conv.folded(blk_mod.conv1, blk_mod.norm1, precision), "c2": Conv.folded(blk_mod.conv2, blk_mod.norm2, precision)}
+                if item["stride"] != 1:
+                    f["ds"] = Conv.folded(blk_mod.downsample[0], blk_mod.norm3, precision)
+                self.f_blocks.append(f)
 
     # BatchNorm(eval) -> constant per-channel affine, replicated per image
     def _bn_affine(self, bn, Bn):
@@ -829,6 +857,8 @@ class EncoderPlan:
         outs / auxs: optional split twins of out / aux (with auxs given, aux may be None)."""
         lib = self.lib
         Bn, _, H, W = images.shape
+        if self.fold:
+            return self._run_folded(images, out, epilogue, aux, outs, auxs)
         self._alloc(Bn, H, W)
         bufs = self._bufs
         h, w = H // 2, W // 2
@@ -871,5 +901,56 @@ class EncoderPlan:
                 lib.norm_act(y2, s2, t2, o, Bn, Np, cout, res=x)
             x = o
         # final 1x1 conv 128 -> 256 (core/extractor.py:151)
+        d = self.final.desc(x, 0, 128, out, 0, epilogue, aux=aux, outs=outs, auxs=auxs)
+        lib.conv2d([d], Bn, h, w, x)
+
+    # ---- cnet with folded BatchNorm (bf16x3) ---------------------------------------------------------------------------
+    def _alloc_folded(self, Bn, H, W):
+        key = ("fold", Bn, H, W)
+        if self._bufs is not None and self._bufs["key"] == key:
+            return
+        z = lambda *s_: torch.zeros(*s_, dtype=torch.float32, device=self.dev)  # noqa: E731
+        b = {"key": key, "s2d": z(Bn * (H // 2) * (W // 2), 12)}
+        for lvl, (h, w, c) in enumerate(((H // 2, W // 2, 64), (H // 4, W // 4, 96), (H // 8, W // 8, 128))):
+            rows = Bn * h * w
+            # block inputs / outputs exist in both forms (fp32: residual operand, stride-2 convs, final 1x1; twin: the 3x3 convs);
+            # the intermediate y1 as a twin only; r = the folded downsample branch of a stride-2 block
+            b[f"x{lvl}"] = [z(rows, c), z(rows, c)]
+            b[f"xs{lvl}"] = [split_twin(rows, c, self.dev), split_twin(rows, c, self.dev)]
+            b[f"y{lvl}"] = split_twin(rows, c, self.dev)
+            b[f"r{lvl}"] = z(rows, c)
+        self._bufs = b
+
+    def _run_folded(self, images, out, epilogue, aux, outs, auxs):
+        lib = self.lib
+        Bn, _, H, W = images.shape
+        self._alloc_folded(Bn, H, W)
+        bufs = self._bufs
+        h, w = H // 2, W // 2
+        lib.space_to_depth2(images, bufs["s2d"])
+        x, xs = bufs["x0"][0], bufs["xs0"][0]
+        lib.conv2d([self.f_stem.desc(bufs["s2d"], 0, 12, x, 0, EPI_RELU, outs=xs)], Bn, h, w, x)
+        lvl, cur = 0, 0
+        for f in self.f_blocks:
+            cin, cout, st = f["cin"], f["cout"], f["stride"]
+            if st != 1:
+                x_in = x                                    # fp32 input of the two stride-2 convs
+                lvl += 1
+                h, w = h // 2, w // 2
+                cur = 0
+                y, r = bufs[f"y{lvl}"], bufs[f"r{lvl}"]
+                o, os_ = bufs[f"x{lvl}"][0], bufs[f"xs{lvl}"][0]
+                lib.conv2d([f["c1"].desc(x_in, 0, cin, None, 0, EPI_RELU, stride=st, outs=y)], Bn, h, w, x_in)
+                lib.conv2d([f["ds"].desc(x_in, 0, cin, r, 0, EPI_LINEAR, stride=st)], Bn, h, w, x_in)
+                res = r
+            else:
+                y = bufs[f"y{lvl}"]
+                o, os_ = bufs[f"x{lvl}"][cur ^ 1], bufs[f"xs{lvl}"][cur ^ 1]
+                lib.conv2d([f["c1"].desc(None, 0, cin, None, 0, EPI_RELU, in0s=xs, outs=y)], Bn, h, w, x)
+                res = x
+                cur ^= 1
+            # conv2 + folded norm2 + ReLU, residual add + ReLU in the epilogue (core/extractor.py:44-47)
+            lib.conv2d([f["c2"].desc(None, 0, cout, o, 0, EPI_RELU_RES, in0s=y, h=res, outs=os_)], Bn, h, w, o)
+            x, xs = o, os_
         d = self.final.desc(x, 0, 128, out, 0, epilogue, aux=aux, outs=outs, auxs=auxs)
         lib.conv2d([d], Bn, h, w, x)

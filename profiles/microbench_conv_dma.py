@@ -75,6 +75,33 @@ def descs(name, split):
     return out
 
 
+if "l1" in which:      # encoder layer-1 conv: 3x3 64 -> 64 at 1/2 resolution, MB_BATCH images (fnet: 4, cnet: 2), one group
+    which = [w for w in which if w != "l1"]
+    Bl, Hl, Wl = int(os.environ.get("MB_BATCH", "4")), 256, 512
+    Nl = Bl * Hl * Wl
+    xl = rnd(Nl, 64); yl = torch.zeros(Nl, 64, device=dev)
+    xls, yls = twin_of(xl), split_twin(Nl, 64, dev)
+    cv = conv(64, 64, 3, 3)
+    forms = {"dma": [cv.desc(None, 0, 64, yl, 0, EPI_RELU, in0s=xls, outs=yls)], "halo": [cv.desc(xl, 0, 64, yl, 0, EPI_RELU)]}
+    flops = 2.0 * Nl * 64 * 9 * 64
+    for k, d in forms.items():
+        for _ in range(3):
+            lib.conv2d(d, Bl, Hl, Wl, xl)
+    torch.cuda.synchronize()
+    tm = {k: [] for k in forms}
+    for _ in range(5):
+        for k, d in forms.items():
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for _ in range(reps):
+                lib.conv2d(d, Bl, Hl, Wl, xl)
+            e_.record()
+            torch.cuda.synchronize()
+            tm[k].append(s_.elapsed_time(e_) * 1e3 / reps)
+    for k in forms:
+        t = sorted(tm[k])
+        print(f"l1 x{Bl} {k:4s} tile {lib.conv2d_tile(forms[k], Bl, Hl, Wl)} roles {lib.conv2d_roles(forms[k], Bl, Hl, Wl):2d}  median {t[2]:6.1f} us  "
+              f"{flops / t[2] / 1e6:6.1f} TFLOP/s algorithmic  (x3 = {3 * flops / t[2] / 1e6 / 2500:.3f} of the bf16 pipe)")
 CONVS = {n: [conv(*SHAPES[n][:4]) for _ in range(2)] for n in which}
 ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 for name in which:

@@ -330,6 +330,8 @@ def test_presplit_path_is_bitwise_the_fp32_staged_path(params, size, batch, monk
     (full tiles and a ragged map, graph-captured and eager)."""
     from prior_flow_amd.prior_raft import PriOr_RAFT
 
+    monkeypatch.setenv("PRIORFLOW_FOLD_BN", "0")      # cnet's folded BatchNorm (default with presplit) is different arithmetic: excluded here
+
     def run(presplit, graph):
         monkeypatch.setenv("PRIORFLOW_PRESPLIT", presplit)
         m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))

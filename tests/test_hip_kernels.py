@@ -575,3 +575,47 @@ def test_conv_dma_kernel_matches_symmetric_kernel_bitwise(tmp_path):
     for key, ref in res["ref"]["out"].items():
         got = res["dma"]["out"][key]
         assert torch.equal(got, ref), (key, (got - ref).abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 64, 128), (2, 24, 40), (1, 17, 27)])
+def test_lookup_window_kernel_matches_per_thread_kernel_bitwise(dev, shape, tmp_path):
+    """pf_lookup_win_kernel (a wave per pixel: shared x / y tap geometry, cooperative window loads through LDS;
+    PRIORFLOW_LOOKUP_WIN=1, read once per process -> child process) against the per-thread statement pf_lookup_elem, which
+    pf_dccl_lookup_pair always launches: same bits for both outputs, planar and
+    interleaved grid, on coordinates that exercise every edge rule (negative and multi-wrap x, x in (W-1, W), y far outside,
+    exact integers, flows of +-W/2) and on maps with odd pyramid levels."""
+    import subprocess
+    import sys
+    code = "import os, sys, torch; sys.path[:0] = [%r, %r]; import test_hip_kernels as t; from prior_flow_amd import _lib; " \
+           "t._lookup_window_case(_lib.load(), torch.device('cuda:0'), %r)" % (
+               os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), tuple(shape))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PRIORFLOW_LOOKUP_WIN="1"), timeout=600)
+
+
+def _lookup_window_case(lib, dev, shape):
+    B, H8, W8 = shape
+    N = H8 * W8
+    g = torch.Generator().manual_seed(5)
+    base = torch.stack(torch.meshgrid(torch.arange(H8, dtype=torch.float32), torch.arange(W8, dtype=torch.float32), indexing="ij")[::-1])
+    flow = (torch.rand(B, 2, H8, W8, generator=g) - 0.5) * 24.0
+    flow[:, :, ::3, ::5] = torch.round(flow[:, :, ::3, ::5])                   # exact integers
+    flow[:, 0, 1::4] += 2.5 * W8                                              # multi-wrap
+    flow[:, 0, 2::4] -= 1.75 * W8                                             # negative
+    flow[:, 1, :, 3::7] += 3.0 * H8                                           # far below
+    flow[:, 1, :, 5::7] -= 2.0 * H8                                           # far above
+    coords = (base[None] + flow).contiguous()
+    coords[:, 0, 0, :4] = torch.tensor([W8 - 0.5, W8 - 1.0, -0.25, W8 + 0.0])
+    pyr = [[torch.randn(B * N, (H8 >> l) * (W8 >> l), generator=g).to(dev) for l in range(4)] for _ in range(4)]
+    grid = torch.stack([torch.rand(H8, W8, generator=g) * (W8 + 4) - 2, torch.rand(H8, W8, generator=g) * (H8 + 4) - 2]).to(dev).contiguous()
+    g_il = grid.reshape(2, -1).t().contiguous()
+    co = coords.to(dev)
+    for il in (None, g_il):
+        out = [torch.full((B * N, 324), float("nan"), device=dev) for _ in range(8)]
+        lib.dccl_lookup(co, pyr[0], pyr[1], grid, out[0], out[1], il)
+        lib.dccl_lookup(co, pyr[2], pyr[3], grid, out[2], out[3], il)
+        lib.dccl_lookup_pair([(co, pyr[0], pyr[1], grid, out[4], out[5], il), (co, pyr[2], pyr[3], grid, out[6], out[7], il)])
+        torch.cuda.synchronize()
+        for k in range(4):
+            assert torch.isfinite(out[k]).all()
+            assert torch.equal(out[k], out[4 + k]), (k, il is not None, float((out[k] - out[4 + k]).abs().max()))
