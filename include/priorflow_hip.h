@@ -42,6 +42,12 @@ int pf_sample_grid(float* grid, int H, int W, const float* R_host, void* stream)
 int pf_img_rotate(const float* img, const float* grid, float* out, int B, int C, int H, int W,
                   void* stream);
 
+/* Input normalisation `2 * (image / 255.0) - 1.0` of both images (core/prior_raft.py:121-122; IEEE division, as the
+ * reference's CPU path), written straight into the encoders' batches: image1 -> f1 and (optional) c1, image2 -> f2.
+ * count = B*3*H*W elements per image. */
+int pf_normalise_images(const float* image1, const float* image2, float* f1, float* f2, float* c1,
+                        long count, void* stream);
+
 /* flow = coords1 - coords_grid (core/prior_raft.py:172,177).  coords1: planar.  flow_out
  * (planar) and the two channel-last destinations are optional (NULL to skip). */
 int pf_flow_prep(const float* coords1, float* flow_out,

@@ -74,6 +74,7 @@ class DirectDesc(C.Structure):
 _SIGNATURES = {
     "pf_sample_grid": [_fp, _i, _i, C.POINTER(C.c_float), _fp],
     "pf_img_rotate": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_normalise_images": [_fp, _fp, _fp, _fp, _fp, C.c_long, _fp],
     "pf_flow_prep": [_fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_flo_rotate": [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_corr_pyramid": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
@@ -215,6 +216,15 @@ class PfLib:
         self._rc(self._dll.pf_img_rotate(_ptr(img), _ptr(grid), _ptr(out), B, Cc, H, W,
                                          self._stream(img)), "pf_img_rotate")
         return out
+
+    def normalise_images(self, image1, image2, f1, f2, c1=None):
+        """2 * (image / 255.0) - 1.0 of both images into the encoders' batches (image1 -> f1 and c1, image2 -> f2)."""
+        self._chk(image1, image2, f1, f2, c1)
+        n = image1.numel()
+        if not (image2.numel() == f1.numel() == f2.numel() == n and (c1 is None or c1.numel() == n)):
+            raise PfError("normalise_images: operand sizes differ")
+        self._rc(self._dll.pf_normalise_images(_ptr(image1), _ptr(image2), _ptr(f1), _ptr(f2), _ptr(c1), n,
+                                               self._stream(image1)), "pf_normalise_images")
 
     def flow_prep(self, coords1, flow_out=None, d0=None, d0_off=0, d1=None, d1_off=0):
         self._chk(coords1, flow_out, d0, d1)

@@ -260,6 +260,19 @@ PF_HD void pf_img_rotate_elem(long idx, const PfImgRotArgs& a) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// input normalisation 2 * (image / 255.0) - 1.0 of both images (core/prior_raft.py:121-122), written straight into the
+// encoders' batches: image1 -> f1 and c1 (feature and context batch), image2 -> f2
+// ----------------------------------------------------------------------------------------------
+struct PfNormImgArgs { const float* image1; const float* image2; float* f1; float* f2; float* c1; };
+PF_HD float pf_norm255(float v) { return 2.f * (v / 255.0f) - 1.0f; }
+PF_HD void pf_normalise_images_elem(long idx, const PfNormImgArgs& a) {
+    const float v1 = pf_norm255(a.image1[idx]);
+    a.f1[idx] = v1;
+    if (a.c1) a.c1[idx] = v1;
+    a.f2[idx] = pf_norm255(a.image2[idx]);
+}
+
+// ----------------------------------------------------------------------------------------------
 // flow = coords1 - coords0, scattered to planar + up to two channel-last destinations
 // (core/prior_raft.py:172,177; coords_grid core/utils/utils.py:98-101)
 // ----------------------------------------------------------------------------------------------

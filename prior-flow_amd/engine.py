@@ -284,8 +284,6 @@ class Workspace:
         self.g_a2b_8_il = self.g_a2b_8.reshape(2, -1).t().contiguous() if il else None
         self.g_b2a_8_il = self.g_b2a_8.reshape(2, -1).t().contiguous() if il else None
         # ---- encoders' side
-        self.img_stack = z(B, 6, H, W)
-        self.img_rot = z(B, 6, H, W)
         # fnet output of the 4 images (f1A, f2A, f1B, f2B), one row block each
         self.f_all = z(4 * rows, 256)
         self.f = {k: self.f_all[i * rows:(i + 1) * rows] for i, k in enumerate(("f1a", "f2a", "f1b", "f2b"))}
@@ -378,13 +376,20 @@ class Engine:
         return self.presplit_on and P["precision"] == PREC_BF16X3
 
     # ---- stage 0: view B images --------------------------------------------------------------
-    def rotate_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
-        """img_rotate(cat[image1,image2], A2B) (core/prior_raft.py:127).  Inputs already
-        normalised to [-1,1].  Returns views (image1_B, image2_B)."""
-        ws.img_stack[:, :3].copy_(image1)
-        ws.img_stack[:, 3:].copy_(image2)
-        self.lib.img_rotate(ws.img_stack, ws.g_a2b, ws.img_rot)
-        return ws.img_rot[:, :3], ws.img_rot[:, 3:]
+    def prepare_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
+        """Input stage (core/prior_raft.py:121-127): 2 * (image / 255) - 1 of both images and img_rotate of the pair into
+        view B, written straight into the encoders' batches ws.img_f = [im1 | im2 | im1_B | im2_B] and
+        ws.img_c = [im1 | im1_B]: three launches (normalise, rotate, one copy) and no torch arithmetic."""
+        B = ws.B
+        if tuple(image1.shape) != tuple(ws.img_f[:B].shape) or image2.shape != image1.shape:
+            raise PfError(f"prepare_images: images {tuple(image1.shape)} / {tuple(image2.shape)} do not fit the workspace")
+        image1 = image1.contiguous().float()
+        image2 = image2.contiguous().float()
+        self.lib.normalise_images(image1, image2, ws.img_f[:B], ws.img_f[B:2 * B], ws.img_c[:B])
+        # rotating [im1 | im2] as a batch of 2B three-channel images gives [im1_B | im2_B] in place of the reference's
+        # six-channel stack: the sample grid has no batch dimension
+        self.lib.img_rotate(ws.img_f[:2 * B], ws.g_a2b, ws.img_f[2 * B:])
+        ws.img_c[B:].copy_(ws.img_f[2 * B:3 * B])
 
     # ---- stage 1: corr volumes + pyramids (the encoders write the channel-last features themselves) ----------
     def build_pyramids(self, ws: Workspace, precision: int = PREC_F32):

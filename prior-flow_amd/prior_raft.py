@@ -116,16 +116,11 @@ class PriOr_RAFT(nn.Module):
         inp = relu(cnet[128:]) for both views."""
         from ._lib import EPI_LINEAR, EPI_TANH_RELU
         B = ws.B
-        image1 = 2 * (image1 / 255.0) - 1.0
-        image2 = 2 * (image2 / 255.0) - 1.0
-        image1_b, image2_b = eng.rotate_images(ws, image1, image2)
+        eng.prepare_images(ws, image1, image2)      # normalise + rotate, straight into ws.img_f / ws.img_c
         cplan, fplan = self._encoder_plans()       # both precisions run on the HIP library: there is no PyTorch-ROCm branch
         # context features: net (fp32 + split twin) and inp (first 128 columns of the GRU input x; twin only when the
         # update blocks run on pre-split activations)
         ctx = dict(outs=ws.net0_ab_s, auxs=ws.x_ab_s) if eng.presplit(self._weights()) else dict(aux=ws.x_ab)
-        ws.img_c[:B].copy_(image1); ws.img_c[B:].copy_(image1_b)
-        ws.img_f[:B].copy_(image1); ws.img_f[B:2 * B].copy_(image2)
-        ws.img_f[2 * B:3 * B].copy_(image1_b); ws.img_f[3 * B:].copy_(image2_b)
         if self.use_streams and int(os.environ.get("PRIORFLOW_FORKS", "15")) & 1:
             # cnet and fnet are independent: fork them onto two side streams (the fork/join
             # is captured into the HIP graph as parallel branches) so that the latency-bound

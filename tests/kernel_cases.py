@@ -82,6 +82,26 @@ def case_img_rotate(lib, dev):
         check(o, ref[b:b + 1], 2e-6, f"seam sampler b={b}")
 
 
+def case_normalise_images(lib, dev):
+    """pf_normalise_images against numpy's fp32 `2 * (image / 255.0) - 1.0` (IEEE division, the reference's CPU arithmetic,
+    core/prior_raft.py:121-122) bit for bit, on every integer pixel value, fractional values and values outside [0, 255]."""
+    g = torch.Generator().manual_seed(3)
+    n = 2 * 3 * 16 * 24
+    i1 = torch.cat([torch.arange(256, dtype=torch.float32), torch.rand(n - 256, generator=g) * 300 - 20]).reshape(2, 3, 16, 24)
+    i2 = (torch.rand(2, 3, 16, 24, generator=g) * 255).round()
+    f = torch.full((8, 3, 16, 24), 7.0, device=dev)
+    c = torch.full((4, 3, 16, 24), 7.0, device=dev)
+    lib.normalise_images(i1.to(dev), i2.to(dev), f[:2], f[2:4], c[:2])
+    r1 = (np.float32(2) * (i1.numpy() / np.float32(255)) - np.float32(1)).astype(np.float32)
+    r2 = (np.float32(2) * (i2.numpy() / np.float32(255)) - np.float32(1)).astype(np.float32)
+    assert r1.dtype == np.float32
+    assert np.array_equal(f[:2].cpu().numpy(), r1) and np.array_equal(c[:2].cpu().numpy(), r1), "image1"
+    assert np.array_equal(f[2:4].cpu().numpy(), r2), "image2"
+    assert float(f[4:].min()) == 7.0 and float(c[2:].max()) == 7.0, "wrote outside its slices"
+    lib.normalise_images(i1.to(dev), i2.to(dev), f[4:6], f[6:], None)           # the context destination is optional
+    assert np.array_equal(f[4:6].cpu().numpy(), r1) and np.array_equal(f[6:].cpu().numpy(), r2)
+
+
 def case_flow_prep(lib, dev):
     co = gc.nasty_coords("prep", B=2)
     flow = torch.empty(2, 2, H8, W8, device=dev)
@@ -639,7 +659,7 @@ def case_norm_backward(lib, dev):
     check(uncl(dx.cpu(), B, H, W), x2.grad, 1e-6, "affine + relu backward")
 
 
-ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_flow_prep, case_flo_rotate, case_dccl,
+ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_normalise_images, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_motion_prep, case_conf_stem, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
                      case_flow_metrics, case_training_pieces, case_dccl_backward, case_upsample_backward,

@@ -579,7 +579,7 @@ def test_conv_dma_kernel_matches_symmetric_kernel_bitwise(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 64, 128), (2, 24, 40), (1, 17, 27)])
-def test_lookup_window_kernel_matches_per_thread_kernel_bitwise(dev, shape, tmp_path):
+def test_lookup_window_kernel_matches_per_thread_kernel_bitwise(dev, shape):
     """pf_lookup_win_kernel (a wave per pixel: shared x / y tap geometry, cooperative window loads through LDS;
     PRIORFLOW_LOOKUP_WIN=1, read once per process -> child process) against the per-thread statement pf_lookup_elem, which
     pf_dccl_lookup_pair always launches: same bits for both outputs, planar and
@@ -587,9 +587,10 @@ def test_lookup_window_kernel_matches_per_thread_kernel_bitwise(dev, shape, tmp_
     exact integers, flows of +-W/2) and on maps with odd pyramid levels."""
     import subprocess
     import sys
-    code = "import os, sys, torch; sys.path[:0] = [%r, %r]; import test_hip_kernels as t; from prior_flow_amd import _lib; " \
-           "t._lookup_window_case(_lib.load(), torch.device('cuda:0'), %r)" % (
-               os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), tuple(shape))
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    code = "import os, sys, torch; sys.path[:0] = [%r, %r, %r]; import test_hip_kernels as t; from prior_flow_amd import _lib; " \
+           "t._lookup_window_case(_lib.load(), torch.device('cuda:0'), %r)" % (here, root, os.path.join(root, "oracle"), tuple(shape))
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PRIORFLOW_LOOKUP_WIN="1"), timeout=600)
 
 
