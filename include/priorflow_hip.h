@@ -208,6 +208,12 @@ typedef struct pf_conv_desc {
     /* with in0_split: a block of at least 128 * max(lds0, lds1) zero bytes (16-byte aligned) -- what the all-DMA kernel
      * reads for the zero padding around the map (an LDS-DMA copies memory; it cannot write a constant) */
     const void* zeros; int zeros_bytes;
+    /* Optional start value of the accumulation (all-DMA kernel only; any other kernel form answers PF_ERR_BAD_SHAPE):
+     * channel-last fp32 [B*N][ld_pre], output channel j of this conv at column off_pre + j.  The accumulators start from
+     * pre instead of zero, so out = epilogue(pre + conv(in) + bias).  Used for the iteration-invariant part of the GRU
+     * convolutions: the context features `inp` are the same in all `iters` iterations (core/prior_raft.py:148,196), so
+     * conv_{[h|inp|motion]} = conv_inp(inp) [computed once] + conv_{[h|motion]} [per iteration, 2/3 of the MFMA work]. */
+    const float* pre; int ld_pre; int off_pre;
 } pf_conv_desc;
 
 /* The tail of DCCL.__call__ fused with the first motion-encoder convolution (core/corr.py:138,

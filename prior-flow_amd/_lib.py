@@ -56,6 +56,7 @@ class ConvDesc(C.Structure):
         ("out_split", _fp), ("lds_out", _i),
         ("aux_split", _fp), ("lds_aux", _i),
         ("zeros", _fp), ("zeros_bytes", _i),
+        ("pre", _fp), ("ld_pre", _i), ("off_pre", _i),
     ]
 
 

@@ -28,6 +28,7 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
         if (d.in1_split && d.c1 > 0 && ((d.off1 & 31) || (d.c0 & 31) || d.lds1 * 32 < d.off1 + d.c1)) return PF_ERR_BAD_SHAPE;
         if (d.out_split && ((d.off_out & 31) || d.lds_out <= 0)) return PF_ERR_BAD_SHAPE;
         if (d.aux_split && d.lds_aux * 32 < 128) return PF_ERR_BAD_SHAPE;
+        if (d.pre && (d.off_pre < 0 || d.off_pre + d.cout > d.ld_pre)) return PF_ERR_BAD_SHAPE;
         if ((d.in0_split != nullptr) != (f.in0_split != nullptr) || (d.c1 > 0 && (d.in1_split != nullptr) != (d.in0_split != nullptr)))
             return PF_ERR_BAD_ARG;              // every group and both segments agree on the operand form
         // same geometry in every group: one kernel, one K loop
@@ -134,8 +135,10 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
     }
     if (const int roles = conv_dma_choice(grp, ngroups, g, max_cout, tile_id))      // pre-split operands: the all-DMA kernel
         return pf_conv_dma_launch(grp, ngroups, g, max_cout, tile_id == 4 ? 2 : 1, roles, s);
-    for (int i = 0; i < ngroups; ++i)
+    for (int i = 0; i < ngroups; ++i) {
         if (!descs[i].in0 || (descs[i].c1 > 0 && !descs[i].in1)) return PF_ERR_BAD_ARG;   // fp32 operands needed from here on
+        if (descs[i].pre) return PF_ERR_BAD_SHAPE;                                          // accumulator start values: all-DMA kernel only
+    }
     switch (tile_id) {
         case 0: case 1: case 2: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
         case 3: return pf_conv_part1_launch(grp, ngroups, g, max_cout, s);

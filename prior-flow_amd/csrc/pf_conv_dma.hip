@@ -363,12 +363,40 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
     const bool ragged = (g.W % TW) != 0 || (g.H % TH) != 0;
     bool have = true;
     while (have) {
+        if (const float* pre = gdesc[it.grp].pre) {
+            // accumulators start from pf_conv_desc.pre (the iteration-invariant part of a GRU conv) instead of zero: element
+            // (m, t, r) is pixel p0[m] + roff(r), channel jb + 32 t + li -- the epilogue's mapping.  The loads of an item's
+            // first launch run under the loader waves' prologue; each MFMA waits only for its own accumulator.
+            const auto& dp = gdesc[it.grp];
+            const int ldp = dp.ld_pre, jb = it.ntile * BN + 32 * NT * wn + li;
+            const int cout = dp.cout;
+            pre += dp.off_pre;
+            int x0, y0; long pix0;
+            tile_origin(it, x0, y0, pix0);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m) {
+                const int wy = 2 * wy2 + m;
+                const int xlim = (y0 + wy < g.H) ? g.W - x0 - 4 * lh : 0;
+                const long pm = pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t) {
+                    const bool jok = jb + 32 * t < cout;
+                    const float* pp = pre + pm * ldp + jb + 32 * t;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        acc[m][t][r] = (jok && ro < xlim) ? pp[(long)ro * ldp] : 0.f;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+        }
         {
             int c2 = 0;
             for (; c2 + 1 < nchunks; c2 += 2)

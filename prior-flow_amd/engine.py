@@ -172,9 +172,19 @@ class Conv:
         wp, bp = pack_mfma(w, b)
         return Conv(wp, bp, w.shape[2], w.shape[3], w.shape[1], w.shape[0], precision)
 
+    @staticmethod
+    def of_slices(mods, cin_slices, precision, with_bias: bool) -> "Conv":
+        """The convolutions `mods` (same input, same kernel shape) concatenated on Cout and restricted to the input channels
+        of `cin_slices` (concatenated in that order); bias of the modules, or zero."""
+        w = torch.cat([m.weight.detach().float() for m in mods], 0)
+        w = torch.cat([w[:, a:b] for a, b in cin_slices], 1).contiguous()
+        b = torch.cat([m.bias.detach().float() for m in mods], 0)
+        wp, bp = pack_mfma(w, b if with_bias else torch.zeros_like(b))
+        return Conv(wp, bp, w.shape[2], w.shape[3], w.shape[1], w.shape[0], precision)
+
     def desc(self, in0, off0, c0, out, off_out, epilogue, in1=None, off1=0, c1=0, scale=1.0,
              h=None, z=None, aux=None, stride=1, in_scale=None, in_shift=None, in_relu=False,
-             stats=None, in0s=None, in1s=None, outs=None, auxs=None) -> ConvDesc:
+             stats=None, in0s=None, in1s=None, outs=None, auxs=None, pre=None, off_pre=0) -> ConvDesc:
         """in0s / in1s / outs / auxs: optional split twins (``split_twin``) of in0 / in1 / out / aux; with a twin given the
         fp32 tensor may be None (operands: the all-DMA kernel reads only the twins; outputs: twin only)."""
         assert c0 + c1 == self.cin, (c0, c1, self.cin)
@@ -211,8 +221,11 @@ class Conv:
         d.in_shift = in_shift.data_ptr() if in_shift is not None else None
         d.in_relu = int(in_relu)
         d.stats_out = stats.data_ptr() if stats is not None else None
+        # start value of the accumulation (all-DMA kernel): channel-last fp32 [rows][ld_pre], this conv's channels at off_pre
+        d.pre = pre.data_ptr() if pre is not None else None
+        d.ld_pre, d.off_pre = (pre.shape[-1] if pre is not None else 0), off_pre
         # the C struct holds raw pointers only: keep every tensor alive for as long as the descriptor is
-        d._keep = (in0, in1, out, h, z, aux, in_scale, in_shift, stats, self.w, self.b, in0s, in1s, outs, auxs, zb)
+        d._keep = (in0, in1, out, h, z, aux, in_scale, in_shift, stats, self.w, self.b, in0s, in1s, outs, auxs, zb, pre)
         return d
 
 
@@ -244,6 +257,14 @@ def pack_update_blocks(oddc, upd, precision: Optional[int] = None) -> Dict[str, 
         P[f"{tag}.q1"] = C(g.convq1)
         P[f"{tag}.zr2"] = Conv.fused(g.convz2, g.convr2, pr)
         P[f"{tag}.q2"] = C(g.convq2)
+        if pr == PREC_BF16X3:
+            # context hoist (Engine.hoist_context): GRU input = [h 0:128 | inp 128:256 | motion 256:384]; `inp` does not change
+            # over the iterations, so its part of all three gates is ONE 128 -> 384 conv per half-step, run once per forward
+            # (with the biases), and the per-iteration convs see [h | motion] only
+            for n, (cz, cr, cq) in (("1", (g.convz1, g.convr1, g.convq1)), ("2", (g.convz2, g.convr2, g.convq2))):
+                P[f"{tag}.pre{n}"] = Conv.of_slices((cz, cr, cq), [(128, 256)], pr, with_bias=True)
+                P[f"{tag}.zr{n}h"] = Conv.of_slices((cz, cr), [(0, 128), (256, 384)], pr, with_bias=False)
+                P[f"{tag}.q{n}h"] = Conv.of_slices((cq,), [(0, 128), (256, 384)], pr, with_bias=False)
         P[f"{tag}.fh1"] = C(blk.flow_head.conv1)
         P[f"{tag}.fh2"] = C(blk.flow_head.conv2)
         w2 = blk.flow_head.conv2.weight.detach().float()          # [2,256,3,3] -> [2][9][256]
@@ -334,6 +355,9 @@ class Workspace:
         self.x_ab_s = tw(2 * rows, 256)
         self.x_a_s, self.x_b_s = self.x_ab_s[:rows], self.x_ab_s[rows:]
         self.rh_a_s, self.rh_b_s = tw(rows, 128), tw(rows, 128)
+        # context hoist: conv_inp(inp) + bias of [z | r | q] for the two GRU half-steps, per branch (fp32 [rows][384])
+        self.pre = {(t, n): z(rows, 384) for t in "ab" for n in "12"}
+        self.pre_ready = False          # set by Engine.hoist_context, cleared whenever `inp` is rewritten
         self.c1_a_s, self.c1_b_s = tw(rows, 256), tw(rows, 256)
         self.cat_a_s, self.cat_b_s = tw(rows, 272), tw(rows, 272)      # 9 chunks; cat_b's last chunk stays zero
         self.t_a_s, self.t_ba_s, self.t_b_s = tw(rows, 128), tw(rows, 128), tw(rows, 128)
@@ -371,9 +395,27 @@ class Engine:
         # pre-split activations + all-DMA convs (bf16x3 only); PRIORFLOW_PRESPLIT=0 keeps the fp32-staged kernels (A/B knob:
         # the results are bit-identical)
         self.presplit_on = os.environ.get("PRIORFLOW_PRESPLIT", "1") != "0"
+        self.hoist_on = os.environ.get("PRIORFLOW_HOIST_CTX", "1") != "0"
 
     def presplit(self, P) -> bool:
         return self.presplit_on and P["precision"] == PREC_BF16X3
+
+    def hoist(self, P) -> bool:
+        """Context hoist on: the GRU convs take the iteration-invariant `inp` part from ws.pre (needs the all-DMA kernel)."""
+        return self.hoist_on and self.presplit(P)
+
+    def hoist_context(self, ws: "Workspace", P):
+        """Once per forward, after cnet: pre = conv_{inp-part of [convz|convr|convq]}(inp) + bias for both GRU half-steps
+        (core/update.py:46-60 with x = cat[inp, motion], core/prior_raft.py:196: `inp` is the same tensor in every
+        iteration).  Two launches (1x5, 5x1), both branches as groups; consumed by update_blocks through pf_conv_desc.pre."""
+        ws.pre_ready = False
+        if not self.hoist(P):
+            return
+        ws.pre_ready = True
+        like = ws.pre[("a", "1")]
+        for n in "12":
+            self.lib.conv2d([P[f"{t}.pre{n}"].desc(None, 0, 128, ws.pre[(t, n)], 0, EPI_LINEAR, in0s=xs)
+                             for t, xs in (("a", ws.x_a_s), ("b", ws.x_b_s))], ws.B, ws.H8, ws.W8, like)
 
     # ---- stage 0: view B images --------------------------------------------------------------
     def prepare_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
@@ -661,7 +703,14 @@ class Engine:
             branches.append(("b", ws.net_b, ws.x_b, ws.z_b, ws.rh_b, ws.net_b_s, ws.x_b_s, ws.rh_b_s))
         c = cur
         for tag in ("1", "2"):
-            if ps:      # operands as twins; z stays fp32 (epilogue operand of q), r*h exists as a twin only, h' in both forms
+            if ps and self.hoist(P) and ws.pre_ready:     # [h | motion] only: the inp part (and the bias) is the accumulators' start value
+                conv([P[f"{t}.zr{tag}h"].desc(None, 0, 128, zb, 0, EPI_GRU_ZR, off1=128, c1=128, h=net[c], in0s=ns[c], in1s=xs,
+                                               auxs=rhs, pre=ws.pre[(t, tag)], off_pre=0)
+                      for t, net, x, zb, rh, ns, xs, rhs in branches])
+                conv([P[f"{t}.q{tag}h"].desc(None, 0, 128, net[c ^ 1], 0, EPI_GRU_Q, off1=128, c1=128, h=net[c], z=zb,
+                                              in0s=rhs, in1s=xs, outs=ns[c ^ 1], pre=ws.pre[(t, tag)], off_pre=256)
+                      for t, net, x, zb, rh, ns, xs, rhs in branches])
+            elif ps:    # operands as twins; z stays fp32 (epilogue operand of q), r*h exists as a twin only, h' in both forms
                 conv([P[f"{t}.zr{tag}"].desc(None, 0, 128, zb, 0, EPI_GRU_ZR, off1=0, c1=256, h=net[c], in0s=ns[c], in1s=xs,
                                               auxs=rhs) for t, net, x, zb, rh, ns, xs, rhs in branches])
                 conv([P[f"{t}.q{tag}"].desc(None, 0, 128, net[c ^ 1], 0, EPI_GRU_Q, off1=0, c1=256, h=net[c], z=zb,

@@ -116,6 +116,7 @@ class PriOr_RAFT(nn.Module):
         inp = relu(cnet[128:]) for both views."""
         from ._lib import EPI_LINEAR, EPI_TANH_RELU
         B = ws.B
+        ws.pre_ready = False                        # `inp` is about to be rewritten (Engine.hoist_context)
         eng.prepare_images(ws, image1, image2)      # normalise + rotate, straight into ws.img_f / ws.img_c
         cplan, fplan = self._encoder_plans()       # both precisions run on the HIP library: there is no PyTorch-ROCm branch
         # context features: net (fp32 + split twin) and inp (first 128 columns of the GRU input x; twin only when the
@@ -158,6 +159,7 @@ class PriOr_RAFT(nn.Module):
         eng = Engine(self._lib(), self._streams() if self.use_streams else None)
         P = self._weights()
         self._encode(image1, image2, ws, eng)
+        eng.hoist_context(ws, P)                   # iteration-invariant part of the GRU convs (pre-split path only)
         eng.build_pyramids(ws, P["precision"])
         eng.init_coords(ws, init_flow)
         cur = 0

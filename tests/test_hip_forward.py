@@ -331,6 +331,7 @@ def test_presplit_path_is_bitwise_the_fp32_staged_path(params, size, batch, monk
     from prior_flow_amd.prior_raft import PriOr_RAFT
 
     monkeypatch.setenv("PRIORFLOW_FOLD_BN", "0")      # cnet's folded BatchNorm (default with presplit) is different arithmetic: excluded here
+    monkeypatch.setenv("PRIORFLOW_HOIST_CTX", "0")    # so is the hoisted context term of the GRU convs (another summation order)
 
     def run(presplit, graph):
         monkeypatch.setenv("PRIORFLOW_PRESPLIT", presplit)
@@ -348,3 +349,28 @@ def test_presplit_path_is_bitwise_the_fp32_staged_path(params, size, batch, monk
     for graph in (False, True):
         got = run("1", graph)
         assert torch.equal(got, ref), (graph, float((got - ref).abs().max()))
+
+
+def test_hoisted_context_and_folded_batchnorm_change_the_flow_by_rounding_only(params, monkeypatch):
+    """The two re-associations of the default path -- cnet's eval-mode BatchNorm folded into its convolutions and the
+    iteration-invariant `inp` part of the GRU convolutions computed once (pf_conv_desc.pre) -- against the same forward
+    without them (PRIORFLOW_FOLD_BN=0 PRIORFLOW_HOIST_CTX=0, which test_presplit_path_is_bitwise_the_fp32_staged_path ties to
+    the fp32-staged kernels bit for bit): 512x1024, iters=12; the flows differ by fp32 rounding carried through 12 iterations,
+    far below the 1e-3 EPE bar against the reference."""
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+
+    def run(flag):
+        monkeypatch.setenv("PRIORFLOW_FOLD_BN", flag)
+        monkeypatch.setenv("PRIORFLOW_HOIST_CTX", flag)
+        m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+        m.load_state_dict(params, strict=True)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            return m(i1, i2, iters=12, test_mode=True).clone()
+
+    i1, i2 = gc.synthetic_pair(1, 512, 1024, seed=5)
+    i1, i2 = i1.cuda(), i2.cuda()
+    plain, fast = run("0"), run("1")
+    epe = (fast - plain).pow(2).sum(1).sqrt()
+    assert float(plain.abs().mean()) > 0.5
+    assert float(epe.mean()) < 1e-4, float(epe.mean())

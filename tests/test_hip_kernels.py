@@ -578,6 +578,61 @@ def test_conv_dma_kernel_matches_symmetric_kernel_bitwise(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 64, 128), (2, 22, 40), (8, 64, 128)])
+def test_gru_half_step_with_hoisted_context_equals_full_convolutions(lib, dev, shape):
+    """pf_conv_desc.pre (accumulators start from a stored map) and a second operand segment at a channel offset: one SepConvGRU
+    half-step (core/update.py:46-60) as the engine runs it with the context hoisted -- pre = conv_inp(inp) + bias once, then
+    z|r and q over [h | motion] only -- against the same half-step with the full 384-channel convolutions.  Same products,
+    another summation order: equal to fp32 rounding of the pre-activations (bound 2e-5 on gate outputs of size <= 1)."""
+    from prior_flow_amd._lib import EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, PREC_BF16X3, PfError
+    from prior_flow_amd.engine import Conv, split_twin
+    B, H8, W8 = shape
+    N = B * H8 * W8
+    torch.manual_seed(11)
+    for kh, kw in ((1, 5), (5, 1)):
+        cz, cr, cq = [torch.nn.Conv2d(384, 128, (kh, kw), padding=(kh // 2, kw // 2)).to(dev) for _ in range(3)]
+        h = (torch.rand(N, 128, device=dev) * 2 - 1)
+        x = (torch.rand(N, 256, device=dev) * 2 - 1)
+
+        def twin(t):
+            return lib.split_bf16(t, split_twin(t.shape[0], t.shape[1], dev))
+        hs, xs = twin(h), twin(x)
+
+        def half_step(hoisted):
+            z = torch.zeros(N, 128, device=dev)
+            hn = torch.zeros(N, 128, device=dev)
+            rhs, hns = split_twin(N, 128, dev), split_twin(N, 128, dev)
+            if hoisted:
+                pre = torch.zeros(N, 384, device=dev)
+                cp = Conv.of_slices((cz, cr, cq), [(128, 256)], PREC_BF16X3, with_bias=True)
+                czr = Conv.of_slices((cz, cr), [(0, 128), (256, 384)], PREC_BF16X3, with_bias=False)
+                cqq = Conv.of_slices((cq,), [(0, 128), (256, 384)], PREC_BF16X3, with_bias=False)
+                lib.conv2d([cp.desc(None, 0, 128, pre, 0, EPI_LINEAR, in0s=xs)], B, H8, W8, x)
+                kz = dict(off1=128, c1=128, pre=pre, off_pre=0)
+                kq = dict(off1=128, c1=128, pre=pre, off_pre=256)
+            else:
+                czr, cqq = Conv.fused(cz, cr, PREC_BF16X3), Conv.of(cq, PREC_BF16X3)
+                kz = kq = dict(off1=0, c1=256)
+            dz = czr.desc(None, 0, 128, z, 0, EPI_GRU_ZR, h=h, in0s=hs, in1s=xs, auxs=rhs, **kz)
+            assert lib.conv2d_roles([dz], B, H8, W8) >= 16            # the all-DMA kernel
+            lib.conv2d([dz], B, H8, W8, x)
+            lib.conv2d([cqq.desc(None, 0, 128, hn, 0, EPI_GRU_Q, h=h, z=z, in0s=rhs, in1s=xs, outs=hns, **kq)], B, H8, W8, x)
+            torch.cuda.synchronize()
+            return z, hn, hns
+        z0, h0, hs0 = half_step(False)
+        z1, h1, hs1 = half_step(True)
+        assert float((z1 - z0).abs().max()) < 2e-5 and float((h1 - h0).abs().max()) < 2e-5, \
+            (kh, kw, float((z1 - z0).abs().max()), float((h1 - h0).abs().max()))
+        assert torch.equal(hs1, twin(h1))                               # the output twin is the split of the fp32 output
+        assert float(h0.abs().mean()) > 0.05
+    # start values are implemented by the all-DMA kernel only: fp32 operands + pre is refused, not silently ignored
+    c = Conv.of(cq, PREC_BF16X3)
+    with pytest.raises(PfError):
+        lib.conv2d([c.desc(h, 0, 128, torch.zeros(N, 128, device=dev), 0, EPI_LINEAR, in1=x, off1=0, c1=256,
+                           pre=torch.zeros(N, 384, device=dev), off_pre=0)], B, H8, W8, x)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 64, 128), (2, 24, 40), (1, 17, 27)])
 def test_lookup_window_kernel_matches_per_thread_kernel_bitwise(dev, shape):
     """pf_lookup_win_kernel (a wave per pixel: shared x / y tap geometry, cooperative window loads through LDS;
