@@ -181,7 +181,7 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
             const char* wp = wb + ((long)tap * nchunks + chunk) * 128;                // wave-uniform
             static_for<0, WP>([&](auto J) __attribute__((always_inline)) {
                 constexpr int j = decltype(J)::value;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PF_DMA_ABL_NO_DMA)      // (timing-only ablation: no DMA issued)
                 lds_void* dst = (lds_void*)(smem + RING + slot * SLOT_BYTES + (lw * WP + j) * 1024);
                 __builtin_amdgcn_global_load_lds(wp + bg[j], dst, 16, 0, 0);
 #else
@@ -195,7 +195,7 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
                 const char* base = seg0 + (long)chunk * 128;
                 static_for<decltype(J0)::value, decltype(J1)::value>([&](auto J) __attribute__((always_inline)) {
                     constexpr int j = decltype(J)::value;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PF_DMA_ABL_NO_DMA)
                     lds_void* dst = (lds_void*)(smem + buf * HALO_BYTES + (lw * HP + j) * 1024);
                     __builtin_amdgcn_global_load_lds(base + a0[j], dst, 16, 0, 0);
 #else
@@ -206,7 +206,7 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
                 const char* base = seg1 + (long)(chunk - c0s) * 128;
                 static_for<decltype(J0)::value, decltype(J1)::value>([&](auto J) __attribute__((always_inline)) {
                     constexpr int j = decltype(J)::value;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PF_DMA_ABL_NO_DMA)
                     lds_void* dst = (lds_void*)(smem + buf * HALO_BYTES + (lw * HP + j) * 1024);
                     __builtin_amdgcn_global_load_lds(base + a1[j], dst, 16, 0, 0);
 #else
@@ -277,6 +277,13 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
     const unsigned b_off = (unsigned)(32 * NT * wn + li) * 128 + ((P0 ^ (((unsigned)(32 * NT * wn + li) >> 1) & 7u)) << 4);
     // fragments, double buffered in registers: [set][...][piece]; pieces 0,1 = hi K-halves, 2,3 = lo K-halves
     bf16x8 fa[2][2][4], fb[2][NT][4];
+#ifdef PF_DMA_ABL_NO_READS
+    for (int i = 0; i < 2; ++i)
+        for (int k = 0; k < 4; ++k) {
+            for (int m = 0; m < 2; ++m) for (int e = 0; e < 8; ++e) fa[i][m][k][e] = (__bf16)(float)(lane & 7);
+            for (int t = 0; t < NT; ++t) for (int e = 0; e < 8; ++e) fb[i][t][k][e] = (__bf16)(float)(lane & 3);
+        }
+#endif
     unsigned a_addr[2] = {0, 0}, b_addr = 0;
     // A fragment of tap (ky, kx), M-tile m: halo row hr = arow0 + (ky + m) * HW + kx, piece P0 at hr*128 + ((P0 ^ swz(hr)) << 4).
     // These TAPS * 2 offsets are computed once (stamps of the first version: the dependent add / bfe / xor / shift-add chain in
@@ -314,12 +321,16 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
                 a_addr[m] = a0;
             }
             constexpr unsigned x = (k & 1) * 16u + (k >> 1) * 64u;          // pieces P0+1, P0+4, P0+5: XOR on the piece bits
+#ifndef PF_DMA_ABL_NO_READS                               // (timing-only ablation: fragments stay whatever they are)
             fa[set][m][k] = *reinterpret_cast<const bf16x8*>(smem + (a_addr[m] ^ x));
+#endif
         } else {
             constexpr int t = (p - 8) / 4, k = (p - 8) % 4;
             if constexpr (t == 0 && k == 0) b_addr = (unsigned)RING + slot_off + b_off;
             constexpr unsigned x = (k & 1) * 16u + (k >> 1) * 64u;
+#ifndef PF_DMA_ABL_NO_READS
             fb[set][t][k] = *reinterpret_cast<const bf16x8*>(smem + (b_addr ^ x) + t * 4096);
+#endif
         }
     };
     unsigned jm = wslot;
