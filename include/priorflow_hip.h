@@ -288,10 +288,11 @@ int pf_channel_stats_final(const double* partials, int B, int Np, int C, int nbl
 int pf_channel_stats(const float* y, int B, int Np, int C, float eps, float* scale, float* shift,
                      double* partials, int nblk, void* stream);
 
-/* out = relu( res' + relu(y*s + t) ), res' = res | res*rs + rt | absent (ResidualBlock tail,
- * core/extractor.py:41-47).  y,res,out channel-last [B*Np][C]; s,t,rs,rt [B][C]. */
+/* out = relu( res' + relu(y*s + t) ), res' = res | res*rs + rt | relu(res*rs + rt) [res_relu != 0: the skip input is itself
+ * a normalised + activated raw conv output that was never materialised -- the stem of the encoder] | absent (ResidualBlock
+ * tail, core/extractor.py:41-47).  y,res,out channel-last [B*Np][C]; s,t,rs,rt [B][C]. */
 int pf_norm_act(const float* y, const float* s, const float* t, const float* res,
-                const float* rs, const float* rt, float* out, int B, int Np, int C, void* stream);
+                const float* rs, const float* rt, int res_relu, float* out, int B, int Np, int C, void* stream);
 
 /* FlowHead.conv2 (3x3, C->2; core/update.py:10,13-14) fused with coords1 += delta_flow
  * (core/prior_raft.py:193,196).  x: channel-last hidden features [B*N][ld] (C channels at column 0);

@@ -97,7 +97,7 @@ _SIGNATURES = {
     "pf_conv2d_small": [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_channel_stats": [_fp, _i, _i, _i, C.c_float, _fp, _fp, _fp, _i, _fp],
     "pf_channel_stats_final": [_fp, _i, _i, _i, _i, C.c_float, _fp, _fp, _fp],
-    "pf_norm_act": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pf_norm_act": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_flow_head_out": [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_coords_add": [_fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
@@ -426,9 +426,9 @@ class PfLib:
                                                   _ptr(scale), _ptr(shift), self._stream(scale)),
                  "pf_channel_stats_final")
 
-    def norm_act(self, y, s, t, out, B, Np, Cc, res=None, rs=None, rt=None):
+    def norm_act(self, y, s, t, out, B, Np, Cc, res=None, rs=None, rt=None, res_relu=False):
         self._chk(y, s, t, out, res, rs, rt)
-        self._rc(self._dll.pf_norm_act(_ptr(y), _ptr(s), _ptr(t), _ptr(res), _ptr(rs), _ptr(rt), _ptr(out),
+        self._rc(self._dll.pf_norm_act(_ptr(y), _ptr(s), _ptr(t), _ptr(res), _ptr(rs), _ptr(rt), int(res_relu), _ptr(out),
                                        B, Np, Cc, self._stream(y)), "pf_norm_act")
 
     def flow_head_out(self, x, Cch, weight, bias, coords1, delta=None):

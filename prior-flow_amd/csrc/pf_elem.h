@@ -842,7 +842,7 @@ PF_HD void pf_split_bf16_elem(long idx, const PfSplitArgs& a) {   // idx over ro
 struct PfNormActArgs {
     const float* y; const float* s; const float* t;
     const float* res; const float* rs; const float* rt;
-    float* out; int B, Np, C;
+    float* out; int B, Np, C; int res_relu;
 };
 PF_HD void pf_norm_act_elem(long idx, const PfNormActArgs& a) {   // idx over B*Np*C/4
     const int c4n = a.C / 4;
@@ -855,6 +855,7 @@ PF_HD void pf_norm_act_elem(long idx, const PfNormActArgs& a) {   // idx over B*
         if (a.res) {
             float r = a.res[e];
             if (a.rs) r = r * a.rs[pc] + a.rt[pc];
+            if (a.res_relu) r = fmaxf(r, 0.f);
             v = fmaxf(r + v, 0.f);
         }
         a.out[e] = v;

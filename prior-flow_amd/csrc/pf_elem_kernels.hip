@@ -573,6 +573,7 @@ __global__ void __launch_bounds__(256) pf_norm_act_vec(const PfNormActArgs a, co
                 const float4 rt = *reinterpret_cast<const float4*>(a.rt + pc);
                 r.x = r.x * rs.x + rt.x; r.y = r.y * rs.y + rt.y; r.z = r.z * rs.z + rt.z; r.w = r.w * rs.w + rt.w;
             }
+            if (a.res_relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
             v.x = fmaxf(r.x + v.x, 0.f); v.y = fmaxf(r.y + v.y, 0.f);
             v.z = fmaxf(r.z + v.z, 0.f); v.w = fmaxf(r.w + v.w, 0.f);
         }

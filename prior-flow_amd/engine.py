@@ -918,16 +918,24 @@ class EncoderPlan:
         h, w = H // 2, W // 2
         a0 = bufs["act0"]
         # stem: raw conv -> a0[0]; x0 = relu(norm1(.)) materialised -> a0[1]
+        # bf16x3: x0 = relu(norm1(stem)) is never materialised -- the first block's conv1 applies it while staging and its tail
+        # applies it to the skip input (one 2 x 134 MB pass less per 4 images); the stem's statistics live in slot 2 until then
+        stem_folded = self.precision == PREC_BF16X3 and self.kind != "batch" and os.environ.get("PRIORFLOW_FOLD_STEM", "1") != "0"
+        slot0 = 2 if stem_folded else 0
         if self.stem_s2d is not None:
             lib.space_to_depth2(images, bufs["s2d"])
-            sc, sh = self._conv_norm(self.stem_s2d, self.norm1, bufs["s2d"], 12, a0[0], Bn, h, w, 64, 0)
+            sc, sh = self._conv_norm(self.stem_s2d, self.norm1, bufs["s2d"], 12, a0[0], Bn, h, w, 64, slot0)
         else:
             lib.conv2d_small(images, True, 0, 3, self.stem.w, self.stem.b, a0[0], 0, 64, 7, 7, 2, False, Bn, h, w)
-            sc, sh = self._affine(self.norm1, a0[0], Bn, h * w, 64, 0)
-        lib.norm_act(a0[0], sc, sh, a0[1], Bn, h * w, 64)
-        x = a0[1]
+            sc, sh = self._affine(self.norm1, a0[0], Bn, h * w, 64, slot0)
+        if stem_folded:
+            s0, t0 = sc, sh
+            x = a0[0]
+        else:
+            lib.norm_act(a0[0], sc, sh, a0[1], Bn, h * w, 64)
+            x = a0[1]
         lvl = 0
-        for blk in self.blocks:
+        for bi, blk in enumerate(self.blocks):
             cin, cout, st = blk["cin"], blk["cout"], blk["stride"]
             if st != 1:
                 lvl += 1
@@ -936,8 +944,10 @@ class EncoderPlan:
             free = [t for t in acts if t.data_ptr() != x.data_ptr()]
             y1, y2, o = free[0], free[1], free[2]
             Np = h * w
-            # conv1 (input x is a materialised activation: no affine)
-            s1, t1 = self._conv_norm(blk["c1"], blk["n1"], x, cin, y1, Bn, h, w, cout, 0, stride=st)
+            # conv1 (input x is a materialised activation: no affine -- except the folded stem in front of the first block)
+            first = stem_folded and bi == 0
+            kw1 = dict(in_scale=s0, in_shift=t0, in_relu=True) if first else {}
+            s1, t1 = self._conv_norm(blk["c1"], blk["n1"], x, cin, y1, Bn, h, w, cout, 0, stride=st, **kw1)
             if self.precision == PREC_BF16X3:
                 # conv2 consumes relu(norm1(y1)) folded into its load
                 s2, t2 = self._conv_norm(blk["c2"], blk["n2"], y1, cout, y2, Bn, h, w, cout, 1,
@@ -951,6 +961,8 @@ class EncoderPlan:
                 lib.conv2d([blk["ds"].desc(x, 0, cin, y1, 0, EPI_LINEAR, stride=st)], Bn, h, w, x)
                 s3, t3 = self._affine(blk["n3"], y1, Bn, Np, cout, 2)
                 lib.norm_act(y2, s2, t2, o, Bn, Np, cout, res=y1, rs=s3, rt=t3)
+            elif first:
+                lib.norm_act(y2, s2, t2, o, Bn, Np, cout, res=x, rs=s0, rt=t0, res_relu=True)
             else:
                 lib.norm_act(y2, s2, t2, o, Bn, Np, cout, res=x)
             x = o

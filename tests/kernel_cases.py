@@ -413,6 +413,15 @@ def case_channel_stats_and_norm_act(lib, dev):
     lib.channel_stats(cl(d).to(dev), B, Np, C, sc3, sh3, part, 16)
     lib.norm_act(cl(y).to(dev), sc, sh, out, B, Np, C, res=cl(d).to(dev), rs=sc3, rt=sh3)
     check(uncl(out.cpu(), B, h, w), torch.relu(inorm(d) + torch.relu(inorm(y))), 5e-6, "normalised shortcut")
+    # res_relu: the skip input is relu(norm(raw)) of a raw map that was never materialised (the encoder stem) -- and it is
+    # the same bits as materialising it with pf_norm_act first
+    lib.norm_act(cl(y).to(dev), sc, sh, out, B, Np, C, res=cl(d).to(dev), rs=sc3, rt=sh3, res_relu=True)
+    check(uncl(out.cpu(), B, h, w), torch.relu(torch.relu(inorm(d)) + torch.relu(inorm(y))), 5e-6, "activated normalised shortcut")
+    x0 = torch.empty(B * Np, C, device=dev)
+    out2 = torch.empty(B * Np, C, device=dev)
+    lib.norm_act(cl(d).to(dev), sc3, sh3, x0, B, Np, C)
+    lib.norm_act(cl(y).to(dev), sc, sh, out2, B, Np, C, res=x0)
+    assert torch.equal(out, out2), "res_relu differs from the materialised skip input"
 
 
 def case_small_conv_stem(lib, dev):

@@ -374,3 +374,24 @@ def test_hoisted_context_and_folded_batchnorm_change_the_flow_by_rounding_only(p
     epe = (fast - plain).pow(2).sum(1).sqrt()
     assert float(plain.abs().mean()) > 0.5
     assert float(epe.mean()) < 1e-4, float(epe.mean())
+
+
+def test_folded_stem_normalisation_is_bitwise_the_materialised_one(params, monkeypatch):
+    """fnet's relu(norm1(stem)) applied while the first block's conv1 stages its input and to the skip input of that block's
+    tail (pf_norm_act res_relu) instead of being written out first (PRIORFLOW_FOLD_STEM=0): the same operations on the same
+    operands, so the flow is equal bit for bit."""
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+
+    def run(flag):
+        monkeypatch.setenv("PRIORFLOW_FOLD_STEM", flag)
+        m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+        m.load_state_dict(params, strict=True)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            return m(i1, i2, iters=3, test_mode=True).clone()
+
+    i1, i2 = gc.synthetic_pair(2, 256, 512, seed=9)
+    i1, i2 = i1.cuda(), i2.cuda()
+    a, b = run("0"), run("1")
+    assert float(a.abs().mean()) > 0.1
+    assert torch.equal(a, b), float((a - b).abs().max())
