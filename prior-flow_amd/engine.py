@@ -440,6 +440,17 @@ class Engine:
             self.lib.split_bf16(ws.f_all, ws.f_split)          # all four feature maps at once
             rows = ws.B * ws.N
             fs = [ws.f_split[i * rows:(i + 1) * rows] for i in range(4)]
+            if self.side is not None and os.environ.get("PRIORFLOW_CORR_PAR", "0") == "1":
+                # A/B knob: the two volumes on two queues (one launch's store phase under the other's GEMM phase)
+                main, sb = torch.cuda.current_stream(), self.side[1]
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self.lib.corr_pyramid_bf16x3(fs[0], fs[1], ws.pyr_a, ws.B, ws.H8, ws.W8, 256)
+                sb.wait_event(ev)
+                with torch.cuda.stream(sb):
+                    self.lib.corr_pyramid_bf16x3(fs[2], fs[3], ws.pyr_b, ws.B, ws.H8, ws.W8, 256)
+                main.wait_stream(sb)
+                return
             self.lib.corr_pyramid_bf16x3(fs[0], fs[1], ws.pyr_a, ws.B, ws.H8, ws.W8, 256)
             self.lib.corr_pyramid_bf16x3(fs[2], fs[3], ws.pyr_b, ws.B, ws.H8, ws.W8, 256)
             return

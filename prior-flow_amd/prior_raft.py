@@ -159,8 +159,20 @@ class PriOr_RAFT(nn.Module):
         eng = Engine(self._lib(), self._streams() if self.use_streams else None)
         P = self._weights()
         self._encode(image1, image2, ws, eng)
-        eng.hoist_context(ws, P)                   # iteration-invariant part of the GRU convs (pre-split path only)
-        eng.build_pyramids(ws, P["precision"])
+        if self.use_streams and eng.hoist(P) and os.environ.get("PRIORFLOW_HOIST_SIDE", "1") != "0":
+            # the hoisted context convs (MFMA-bound) run beside the corr build (store-bound); the corr build stays on the calling
+            # stream and is enqueued first
+            cur, side = torch.cuda.current_stream(), self._streams()[0]
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            eng.build_pyramids(ws, P["precision"])
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                eng.hoist_context(ws, P)
+            cur.wait_stream(side)
+        else:
+            eng.hoist_context(ws, P)               # iteration-invariant part of the GRU convs (pre-split path only)
+            eng.build_pyramids(ws, P["precision"])
         eng.init_coords(ws, init_flow)
         cur = 0
         for it in range(iters):
