@@ -2,7 +2,7 @@
 # Regenerates the committed round-3 measurement artefacts on the GPU box (run through gpurun from the repo root):
 #   gpurun_out/final3/{pytest_gpu.log,bench_n1.json,kernel_stats.csv,forward_breakdown.txt,iteration_timeline.txt,encoder_timeline.txt,
 #                      pmc_traffic.json,mfma_busy.json,bench_batch32.json,kernel_stats_batch32.csv,time_sizes.txt,train_step_time.json,
-#                      bench_gloo2.json,train_2rank_check.txt,conv_dma_microbench.txt,ab_presplit.txt,ab_lookup_win.txt}
+#                      bench_gloo2.json,train_2rank_check.txt,conv_dma_microbench.txt,ab_presplit.txt,ab_hoist.txt,ab_folds.txt,ab_lookup_win.txt}
 # Copy what is to be judged into profiles/ as r3_final_<name> (profiles/r3_pmc_traffic.json and r3_final_kernel_stats.csv are the
 # files bench.py reads for `traffic` and `in_replay_us`).
 export TMPDIR=/tmp
@@ -43,6 +43,14 @@ for i in 1 2; do for p in 0 1; do
   PRIORFLOW_PRESPLIT=$p python bench.py --batch 32 --no-cpu-baseline --steps 4 --warmup 2 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=32 presplit=$p', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"
 done; done > $O/ab_presplit.txt
 for i in 1 2; do for p in 0 1; do
+  PRIORFLOW_HOIST_CTX=$p python bench.py --no-cpu-baseline --steps 60 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=1  hoist_ctx=$p', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"
+  PRIORFLOW_HOIST_CTX=$p python bench.py --batch 32 --no-cpu-baseline --steps 4 --warmup 2 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=32 hoist_ctx=$p', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"
+done; done > $O/ab_hoist.txt
+for i in 1 2; do for p in 0 1; do
+  PRIORFLOW_FOLD_BN=$p PRIORFLOW_FOLD_STEM=$p python bench.py --no-cpu-baseline --steps 60 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=1  fold_bn=fold_stem=$p', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"
+  PRIORFLOW_FOLD_BN=$p PRIORFLOW_FOLD_STEM=$p python bench.py --batch 32 --no-cpu-baseline --steps 4 --warmup 2 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=32 fold_bn=fold_stem=$p', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"
+done; done > $O/ab_folds.txt
+for i in 1 2; do for p in 0 1; do
   PRIORFLOW_LOOKUP_WIN=$p python bench.py --no-cpu-baseline --steps 60 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=1 lookup_win=$p', d['value'], 'pairs/s; lookup alone', d['roofline_lookup']['avg_launch_us'], 'us')"
 done; done > $O/ab_lookup_win.txt
-cat $O/pytest_gpu.log; cut -c1-300 $O/bench_n1.json; head -3 $O/forward_breakdown.txt | cut -c1-200; cat $O/time_sizes.txt; cut -c1-200 $O/bench_batch32.json; cat $O/ab_presplit.txt $O/ab_lookup_win.txt
+cat $O/pytest_gpu.log; cut -c1-300 $O/bench_n1.json; head -3 $O/forward_breakdown.txt | cut -c1-200; cat $O/time_sizes.txt; cut -c1-200 $O/bench_batch32.json; cat $O/ab_presplit.txt $O/ab_hoist.txt $O/ab_folds.txt $O/ab_lookup_win.txt
