@@ -391,6 +391,15 @@ def self_launch(args) -> int:
     return max(abs(c) for c in codes)
 
 
+def rccl_version():
+    """Version of the RCCL library torch is linked against (reported, never required: the line must print without it)."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as exc:        # noqa: BLE001
+        return "unavailable: " + repr(exc)
+
+
 def init_ranks(world: int, rank: int, device):
     """torch.distributed for the barrier / max-over-ranks of the timing (the forward itself has no collective).
     RCCL first; PRIORFLOW_BENCH_BACKEND=gloo selects the CPU backend for rehearsals on a box without N GPUs."""
@@ -489,7 +498,7 @@ def main():
                                       + (f"; timing barrier / max over {backend}" if dist is not None else ""),
                        # what the communicator really saw (a SCALE record shows RCCL spanning N ranks, or that it was a gloo rehearsal)
                        "collective_backend": backend, "rccl_world": world if backend == "nccl" else None,
-                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
+                       "rccl_version": rccl_version() if backend == "nccl" else None,
                        "weights": "deterministic closed-form fill (no checkpoints offline)",
                        "hip_graph": bool(model.use_graph),
                        "encoders": "libpriorflow_hip.so (HIP kernels, both precisions)"},
