@@ -48,6 +48,10 @@ PMC_FILE = "r3_pmc_traffic.json"   # rocprofv3 --pmc passes of this command (pro
 STATS_FILE = "r3_final_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this command (graph replay)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
+# what a loop of v_mfma_f32_32x32x16_bf16 and nothing else sustains on all 256 CUs with operands that toggle like real data
+# (profiles/mfma_rate/mfma_rate.hip -> profiles/r3_mfma_rate.txt: 1.83 PFLOP/s; 2.2-2.5 with constant operands or on 64 CUs).
+# Reported beside `peak` as context for `mfma_pipe_util`; `frac` stays against the nameplate.
+SUSTAINED_BF16_MFMA_TFLOPS = 1830.0
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 TILE_NAMES = {0: "pf_conv_mfma_kernel<4,1,1> (128x32)", 1: "pf_conv_mfma_kernel<2,2,1> (64x64)",
               2: "pf_conv_mfma_kernel<2,2,2> (64x128)", 3: "pf_conv_halo_kernel<1> (128x64)",
@@ -254,6 +258,10 @@ def profile_kernels(model, i1, i2):
                       # the 3-pass split issues 3 bf16 MFMA FLOPs per algorithmic FLOP: pipe utilisation
                       "mfma_issue_tflops": round(ach * (3 if split else 1), 2),
                       "mfma_pipe_util": round(ach * (3 if split else 1) / peak_mfma, 4),
+                      **({"mfma_real_data_rate_tflops": SUSTAINED_BF16_MFMA_TFLOPS,
+                          "mfma_issue_vs_real_data_rate": round(ach * 3 / SUSTAINED_BF16_MFMA_TFLOPS, 4),
+                          "mfma_real_data_rate_source": "profiles/r3_mfma_rate.txt (MFMA-only loop, toggling operands, 256 CUs)"}
+                         if split else {}),
                       "gflop_per_forward": round(work / 1e9, 1)})
         elif work > 0:
             gbps = work / (ms * 1e-3) / 1e9

@@ -301,6 +301,12 @@ int pf_norm_act(const float* y, const float* s, const float* t, const float* res
 int pf_flow_head_out(const float* x, int ld, int C, const float* weight, const float* bias,
                      float* coords1, float* delta, int ld_delta, int B, int H8, int W8, void* stream);
 
+/* The same for the two branches of an iteration (same shapes, two weight sets, two coords1 / delta destinations) as ONE
+ * launch: branch B's FlowHead tail then needs no cross-queue dependency of its own (core/prior_raft.py:193-196, 206-209). */
+int pf_flow_head_out_pair(const float* x_a, const float* weight_a, const float* bias_a, float* coords1_a, float* delta_a,
+                          const float* x_b, const float* weight_b, const float* bias_b, float* coords1_b, float* delta_b,
+                          int ld, int C, int ld_delta, int B, int H8, int W8, void* stream);
+
 /* coords1 += delta (core/prior_raft.py:193,196).  delta: channel-last, 2 channels at column 0. */
 int pf_coords_add(float* coords1, const float* delta, int ld, int B, int H8, int W8, void* stream);
 

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "pf_channel_stats_final": [_fp, _i, _i, _i, _i, C.c_float, _fp, _fp, _fp],
     "pf_norm_act": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_flow_head_out": [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_flow_head_out_pair": [_fp] * 10 + [_i] * 6 + [_fp],
     "pf_coords_add": [_fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
@@ -437,6 +438,17 @@ class PfLib:
         self._rc(self._dll.pf_flow_head_out(_ptr(x), x.shape[-1], Cch, _ptr(weight), _ptr(bias), _ptr(coords1),
                                             _ptr(delta), 0 if delta is None else delta.shape[-1], B, H, W,
                                             self._stream(x)), "pf_flow_head_out")
+
+    def flow_head_out_pair(self, xa, wa, ba, c1a, da, xb, wb, bb, c1b, db, Cch):
+        """FlowHead.conv2 + coords1 += delta of both branches in one launch."""
+        self._chk(xa, wa, ba, c1a, da, xb, wb, bb, c1b, db)
+        B, _, H, W = c1a.shape
+        if xa.shape[-1] != xb.shape[-1] or (da is None) != (db is None) or (da is not None and da.shape[-1] != db.shape[-1]):
+            raise PfError("flow_head_out_pair: the two branches' buffers differ in shape")
+        self._rc(self._dll.pf_flow_head_out_pair(_ptr(xa), _ptr(wa), _ptr(ba), _ptr(c1a), _ptr(da),
+                                                 _ptr(xb), _ptr(wb), _ptr(bb), _ptr(c1b), _ptr(db),
+                                                 xa.shape[-1], Cch, 0 if da is None else da.shape[-1], B, H, W,
+                                                 self._stream(xa)), "pf_flow_head_out_pair")
 
     def coords_add(self, coords1, delta):
         self._chk(coords1, delta)

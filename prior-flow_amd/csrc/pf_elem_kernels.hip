@@ -593,12 +593,19 @@ int launch_norm_act(const PfNormActArgs& a, long total, void* stream) {
 // the eight partial sums (4 pixels x 2 outputs) are reduced with a halving exchange: 10 cross-lane steps.
 // History: this kernel is how the packed-fp32 / MFMA erratum of DESIGN.md section 8 was found -- compiled with
 // the SLP vectoriser it was not reproducible beside the mask head's conv.
-__global__ void __launch_bounds__(256) pf_flow_out_strip(const PfFlowOutArgs a, const long strips, const int spr) {
+// NP problems of one shape in one launch (branch A and branch B of an iteration: one launch, no cross-queue hop in front
+// of branch B's strip); the problem is a wave-uniform choice between the kernel arguments.
+struct PfFlowOutN { PfFlowOutArgs p[2]; };
+template <int NP>
+__global__ void __launch_bounds__(256) pf_flow_out_strip(const PfFlowOutN pn, const long strips, const int spr) {
     const int lane = threadIdx.x & 63;
-    const long N = (long)a.H * a.W;
-    long strip = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long strip_all = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long stride = (long)gridDim.x * 4;
-    for (; strip < strips; strip += stride) {
+    for (; strip_all < strips * NP; strip_all += stride) {
+        const bool second = NP == 2 && strip_all >= strips;
+        const PfFlowOutArgs& a = second ? pn.p[1] : pn.p[0];
+        const long strip = second ? strip_all - strips : strip_all;
+        const long N = (long)a.H * a.W;
         const long b = strip / ((long)a.H * spr);
         const int rem = (int)(strip % ((long)a.H * spr));
         const int y = rem / spr, x0 = (rem % spr) * 4;
@@ -668,10 +675,25 @@ int launch_flow_out(const PfFlowOutArgs& a, long total, void* stream) {
         const long strips = (long)a.B * a.H * spr;
         long blocks = (strips + 3) / 4;
         if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-        hipLaunchKernelGGL(pf_flow_out_strip, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, strips, spr);
+        PfFlowOutN pn; pn.p[0] = a; pn.p[1] = a;
+        hipLaunchKernelGGL(pf_flow_out_strip<1>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, pn, strips, spr);
         return (int)hipGetLastError();
     }
     return pf_launch_elem<PfFlowOutArgs, pf_flow_out_elem>(a, total, stream);
+}
+// two problems of one shape (C, ld multiples of 4: the strip kernel); else two launches
+int launch_flow_out2(const PfFlowOutArgs& a, const PfFlowOutArgs& b, long total, void* stream) {
+    if (a.C % 4 == 0 && a.ld % 4 == 0 && b.C == a.C && b.ld % 4 == 0) {
+        const int spr = (a.W + 3) / 4;
+        const long strips = (long)a.B * a.H * spr;
+        long blocks = (2 * strips + 3) / 4;
+        if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+        PfFlowOutN pn; pn.p[0] = a; pn.p[1] = b;
+        hipLaunchKernelGGL(pf_flow_out_strip<2>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, pn, strips, spr);
+        return (int)hipGetLastError();
+    }
+    const int rc = launch_flow_out(a, total, stream);
+    return rc != 0 ? rc : launch_flow_out(b, total, stream);
 }
 
 // Region sums: one block per (pixel chunk k, image b); per-thread fp64 accumulators for up to 8
@@ -878,6 +900,7 @@ static int pf_lookup_dispatch(const PfLookupArgs& a, long total, void* stream) {
 #define PF_SEQ_LOSS_LAUNCH(a, stream) launch_seq_loss(a, stream)
 #define PF_SUMSQ_LAUNCH(a, stream) launch_sumsq(a, stream)
 #define PF_FLOW_OUT_LAUNCH(a, total, stream) launch_flow_out(a, total, stream)
+#define PF_FLOW_OUT2_LAUNCH(a, b, total, stream) launch_flow_out2(a, b, total, stream)
 #define PF_NORM_ACT_LAUNCH(a, total, stream) launch_norm_act(a, total, stream)
 #define PF_STATS_LAUNCH launch_stats
 #define PF_STATS_FINAL_LAUNCH launch_stats_final

@@ -751,6 +751,13 @@ class Engine:
             d.append(P["a.m2"].desc(ws.mh_a, 0, 256, ws.mask_a, 0, EPI_LINEAR, scale=0.25))
         if mask_b and need_b:
             d.append(P["b.m2"].desc(ws.mh_b, 0, 256, ws.mask_b, 0, EPI_LINEAR, scale=0.25))
+        if need_b and not d and os.environ.get("PRIORFLOW_STRIP_PAIR", "0") == "1":
+            # A/B knob, off: both branches' FlowHead tails as ONE launch on the calling stream (pf_flow_head_out_pair), so that
+            # branch B's coords need no cross-queue hop of their own.  Bit-identical; measured 128.8 / 129.4 against 130.8 / 130.8
+            # pairs/s (same box): the hop it removes costs less than running the two tails back to back.
+            lib.flow_head_out_pair(ws.fh_a, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a,
+                                   ws.fh_b, P["b.fh2w"], P["b.fh2b"], ws.c1b, ws.delta_b, 256)
+            return c
         if self.forks & 8 and (need_b or d):
             # three independent tails of the heads: flow_out A | flow_out B | mask convs
             main = torch.cuda.current_stream()

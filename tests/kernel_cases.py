@@ -465,6 +465,20 @@ def case_flow_head_out(lib, dev):
     lib.flow_head_out(cl(x).to(dev), 256, w.permute(0, 2, 3, 1).reshape(2, 9, 256).contiguous().to(dev),
                       b.to(dev), c2, None)
     check(c2, c1, 0.0, "delta buffer is optional")
+    # both branches of an iteration in one launch (pf_flow_head_out_pair): the bits of two single launches
+    x2 = gc.uni("fho/x2", (2, 256, H8, W8), -1, 1)
+    w2 = gc.uni("fho/w2", (2, 256, 3, 3), -0.05, 0.05)
+    b2 = gc.uni("fho/b2", (2,), -0.1, 0.1)
+    pk = lambda t: t.permute(0, 2, 3, 1).reshape(2, 9, 256).contiguous().to(dev)      # noqa: E731
+    ca, cb = co.clone().to(dev), co.flip(0).clone().to(dev)
+    da, db = torch.zeros(2 * N, 4, device=dev), torch.zeros(2 * N, 4, device=dev)
+    lib.flow_head_out(cl(x).to(dev), 256, pk(w), b.to(dev), ca, da)
+    lib.flow_head_out(cl(x2).to(dev), 256, pk(w2), b2.to(dev), cb, db)
+    pa, pb = co.clone().to(dev), co.flip(0).clone().to(dev)
+    qa, qb = torch.zeros(2 * N, 4, device=dev), torch.zeros(2 * N, 4, device=dev)
+    lib.flow_head_out_pair(cl(x).to(dev), pk(w), b.to(dev), pa, qa, cl(x2).to(dev), pk(w2), b2.to(dev), pb, qb, 256)
+    assert torch.equal(pa, ca) and torch.equal(pb, cb) and torch.equal(qa, da) and torch.equal(qb, db), "pair launch != two launches"
+    assert float((da - db).abs().max()) > 1e-3
 
 
 def case_split_bf16(lib, dev):
