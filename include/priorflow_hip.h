@@ -330,9 +330,10 @@ int pf_space_to_depth2(const float* in, int C, float* out, int ld_out, int B, in
 /* ---- evaluation counterpart ---------------------------------------------- */
 
 /* Per-pixel EPE (evaluate.py:265 `torch.sum((flow - flow_gt)**2, dim=0).sqrt()`) and SEPE
- * (core/utils/spherical.py:20-53 `calculate_great_circle_distance`, method 'Haversine', R = 1) of
+ * (core/utils/spherical.py:20-53 `calculate_great_circle_distance`, R = 1; cosine = 0: method 'Haversine', the one
+ * evaluate.py uses; cosine = 1: method 'Cosine', arccos of the spherical law of cosines as written at :40-46) of
  * pred vs gt, both NCHW [B,2,H,W].  epe / sd: [B,H,W]; either may be NULL. */
-int pf_flow_metrics(const float* pred, const float* gt, float* epe, float* sd, int B, int H, int W,
+int pf_flow_metrics(const float* pred, const float* gt, float* epe, float* sd, int cosine, int B, int H, int W,
                     void* stream);
 
 /* Region sums of evaluate.py:246-275 (All / Equator / Poles / Center ...): bit r of bits[n] puts

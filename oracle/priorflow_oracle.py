@@ -482,6 +482,14 @@ def great_circle_distance(pre: Tensor, gt: Tensor) -> Tensor:
     return 2 * torch.arcsin(torch.sqrt(hav))
 
 
+def great_circle_distance_cosine(pre: Tensor, gt: Tensor) -> Tensor:
+    """The method='Cosine' form of the same distance (core/utils/spherical.py:40-46): arccos of the spherical law of cosines."""
+    tp, pp = _endpoint_sph(pre)
+    tg, pg = _endpoint_sph(gt)
+    cos_alpha = torch.sin(pp) * torch.sin(pg) + torch.cos(pp) * torch.cos(pg) * torch.cos(tg - tp)
+    return torch.arccos(cos_alpha)
+
+
 def spherical_mask(H: int, W: int) -> Tensor:
     """cos(latitude) weights normalised to sum 1 (core/utils/spherical.py:11-17)."""
     n = torch.arange(0, H).view(-1, 1).repeat(1, W)

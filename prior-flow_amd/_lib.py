@@ -119,7 +119,7 @@ _SIGNATURES = {
     "pf_sum_squares": [_fp, C.c_long, _fp, _i, _fp],
     "pf_adamw_step": [_fp, _fp, _fp, _fp, C.c_long, C.c_double, C.c_float, C.c_float, C.c_float, C.c_double, _i,
                       C.c_float, _fp],
-    "pf_flow_metrics": [_fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pf_flow_metrics": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_region_sums": [_fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
 }
 EXPORTS = ["pf_version"] + list(_SIGNATURES)
@@ -597,13 +597,13 @@ class PfLib:
         self._rc(self._dll.pf_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps,
                                          weight_decay, step, grad_scale, self._stream(p)), "pf_adamw_step")
 
-    def flow_metrics(self, pred, gt, epe=None, sd=None):
-        """pred, gt: NCHW [B,2,H,W]; epe / sd: [B,H,W] outputs (either optional)."""
+    def flow_metrics(self, pred, gt, epe=None, sd=None, cosine=False):
+        """pred, gt: NCHW [B,2,H,W]; epe / sd: [B,H,W] outputs (either optional); cosine: the 'Cosine' form of the distance."""
         self._chk(pred, gt, epe, sd)
         B, _, H, W = pred.shape
         if gt.shape != pred.shape:
             raise PfError("flow_metrics: pred and gt must have the same shape")
-        self._rc(self._dll.pf_flow_metrics(_ptr(pred), _ptr(gt), _ptr(epe), _ptr(sd), B, H, W, self._stream(pred)),
+        self._rc(self._dll.pf_flow_metrics(_ptr(pred), _ptr(gt), _ptr(epe), _ptr(sd), int(cosine), B, H, W, self._stream(pred)),
                  "pf_flow_metrics")
 
     def region_sums(self, epe, sd, weight, bits, nregions, partials):

@@ -904,7 +904,7 @@ PF_HD void pf_s2d_elem(long idx, const PfS2dArgs& a) {           // idx over B*(
 // end point x wraps, y clamps (core/utils/projection_prim_ortho.py:200-218), pixel -> (theta, phi)
 // by ERP.plane2spherical (:397-411).
 // ----------------------------------------------------------------------------------------------
-struct PfFlowMetricsArgs { const float* pred; const float* gt; float* epe; float* sd; int B, H, W; };
+struct PfFlowMetricsArgs { const float* pred; const float* gt; float* epe; float* sd; int B, H, W; int cosine; };
 PF_HD void pf_endpoint_sph(float x, float y, float u, float v, int H, int W, float& theta, float& phi) {
     const float pi = 3.14159265358979323846f;
     const float e0 = pf_pymod(x + u + 0.5f, (float)W) - 0.5f;
@@ -926,8 +926,13 @@ PF_HD void pf_flow_metrics_elem(long idx, const PfFlowMetricsArgs& a) {   // idx
         float tp, pp, tg, pg;
         pf_endpoint_sph(x, y, pu, pv, a.H, a.W, tp, pp);
         pf_endpoint_sph(x, y, gu, gv, a.H, a.W, tg, pg);
-        const float hv = pf_haversine(pg - pp) + (cosf(pp) * cosf(pg)) * pf_haversine(tg - tp);
-        a.sd[idx] = 2.f * asinf(sqrtf(hv));
+        if (a.cosine) {         // method='Cosine' (core/utils/spherical.py:40-46): spherical law of cosines, as written there
+            const float ca = sinf(pp) * sinf(pg) + (cosf(pp) * cosf(pg)) * cosf(tg - tp);
+            a.sd[idx] = acosf(ca);
+        } else {
+            const float hv = pf_haversine(pg - pp) + (cosf(pp) * cosf(pg)) * pf_haversine(tg - tp);
+            a.sd[idx] = 2.f * asinf(sqrtf(hv));
+        }
     }
 }
 

@@ -68,16 +68,16 @@ def spherical_mask(H: int, W: int) -> np.ndarray:
 
 def calculate_great_circle_distance(pre_flow: torch.Tensor, gt_flow: torch.Tensor, method: str = "Haversine",
                                     R: float = 1) -> torch.Tensor:
-    """[B,2,H,W] x2 -> [B,H,W] great-circle distance between the flows' end points."""
+    """[B,2,H,W] x2 -> [B,H,W] great-circle distance between the flows' end points (core/utils/spherical.py:20-53; both
+    methods: 'Haversine', which evaluate.py uses, and 'Cosine', the arccos form -- NaN where rounding takes its argument past 1,
+    as in the reference)."""
     assert method in ["Haversine", "Cosine"]
     assert (pre_flow.shape == gt_flow.shape) and (pre_flow.shape[1] == 2)
-    if method != "Haversine":
-        raise NotImplementedError("only the Haversine form (the one evaluate.py uses) is built")
     lib = _lib.load()
     pre = pre_flow.float().contiguous()
     gt = gt_flow.float().contiguous()
     sd = torch.empty(pre.shape[0], pre.shape[2], pre.shape[3], device=pre.device, dtype=torch.float32)
-    lib.flow_metrics(pre, gt, None, sd)
+    lib.flow_metrics(pre, gt, None, sd, cosine=(method == "Cosine"))
     return sd if R == 1 else sd * R
 
 

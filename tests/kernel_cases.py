@@ -532,6 +532,15 @@ def case_flow_metrics(lib, dev):
     check(epe, po.epe(pre, gt), 1e-6, "epe")
     check(sd, po.great_circle_distance(pre, gt), 2e-6, "sepe")
     assert float(sd[0, 4].abs().max()) == 0.0 and float(epe[0, 4].abs().max()) == 0.0
+    # method='Cosine': arccos is ill-conditioned near 0, so compare away from coincident end points (|d| > 0.05 rad: error of
+    # the argument 1e-7 / sin(d)) and against the Haversine form, which is the same quantity
+    cs = torch.empty(B, h, w, device=dev)
+    lib.flow_metrics(pre.to(dev), gt.to(dev), None, cs, cosine=True)
+    want_c = po.great_circle_distance_cosine(pre, gt)
+    far = want_c > 0.05
+    assert int(far.sum()) > far.numel() // 2
+    assert float((cs.cpu() - want_c)[far].abs().max()) < 5e-6, "cosine form vs oracle"
+    assert float((cs.cpu() - sd.cpu())[far].abs().max()) < 5e-6, "cosine form vs haversine form"
     only = torch.empty(B, h, w, device=dev)
     lib.flow_metrics(pre.to(dev), gt.to(dev), None, only)      # either output is optional
     check(only, sd, 0.0, "sd only")
