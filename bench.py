@@ -44,8 +44,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 torch = None     # imported by main() AFTER the self-launch decision: the launching parent never loads torch / the HIP runtime
 
 H, W, ITERS = 512, 1024, 12
-PMC_FILE = "r3_pmc_traffic.json"   # rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py); not re-measured per run
-STATS_FILE = "r3_final_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this command (graph replay)
+# Committed rocprofv3 summaries of THIS command, one entry per workload (profiles/profile_index.json: batch, gpus, H, W, iters ->
+# `stats` = --kernel-trace --stats of the graph replay, `pmc` = the FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_traffic.py).
+# `in_replay_us` and `traffic` are attached only when an entry matches the run's workload; otherwise they are null with a note.
+PROFILE_INDEX = "profile_index.json"
+PROFILE = {"stats": None, "pmc": None, "note": "no workload selected yet"}      # set by select_profile()
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 # what a loop of v_mfma_f32_32x32x16_bf16 and nothing else sustains on all 256 CUs with operands that toggle like real data
@@ -90,6 +93,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step (configs[1] = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-batch32", action="store_true", help="skip the bounded configs[2] leg of the N=1 line")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
                     help="update-block conv arithmetic (default: PRIORFLOW_PRECISION or bf16x3)")
     return ap.parse_args()
@@ -104,11 +108,31 @@ def build_model(device):
     return model.to(device).eval(), params
 
 
+def select_profile(batch, gpus):
+    """Pick the committed profile files whose recorded workload is this run's (a batch-32 or 2-rank line must not
+    carry the B=1 single-GPU numbers)."""
+    path = os.path.join(ROOT, "profiles", PROFILE_INDEX)
+    want = {"batch": batch, "gpus": gpus, "H": H, "W": W, "iters": ITERS}
+    try:
+        with open(path) as f:
+            entries = json.load(f)["profiles"]
+    except (OSError, ValueError, KeyError):
+        entries = []
+    for e in entries:
+        if all(e.get(k) == v for k, v in want.items()):
+            PROFILE.update(stats=e.get("stats"), pmc=e.get("pmc"), note="profiles/%s entry for %s" % (PROFILE_INDEX, want))
+            return
+    PROFILE.update(stats=None, pmc=None, note="profiles/%s has no entry for %s: in_replay_us / traffic not reported "
+                                              "(the committed profiles are of other workloads)" % (PROFILE_INDEX, want))
+
+
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/pmc_traffic.py:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950, KiB -> bytes).
-    Counters cannot be collected inside this process; None when the profile file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_FILE)
+    Counters cannot be collected inside this process; None when no committed profile matches this run's workload."""
+    if not PROFILE["pmc"]:
+        return None
+    path = os.path.join(ROOT, "profiles", PROFILE["pmc"])
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -122,9 +146,11 @@ def pmc_traffic(kernel_substr):
 
 def replay_stats(kernel_substr):
     """Average duration of a kernel INSIDE the graph replay (where the side streams' kernels share the chip), from the
-    committed rocprofv3 --kernel-trace --stats summary of this command (profiles/STATS_FILE); None when absent."""
+    committed rocprofv3 --kernel-trace --stats summary of this workload (select_profile); None when there is none."""
     import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", STATS_FILE)
+    if not PROFILE["stats"]:
+        return None
+    path = os.path.join(ROOT, "profiles", PROFILE["stats"])
     try:
         with open(path) as f:
             for row in csv.DictReader(f):
@@ -138,12 +164,34 @@ def replay_stats(kernel_substr):
 def traffic_fields(kernel_substr):
     """`traffic` (+ a loud note when the committed PMC passes have no entry for this kernel, e.g. after a rename)."""
     t = pmc_traffic(kernel_substr)
+    if not PROFILE["pmc"]:
+        return {"traffic": None, "traffic_note": PROFILE["note"]}
     out = {"traffic": t, "traffic_note": "HBM-side bytes/launch from the committed PMC passes (profiles/%s): counters cannot be "
-                                         "read inside this process" % PMC_FILE}
+                                         "read inside this process" % PROFILE["pmc"]}
     if t is None:
-        out["traffic_error"] = "profiles/%s has no entry matching %r -- re-run profiles/pmc_traffic.py" % (PMC_FILE, kernel_substr)
+        out["traffic_error"] = "profiles/%s has no entry matching %r -- re-run profiles/pmc_traffic.py" % (PROFILE["pmc"], kernel_substr)
         log("WARNING: " + out["traffic_error"])
     return out
+
+
+def replay_ranking(top=6):
+    """The committed replay profile's own ranking (summed kernel time inside the captured multi-stream forward): the bench
+    line's `roofline` is chosen by alone-on-chip event time, and the two rankings differ (by replay time the lookup
+    leads)."""
+    import csv
+    if not PROFILE["stats"]:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", PROFILE["stats"])) as f:
+            rows = [r for r in csv.DictReader(f) if "pf_" in r.get("Name", "")]
+    except (OSError, ValueError, KeyError):
+        return None
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+    short = lambda n: n.replace("(anonymous namespace)::", "").replace("pfconv::", "").replace("void ", "")[:70]  # noqa: E731
+    return {"source": "profiles/%s" % PROFILE["stats"],
+            "kernels": [{"kernel": short(r["Name"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 1),
+                         "share_of_kernel_time": round(float(r["TotalDurationNs"]) / tot, 4)} for r in rows[:top]]}
 
 
 def profile_kernels(model, i1, i2):
@@ -191,24 +239,27 @@ def profile_kernels(model, i1, i2):
         return Bc * (4.0 * n * n * 85.0 / 64.0 + 2.0 * 4.0 * n * c)
 
     px = lambda c: c.shape[0] * c.shape[2] * c.shape[3]  # noqa: E731  (coords [B,2,H8,W8] -> pixels)
-    saved = [
-        wrap("conv2d", "conv", lambda d, Bc, H8, W8, like: conv_name(d, Bc, H8, W8),
+    saved = []          # filled inside the try below: a failing wrap() must not leave earlier wrappers installed
+    specs = [
+        ("conv2d", "conv", lambda d, Bc, H8, W8, like: conv_name(d, Bc, H8, W8),
              lambda d, Bc, H8, W8, like: sum(2.0 * Bc * H8 * W8 * x.cout * x.kh * x.kw * (x.c0 + x.c1) for x in d)),
-        wrap("corr_pyramid", "corr", lambda *a: "pf_corr_kernel", lambda f1, f2, lv, Bc, H8, W8: corr_bytes(Bc, H8, W8, f1.shape[-1])),
-        wrap("corr_pyramid_bf16x3", "corr", lambda *a: "pf_corr_kernel", lambda f1, f2, lv, Bc, H8, W8, c: corr_bytes(Bc, H8, W8, c)),
+        ("corr_pyramid", "corr", lambda *a: "pf_corr_kernel", lambda f1, f2, lv, Bc, H8, W8: corr_bytes(Bc, H8, W8, f1.shape[-1])),
+        ("corr_pyramid_bf16x3", "corr", lambda *a: "pf_corr_kernel", lambda f1, f2, lv, Bc, H8, W8, c: corr_bytes(Bc, H8, W8, c)),
         # SURVEY.md 8(d), one branch: own 10x10 patch x 4 B x 4 levels read + 324 x 4 B written; cross <= 81 x 4 taps x 4 B x 4
         # levels read + 324 x 4 B written = 9 376 B per pixel (76.8 MB at 64x128)
-        wrap("dccl_lookup", "lookup", lambda *a, **k: "pf_lookup", lambda coords, *a, **k: px(coords) * (1600.0 + 1296.0 + 5184.0 + 1296.0)),
-        # own row + 4 raw rows read (324 fp32 each), 256 channels written (4 B in either form), per branch
-        wrap("dccl_combine_conv1x1", "combine", lambda *a: "pf_combine_conv_kernel",
-             lambda items, Bc, H8, W8: len(items) * Bc * H8 * W8 * (5 * 1296.0 + 1024.0)),
-        wrap("motion_prep", "other", lambda *a, **k: "pf_motion_prep_kernel", lambda *a, **k: 0.0),
-        wrap("conv2d_direct_group", "other", lambda *a, **k: "pf_stem7x7c2_valu", lambda *a, **k: 0.0),
-        wrap("conf_stem", "other", lambda *a, **k: "pf_conf_stem_kernel", lambda *a, **k: 0.0),
-        wrap("flow_head_out", "other", lambda *a, **k: "pf_flow_out_strip", lambda *a, **k: 0.0),
-        wrap("norm_act", "other", lambda *a, **k: "pf_norm_act_vec", lambda *a, **k: 0.0),
-        wrap("channel_stats_final", "other", lambda *a, **k: "pf_stats_final", lambda *a, **k: 0.0),
-        wrap("channel_stats", "other", lambda *a, **k: "pf_stats_partial+final", lambda *a, **k: 0.0),
+        ("dccl_lookup", "lookup", lambda *a, **k: "pf_lookup", lambda coords, *a, **k: px(coords) * (1600.0 + 1296.0 + 5184.0 + 1296.0)),
+        # compulsory bytes per pixel and branch: its own row + one raw row read (324 fp32 each: the four bilinear corners of the
+        # rotate-back are rows that neighbouring pixels share, every raw row is fetched once) + 256 channels written (4 B in
+        # either form).  (Round 3 counted the four corners per pixel: 117.8 MB "algorithmic" against 82.6 MB of PMC traffic.)
+        ("dccl_combine_conv1x1", "combine", lambda *a: "pf_combine_conv_kernel",
+             lambda items, Bc, H8, W8: len(items) * Bc * H8 * W8 * (2 * 1296.0 + 1024.0)),
+        ("motion_prep", "other", lambda *a, **k: "pf_motion_prep_kernel", lambda *a, **k: 0.0),
+        ("conv2d_direct_group", "other", lambda *a, **k: "pf_stem7x7c2_valu", lambda *a, **k: 0.0),
+        ("conf_stem", "other", lambda *a, **k: "pf_conf_stem_kernel", lambda *a, **k: 0.0),
+        ("flow_head_out", "other", lambda *a, **k: "pf_flow_out_strip", lambda *a, **k: 0.0),
+        ("norm_act", "other", lambda *a, **k: "pf_norm_act_vec", lambda *a, **k: 0.0),
+        ("channel_stats_final", "other", lambda *a, **k: "pf_stats_final", lambda *a, **k: 0.0),
+        ("channel_stats", "other", lambda *a, **k: "pf_stats_partial+final", lambda *a, **k: 0.0),
     ]
     was, was_streams = model.use_graph, model.use_streams
     model.use_graph = False
@@ -224,6 +275,8 @@ def profile_kernels(model, i1, i2):
     gaps = sorted(s.elapsed_time(e) for s, e in cal)
     gap_ms = max(0.0, gaps[len(gaps) // 2] - 0.002)
     try:
+        for spec in specs:
+            saved.append(wrap(*spec))
         with torch.no_grad():
             for _ in range(2):          # second pass is the measured one (caches warm)
                 recs.clear()
@@ -245,7 +298,8 @@ def profile_kernels(model, i1, i2):
     split = model._weights()["precision"] == PREC_BF16X3
     peak_mfma = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     how = "avg_launch_us: the kernel alone on the chip (single-stream eager pass, HIP events, dispatch gap subtracted); " \
-          "in_replay_us: its rocprofv3 average inside the captured multi-stream forward (profiles/%s)" % STATS_FILE
+          "in_replay_us: its rocprofv3 average inside the captured multi-stream forward (%s)" % (
+              ("profiles/" + PROFILE["stats"]) if PROFILE["stats"] else PROFILE["note"])
 
     def obj(kind, name):
         work, ms, n = by[(kind, name)]
@@ -276,7 +330,9 @@ def profile_kernels(model, i1, i2):
     order = sorted(by, key=lambda k: -by[k][1])
     convs = [k for k in order if k[0] == "conv"]
     out = {"roofline": obj(*order[0])}
-    out["roofline"]["chosen_as"] = "the kernel with the largest summed time of the forward, all kinds"
+    out["roofline"]["chosen_as"] = ("the kernel with the largest summed ALONE-ON-CHIP time of the forward (HIP events, single "
+                                    "stream), all kinds; `replay_ranking` is the committed rocprofv3 ranking inside the graph replay")
+    out["replay_ranking"] = replay_ranking()
     if convs:
         out["roofline_conv"] = obj(*convs[0])
         all_fl = sum(by[k][0] for k in convs)
@@ -349,6 +405,34 @@ def fp32_reference_point(params, device, i1, i2, ref_cpu, steps=5):
     if ref_cpu is not None:
         epe = po.epe(flow.cpu(), ref_cpu)
         out["epe_mean"], out["epe_max"] = float(epe.mean()), float(epe.max())
+    return out
+
+
+def batch32_point(params, device, ref_cpu, steps=4, warmup=2, batch=32):
+    """BASELINE.json configs[2] on the driver's own line: the same forward over a resident batch of 32 synthetic pairs
+    (HIP-graph replay, default precision), timed over `steps` steps; pair 0 of that batch is the B=1 pair (the synthetic
+    generator is a counter-based stream), so its EPE is taken against the same CPU-oracle flow."""
+    from prior_flow_amd import synthetic_pair
+    import priorflow_oracle as po
+    m, _ = build_model(device)
+    i1, i2 = (t.to(device) for t in synthetic_pair(batch, H, W, seed=1234))
+    with torch.no_grad():
+        for _ in range(warmup):
+            flow = m(i1, i2, iters=ITERS, test_mode=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            flow = m(i1, i2, iters=ITERS, test_mode=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out = {"workload": f"{batch} synthetic 512x1024 ERP pairs resident on one GPU, iters={ITERS}, test_mode (BASELINE.json configs[2])",
+           "value": round(batch * steps / dt, 3), "unit": "frame-pairs/s", "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup, "hip_graph": bool(m.use_graph)}
+    if ref_cpu is not None:
+        epe = po.epe(flow[:1].cpu(), ref_cpu)
+        out["epe_mean_pair0"], out["epe_max_pair0"] = float(epe.mean()), float(epe.max())
+    del m, i1, i2, flow
+    torch.cuda.empty_cache()
     return out
 
 
@@ -443,6 +527,7 @@ def main():
     if world > 1:
         dist, backend = init_ranks(world, rank, device)
 
+    select_profile(args.batch, world)
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}; building model")
     model, params = build_model(device)
     if args.precision is not None:
@@ -528,6 +613,12 @@ def main():
                     result["fp32_exact"] = fp32_reference_point(params, device, i1[:1], i2[:1], ref_cpu)
                 except Exception as exc:
                     result["fp32_exact"] = {"error": repr(exc)}
+            if args.batch == 1 and not args.no_batch32:
+                try:
+                    log("batch-32 leg (configs[2])")
+                    result["batch32"] = batch32_point(params, device, ref_cpu)
+                except Exception as exc:
+                    result["batch32"] = {"error": repr(exc)}
         print(json.dumps(result), flush=True)
     if dist is not None:
         rank_barrier()

@@ -463,42 +463,83 @@ int launch_conv_dma_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int
     gg.d_ntn = fd_make((unsigned)gg.ntn); gg.d_ntiles = fd_make((unsigned)gg.ntiles);
     gg.d_tx = fd_make((unsigned)((g.W + 31) / 32)); gg.d_ty = fd_make((unsigned)((g.H + TH - 1) / TH));
     // persistent: at most one workgroup per CU (the kernel's LDS footprint admits no second one), each walking its share of
-    // the work sequence; PRIORFLOW_DMA_WGS (A/B knob) overrides the cap, 0 = one workgroup per item
-    static const int cus = [] {
-        const char* e = getenv("PRIORFLOW_DMA_WGS");
-        if (e) return atoi(e);
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        return n;
-    }();
+    // the work sequence; PRIORFLOW_DMA_WGS (A/B knob) overrides the cap, 0 = one workgroup per item.  Per DEVICE: the CU
+    // count and the > 64 KB dynamic-LDS attribute belong to the device that is current at launch time (one process may drive
+    // several cards).
+    constexpr int MAX_DEV = 64;
+    static int cus_of[MAX_DEV];              // 0 = not asked yet
+    static bool attr_set[MAX_DEV];
+    static const int wgs_env = [] { const char* e = getenv("PRIORFLOW_DMA_WGS"); return e ? atoi(e) : -1; }();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    if (cus_of[dev] == 0) {
+        int n = 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus_of[dev] = n;
+    }
+    int cap = wgs_env >= 0 ? wgs_env : cus_of[dev];
     const long items = (long)gg.ntiles * gg.ntn * ngroups;
-    const dim3 grid((unsigned)((cus > 0 && items > cus) ? cus : items));
-    static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&pf_conv_dma_kernel<NT, KH, KW, WN>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr != hipSuccess) return (int)attr;
+    // the kernel cuts the work sequence into 8 ranges (one per XCD) that the workgroups with blockIdx % 8 == range walk: a
+    // capped grid needs at least one workgroup per range, or the ranges without one are never computed
+    if (cap > 0 && cap < 8 && items > cap) cap = 8;
+    const dim3 grid((unsigned)((cap > 0 && items > cap) ? cap : items));
+    if (!attr_set[dev]) {
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_conv_dma_kernel<NT, KH, KW, WN>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr != hipSuccess) return (int)attr;
+        attr_set[dev] = true;
+    }
     hipLaunchKernelGGL((pf_conv_dma_kernel<NT, KH, KW, WN>), grid, dim3(512), lds, stream, grp, gg);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
+// One translation unit per kernel shape (PF_DMA_PART = 0..6, compiled in parallel by __graft_entry__.build_hip: an unrolled
+// K-step body takes about a minute per instantiation) plus the dispatcher (PF_DMA_PART = 7).
+//   part: 0 <2,3,3,1>  1 <2,3,3,2>  2 <2,1,5,2>  3 <2,5,1,2>  4 <1,3,3,2>  5 <1,1,5,2>  6 <1,5,1,2>      (<NT, KH, KW, WN>)
+#ifndef PF_DMA_PART
+#error "compile pf_conv_dma.hip with -DPF_DMA_PART=0..7"
+#endif
+#define PF_DMA_DEFINE_PART(N, NT, KH, KW, WN)                                                                              \
+    int pf_conv_dma_part##N##_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout,   \
+                                     hipStream_t stream) {                                                                  \
+        return launch_conv_dma_t<NT, KH, KW, WN>(grp, ngroups, g, max_cout, stream);                                        \
+    }
+#if PF_DMA_PART == 0
+PF_DMA_DEFINE_PART(0, 2, 3, 3, 1)
+#elif PF_DMA_PART == 1
+PF_DMA_DEFINE_PART(1, 2, 3, 3, 2)
+#elif PF_DMA_PART == 2
+PF_DMA_DEFINE_PART(2, 2, 1, 5, 2)
+#elif PF_DMA_PART == 3
+PF_DMA_DEFINE_PART(3, 2, 5, 1, 2)
+#elif PF_DMA_PART == 4
+PF_DMA_DEFINE_PART(4, 1, 3, 3, 2)
+#elif PF_DMA_PART == 5
+PF_DMA_DEFINE_PART(5, 1, 1, 5, 2)
+#elif PF_DMA_PART == 6
+PF_DMA_DEFINE_PART(6, 1, 5, 1, 2)
+#else
+#define PF_DMA_DECLARE_PART(N) int pf_conv_dma_part##N##_launch(const pfconv::ConvGroups&, int, const pfconv::ConvGeom&, int, hipStream_t);
+PF_DMA_DECLARE_PART(0) PF_DMA_DECLARE_PART(1) PF_DMA_DECLARE_PART(2) PF_DMA_DECLARE_PART(3)
+PF_DMA_DECLARE_PART(4) PF_DMA_DECLARE_PART(5) PF_DMA_DECLARE_PART(6)
+
 int pf_conv_dma_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, int nt, int roles,
                        hipStream_t stream) {
     for (int i = 0; i < ngroups; ++i)
         if (!grp.d[i].zeros || grp.d[i].zeros_bytes < 128 * (grp.d[i].lds0 > grp.d[i].lds1 ? grp.d[i].lds0 : grp.d[i].lds1)) return PF_ERR_BAD_ARG;
-    if (roles == 2) {
-        if (g.kh == 3 && g.kw == 3) return launch_conv_dma_t<2, 3, 3, 1>(grp, ngroups, g, max_cout, stream);
-        return PF_ERR_BAD_SHAPE;
-    }
+    const bool k33 = g.kh == 3 && g.kw == 3, k15 = g.kh == 1 && g.kw == 5, k51 = g.kh == 5 && g.kw == 1;
+    if (roles == 2) return k33 ? pf_conv_dma_part0_launch(grp, ngroups, g, max_cout, stream) : PF_ERR_BAD_SHAPE;
     if (nt == 2) {
-        if (g.kh == 3 && g.kw == 3) return launch_conv_dma_t<2, 3, 3, 2>(grp, ngroups, g, max_cout, stream);
-        if (g.kh == 1 && g.kw == 5) return launch_conv_dma_t<2, 1, 5, 2>(grp, ngroups, g, max_cout, stream);
-        if (g.kh == 5 && g.kw == 1) return launch_conv_dma_t<2, 5, 1, 2>(grp, ngroups, g, max_cout, stream);
+        if (k33) return pf_conv_dma_part1_launch(grp, ngroups, g, max_cout, stream);
+        if (k15) return pf_conv_dma_part2_launch(grp, ngroups, g, max_cout, stream);
+        if (k51) return pf_conv_dma_part3_launch(grp, ngroups, g, max_cout, stream);
     } else {
-        if (g.kh == 3 && g.kw == 3) return launch_conv_dma_t<1, 3, 3, 2>(grp, ngroups, g, max_cout, stream);
-        if (g.kh == 1 && g.kw == 5) return launch_conv_dma_t<1, 1, 5, 2>(grp, ngroups, g, max_cout, stream);
-        if (g.kh == 5 && g.kw == 1) return launch_conv_dma_t<1, 5, 1, 2>(grp, ngroups, g, max_cout, stream);
+        if (k33) return pf_conv_dma_part4_launch(grp, ngroups, g, max_cout, stream);
+        if (k15) return pf_conv_dma_part5_launch(grp, ngroups, g, max_cout, stream);
+        if (k51) return pf_conv_dma_part6_launch(grp, ngroups, g, max_cout, stream);
     }
     return PF_ERR_BAD_SHAPE;
 }
+#endif

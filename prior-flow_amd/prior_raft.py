@@ -128,7 +128,15 @@ class PriOr_RAFT(nn.Module):
             # kernels of one (stem, statistics) hide behind the other's convolutions
             cur = torch.cuda.current_stream()
             s1, s2 = self._streams()[:2]
-            if int(os.environ.get("PRIORFLOW_ORDER", "15")) & 8:
+            # Which queue gets which encoder (round 4, profiles/r4_encoder_order.txt).  The phase is bound by the SUM of the two
+            # encoders' kernel time, not by when cnet starts: with fnet on the calling stream and cnet forked behind it (round 3)
+            # cnet's first kernel only gets CUs at t = 1.5 ms, because every fnet launch of layers 1-2 fills the chip and a
+            # queued workgroup of the older queue wins a freed CU; with both on side streams (default) or cnet on the calling
+            # stream, cnet starts at t = 0.2 ms and both chains run at half speed beside each other -- the phase ends 50-75 us
+            # earlier (2.44 / 2.47 against 2.51 ms), the only gain being the tails and one-workgroup kernels of one chain
+            # filled by the other.
+            order = os.environ.get("PRIORFLOW_ENC_ORDER", "both_side")
+            if order == "fnet_main" or defer_cnet_join:
                 # fnet (the longer chain) stays on the calling stream and is enqueued first; cnet forks from an event
                 ev = torch.cuda.Event()
                 ev.record(cur)
@@ -138,6 +146,14 @@ class PriOr_RAFT(nn.Module):
                     cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
                 if defer_cnet_join:
                     return s1           # the caller keeps working on fnet's results and joins cnet's stream later
+                cur.wait_stream(s1)
+            elif order == "cnet_main":
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
+                s1.wait_event(ev)
+                with torch.cuda.stream(s1):
+                    fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
                 cur.wait_stream(s1)
             else:
                 s1.wait_stream(cur)
