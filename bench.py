@@ -188,7 +188,13 @@ def replay_ranking(top=6):
         return None
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
-    short = lambda n: n.replace("(anonymous namespace)::", "").replace("pfconv::", "").replace("void ", "")[:70]  # noqa: E731
+    import re
+
+    def short(n):
+        m = re.search(r"_Z\d+(pf_\w+?_elem)l", n)          # pf_elem_kernel<Args, &pf_xxx_elem>: name the element function
+        if m:
+            return m.group(1)
+        return n.replace("(anonymous namespace)::", "").replace("pfconv::", "").replace("void ", "")[:70]
     return {"source": "profiles/%s" % PROFILE["stats"],
             "kernels": [{"kernel": short(r["Name"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 1),
                          "share_of_kernel_time": round(float(r["TotalDurationNs"]) / tot, 4)} for r in rows[:top]]}

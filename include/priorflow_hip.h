@@ -158,6 +158,10 @@ int pf_conf_stem(const float* in, int ld_in, int off_in, const float* w1, const 
                             * (net / inp split of the context features, core/prior_raft.py:136-142) */
 #define PF_EPI_RELU_RES 5  /* out = relu(res + relu(acc + bias)), res = h[.., j] (ld_h): the tail of a ResidualBlock whose
                             * norm2 is an eval-mode BatchNorm folded into the weights (core/extractor.py:41-47) */
+#define PF_EPI_MASK 6      /* out = h[.., j] > 0 ? (acc + bias) * scale : 0 -- the data gradient of a convolution whose INPUT was
+                            * a ReLU output y (h = y, ld_h): dgrad and the ReLU's backward in one launch (training, train_flow.py:135) */
+#define PF_EPI_ADD 7       /* out = (acc + bias) * scale + h[.., j] (ld_h; out may alias h): a data gradient accumulated into the
+                            * gradient another consumer of the same tensor has already left there */
 
 /* Arithmetic of pf_conv2d (pf_conv_desc.precision); the weight buffer format follows it. */
 #define PF_PREC_F32 0     /* exact fp32 MFMA; weights fp32 [Cout_pad][KH*KW][Cin_pad]                 */
@@ -214,6 +218,10 @@ typedef struct pf_conv_desc {
      * convolutions: the context features `inp` are the same in all `iters` iterations (core/prior_raft.py:148,196), so
      * conv_{[h|inp|motion]} = conv_inp(inp) [computed once] + conv_{[h|motion]} [per iteration, 2/3 of the MFMA work]. */
     const float* pre; int ld_pre; int off_pre;
+    /* Training forward (the gate values are operands of pf_gru_zr_bwd / pf_gru_q_bwd): with save_gates != 0 and aux_out set,
+     * PF_EPI_GRU_ZR also writes r = sigmoid(.) to aux_out[.., 128 + j'] (j' = j - 128; r*h stays at aux_out[.., j'], so
+     * ld_aux >= 256) and PF_EPI_GRU_Q also writes q = tanh(.) to aux_out[.., j] (ld_aux >= 128). */
+    int save_gates;
 } pf_conv_desc;
 
 /* The tail of DCCL.__call__ fused with the first motion-encoder convolution (core/corr.py:138,

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRIORFLOW_LIB") or os.path.join(_HERE, "lib", "libpriorflow_hip.so")
 
-EPI_LINEAR, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_TANH_RELU, EPI_RELU_RES = 0, 1, 2, 3, 4, 5
+EPI_LINEAR, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_TANH_RELU, EPI_RELU_RES, EPI_MASK, EPI_ADD = 0, 1, 2, 3, 4, 5, 6, 7
 PREC_F32, PREC_BF16X3 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -57,6 +57,7 @@ class ConvDesc(C.Structure):
         ("aux_split", _fp), ("lds_aux", _i),
         ("zeros", _fp), ("zeros_bytes", _i),
         ("pre", _fp), ("ld_pre", _i), ("off_pre", _i),
+        ("save_gates", _i),
     ]
 
 

@@ -379,6 +379,18 @@ def conv2d(x: torch.Tensor, m: nn.Conv2d) -> torch.Tensor:
                        f"{tuple(x.shape)} input")
 
 
+def gate_of(m: nn.Conv2d):
+    """(token, WeightGrad) of convolution module ``m`` for the forward being recorded (created on first use): the
+    accumulator the weight gradient of every use of ``m`` goes to, and the token that orders its WeightGate's backward
+    after all of them."""
+    gates = _TAPE.gates
+    g = gates.get(id(m))
+    if g is None:
+        acc = WeightGrad()
+        g = gates[id(m)] = (WeightGate.apply(acc, m.weight, m.bias), acc)
+    return g
+
+
 class PyramidGrad:
     """Gradient accumulator of one branch's pyramid for one backward pass.  Every DCCL lookup of every iteration
     scatters straight into these four buffers (pf_dccl_lookup_bwd accumulates) instead of handing autograd a
@@ -765,6 +777,13 @@ def _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a
             fl = init_flow.float().contiguous()
             c1a = c1a + fl
             c1b = c1b + lib.flo_rotate(fl, g_b2a_8, g_a2b_8, torch.empty_like(fl))
+    import os
+    if os.environ.get("PRIORFLOW_TRAIN_LOOP", "1") != "0" and all(p.requires_grad for p in model.ODDC.parameters()) \
+            and all(p.requires_grad for p in model.update_block.parameters()):
+        # round 4: the refinement iterations as ONE autograd node with a hand-written backward and deferred weight gradients
+        from .train_loop import run_loop
+        return run_loop(model, lib, zr_a, zr_b, gate_of, net_a, net_b, inp_a, inp_b, f1a, f2a, pyr_a, pyr_b, coords0,
+                        c1a, c1b, g_a2b_8, g_b2a_8, iters)
     preds_a: List[torch.Tensor] = []
     preds_b: List[torch.Tensor] = []
     for _ in range(iters):

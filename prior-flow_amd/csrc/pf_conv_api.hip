@@ -41,8 +41,10 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
         if (d.c1 > 0 && ((d.off1 & 3) || (d.in1 && (d.ld1 & 3)) || (d.c0 % KC) != 0)) return PF_ERR_BAD_SHAPE;
         if (d.off0 < 0 || (d.in0 && d.off0 + d.c0 > d.ld0) || (d.c1 > 0 && (d.off1 < 0 || (d.in1 && d.off1 + d.c1 > d.ld1))))
             return PF_ERR_BAD_ARG;
-        if (d.epilogue < PF_EPI_LINEAR || d.epilogue > PF_EPI_RELU_RES) return PF_ERR_BAD_ARG;
-        if (d.epilogue == PF_EPI_RELU_RES && (!d.h || d.ld_h < d.cout)) return PF_ERR_BAD_ARG;
+        if (d.epilogue < PF_EPI_LINEAR || d.epilogue > PF_EPI_ADD) return PF_ERR_BAD_ARG;
+        if ((d.epilogue == PF_EPI_RELU_RES || d.epilogue == PF_EPI_MASK || d.epilogue == PF_EPI_ADD) && (!d.h || d.ld_h < d.cout)) return PF_ERR_BAD_ARG;
+        if (d.save_gates && d.aux_out && ((d.epilogue == PF_EPI_GRU_ZR && d.ld_aux < 256) || (d.epilogue == PF_EPI_GRU_Q && d.ld_aux < 128)))
+            return PF_ERR_BAD_ARG;
         if (d.stride != f.stride || (d.stride != 1 && d.stride != 2)) return PF_ERR_BAD_SHAPE;
         if ((d.in_scale == nullptr) != (d.in_shift == nullptr)) return PF_ERR_BAD_ARG;
         if (d.epilogue == PF_EPI_TANH_RELU && (d.cout != 256 || (!d.aux_out && !d.aux_split) || (d.aux_out && d.ld_aux < 128))) return PF_ERR_BAD_ARG;

@@ -421,7 +421,7 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
         d.bias = dd.bias; d.out = dd.out; d.ld_out = dd.ld_out; d.off_out = dd.off_out; d.cout = dd.cout;
         d.epilogue = dd.epilogue; d.scale = dd.scale; d.h = dd.h; d.ld_h = dd.ld_h; d.z = dd.z; d.ld_z = dd.ld_z;
         d.aux_out = dd.aux_out; d.ld_aux = dd.ld_aux; d.precision = dd.precision;
-        d.out_split = dd.out_split; d.lds_out = dd.lds_out; d.aux_split = dd.aux_split; d.lds_aux = dd.lds_aux;
+        d.out_split = dd.out_split; d.lds_out = dd.lds_out; d.aux_split = dd.aux_split; d.lds_aux = dd.lds_aux; d.save_gates = dd.save_gates;
         const int n0 = it.ntile * BN;
         int x0, y0; long pix0;
         tile_origin(it, x0, y0, pix0);

@@ -156,7 +156,10 @@ __device__ __forceinline__ void tile_epilogue_t(const pf_conv_desc& d, const f32
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hv[r] = live(r) ? hp[(long)roff(r) * d.ld_h] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = pf_sigmoid<FAST>(acc[t][r] + bias) * hv[r];
+                for (int r = 0; r < 16; ++r) v[r] = pf_sigmoid<FAST>(acc[t][r] + bias);
+                if (d.save_gates && d.aux_out != nullptr) put(v, d.aux_out, d.ld_aux, j, nullptr, 0);      // r itself (training)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] * hv[r];
                 put(v, d.aux_out, d.ld_aux, j - 128, d.aux_split, d.lds_aux);
             }
         } else if (epi == PF_EPI_TANH_RELU) {
@@ -169,13 +172,21 @@ __device__ __forceinline__ void tile_epilogue_t(const pf_conv_desc& d, const f32
                 for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[t][r] + bias, 0.f);
                 put(v, d.aux_out, d.ld_aux, j - 128, d.aux_split, d.lds_aux);
             }
-        } else if (epi == PF_EPI_RELU_RES) {
+        } else if (epi == PF_EPI_RELU_RES || epi == PF_EPI_MASK || epi == PF_EPI_ADD) {
             const float* hp = d.h + p0 * d.ld_h + j;
             float hv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) hv[r] = live(r) ? hp[(long)roff(r) * d.ld_h] : 0.f;
+            if (epi == PF_EPI_RELU_RES) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = fmaxf(hv[r] + fmaxf(acc[t][r] + bias, 0.f), 0.f);
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(hv[r] + fmaxf(acc[t][r] + bias, 0.f), 0.f);
+            } else if (epi == PF_EPI_MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = hv[r] > 0.f ? (acc[t][r] + bias) * d.scale : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = (acc[t][r] + bias) * d.scale + hv[r];
+            }
             put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
         } else {   // PF_EPI_GRU_Q:  h' = (1 - z) h + z tanh(v)
             const float* zp = d.z + p0 * d.ld_z + j;
@@ -187,7 +198,10 @@ __device__ __forceinline__ void tile_epilogue_t(const pf_conv_desc& d, const f32
                 hv[r] = live(r) ? hp[(long)roff(r) * d.ld_h] : 0.f;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = (1.f - zv[r]) * hv[r] + zv[r] * pf_tanh<FAST>(acc[t][r] + bias);
+            for (int r = 0; r < 16; ++r) v[r] = pf_tanh<FAST>(acc[t][r] + bias);
+            if (d.save_gates && d.aux_out != nullptr) put(v, d.aux_out, d.ld_aux, j, nullptr, 0);          // q itself (training)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = (1.f - zv[r]) * hv[r] + zv[r] * v[r];
             put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
         }
     }
@@ -211,7 +225,8 @@ __device__ __forceinline__ void tile_epilogue_pair_t(const pf_conv_desc& d, cons
         const int jt = jb + 32 * t, j = jt + li;
         const bool jok = j < d.cout;
         bias[t] = jok ? d.bias[j] : 0.f;
-        const bool need_h = jok && ((epi == PF_EPI_GRU_ZR && jt >= 128) || epi == PF_EPI_GRU_Q || epi == PF_EPI_RELU_RES);
+        const bool need_h = jok && ((epi == PF_EPI_GRU_ZR && jt >= 128) || epi == PF_EPI_GRU_Q || epi == PF_EPI_RELU_RES ||
+                                    epi == PF_EPI_MASK || epi == PF_EPI_ADD);
         const bool need_z = jok && epi == PF_EPI_GRU_Q;
         const int hc = epi == PF_EPI_GRU_ZR ? j - 128 : j;
         static_for<0, 2>([&](auto M) __attribute__((always_inline)) {
@@ -269,7 +284,9 @@ __device__ __forceinline__ void tile_epilogue_pair_t(const pf_conv_desc& d, cons
                         static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = pf_sigmoid<FAST>(acc[m][t][r] + b); });
                         put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
                     } else {
-                        static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = pf_sigmoid<FAST>(acc[m][t][r] + b) * hv[m][t][r]; });
+                        static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = pf_sigmoid<FAST>(acc[m][t][r] + b); });
+                        if (d.save_gates && d.aux_out != nullptr) put(v, d.aux_out, d.ld_aux, j, nullptr, 0);      // r itself (training)
+                        static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = v[r] * hv[m][t][r]; });
                         put(v, d.aux_out, d.ld_aux, j - 128, d.aux_split, d.lds_aux);
                     }
                 } else if (epi == PF_EPI_TANH_RELU) {
@@ -283,10 +300,18 @@ __device__ __forceinline__ void tile_epilogue_pair_t(const pf_conv_desc& d, cons
                 } else if (epi == PF_EPI_RELU_RES) {
                     static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = fmaxf(hv[m][t][r] + fmaxf(acc[m][t][r] + b, 0.f), 0.f); });
                     put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
+                } else if (epi == PF_EPI_MASK) {
+                    static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = hv[m][t][r] > 0.f ? (acc[m][t][r] + b) * d.scale : 0.f; });
+                    put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
+                } else if (epi == PF_EPI_ADD) {
+                    static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = (acc[m][t][r] + b) * d.scale + hv[m][t][r]; });
+                    put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
                 } else {   // PF_EPI_GRU_Q
+                    static_for<0, 16>([&](auto R) { constexpr int r = decltype(R)::value; v[r] = pf_tanh<FAST>(acc[m][t][r] + b); });
+                    if (d.save_gates && d.aux_out != nullptr) put(v, d.aux_out, d.ld_aux, j, nullptr, 0);          // q itself (training)
                     static_for<0, 16>([&](auto R) {
                         constexpr int r = decltype(R)::value;
-                        v[r] = (1.f - zv[m][t][r]) * hv[m][t][r] + zv[m][t][r] * pf_tanh<FAST>(acc[m][t][r] + b);
+                        v[r] = (1.f - zv[m][t][r]) * hv[m][t][r] + zv[m][t][r] * v[r];
                     });
                     put(v, d.out, d.ld_out, d.off_out + j, d.out_split, d.lds_out);
                 }

@@ -184,18 +184,20 @@ class Conv:
 
     def desc(self, in0, off0, c0, out, off_out, epilogue, in1=None, off1=0, c1=0, scale=1.0,
              h=None, z=None, aux=None, stride=1, in_scale=None, in_shift=None, in_relu=False,
-             stats=None, in0s=None, in1s=None, outs=None, auxs=None, pre=None, off_pre=0) -> ConvDesc:
+             stats=None, in0s=None, in1s=None, outs=None, auxs=None, pre=None, off_pre=0, save_gates=False) -> ConvDesc:
         """in0s / in1s / outs / auxs: optional split twins (``split_twin``) of in0 / in1 / out / aux; with a twin given the
         fp32 tensor may be None (operands: the all-DMA kernel reads only the twins; outputs: twin only)."""
         assert c0 + c1 == self.cin, (c0, c1, self.cin)
         d = ConvDesc()
+        # row buffers may be column-sliced views of wider ones: the row stride, not the view's width, is the leading dimension
+        ld = lambda t: 0 if t is None else (t.stride(-2) if t.dim() >= 2 else t.shape[-1])       # noqa: E731
         d.in0 = in0.data_ptr() if in0 is not None else None
-        d.ld0, d.off0, d.c0 = (in0.shape[-1] if in0 is not None else 0), off0, c0
+        d.ld0, d.off0, d.c0 = ld(in0), off0, c0
         d.in1 = in1.data_ptr() if in1 is not None else None
-        d.ld1, d.off1, d.c1 = (in1.shape[-1] if in1 is not None else 0), off1, c1
+        d.ld1, d.off1, d.c1 = ld(in1), off1, c1
         d.weight, d.bias = self.w.data_ptr(), self.b.data_ptr()
         d.out = out.data_ptr() if out is not None else None
-        d.ld_out, d.off_out, d.cout = (out.shape[-1] if out is not None else 0), off_out, self.cout
+        d.ld_out, d.off_out, d.cout = ld(out), off_out, self.cout
         for name, t in (("in0_split", in0s), ("in1_split", in1s), ("out_split", outs), ("aux_split", auxs)):
             if t is not None:
                 assert t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[2:] == (2, 32) and t.is_contiguous(), name
@@ -210,11 +212,11 @@ class Conv:
         d.lds_aux = auxs.shape[1] if auxs is not None else 0
         d.kh, d.kw, d.epilogue, d.scale = self.kh, self.kw, epilogue, scale
         d.h = h.data_ptr() if h is not None else None
-        d.ld_h = h.shape[-1] if h is not None else 0
+        d.ld_h = ld(h)
         d.z = z.data_ptr() if z is not None else None
-        d.ld_z = z.shape[-1] if z is not None else 0
+        d.ld_z = ld(z)
         d.aux_out = aux.data_ptr() if aux is not None else None
-        d.ld_aux = aux.shape[-1] if aux is not None else 0
+        d.ld_aux = ld(aux)
         d.precision = self.precision
         d.stride = stride
         d.in_scale = in_scale.data_ptr() if in_scale is not None else None
@@ -223,7 +225,8 @@ class Conv:
         d.stats_out = stats.data_ptr() if stats is not None else None
         # start value of the accumulation (all-DMA kernel): channel-last fp32 [rows][ld_pre], this conv's channels at off_pre
         d.pre = pre.data_ptr() if pre is not None else None
-        d.ld_pre, d.off_pre = (pre.shape[-1] if pre is not None else 0), off_pre
+        d.ld_pre, d.off_pre = ld(pre), off_pre
+        d.save_gates = int(save_gates)      # training forward: GRU_ZR also stores r, GRU_Q also stores q (into aux)
         # the C struct holds raw pointers only: keep every tensor alive for as long as the descriptor is
         d._keep = (in0, in1, out, h, z, aux, in_scale, in_shift, stats, self.w, self.b, in0s, in1s, outs, auxs, zb, pre)
         return d

@@ -129,13 +129,13 @@ class PriOr_RAFT(nn.Module):
             cur = torch.cuda.current_stream()
             s1, s2 = self._streams()[:2]
             # Which queue gets which encoder (round 4, profiles/r4_encoder_order.txt).  The phase is bound by the SUM of the two
-            # encoders' kernel time, not by when cnet starts: with fnet on the calling stream and cnet forked behind it (round 3)
+            # encoders' kernel time, not by when cnet starts: with fnet on the calling stream and cnet forked behind it (default)
             # cnet's first kernel only gets CUs at t = 1.5 ms, because every fnet launch of layers 1-2 fills the chip and a
-            # queued workgroup of the older queue wins a freed CU; with both on side streams (default) or cnet on the calling
-            # stream, cnet starts at t = 0.2 ms and both chains run at half speed beside each other -- the phase ends 50-75 us
-            # earlier (2.44 / 2.47 against 2.51 ms), the only gain being the tails and one-workgroup kernels of one chain
-            # filled by the other.
-            order = os.environ.get("PRIORFLOW_ENC_ORDER", "both_side")
+            # queued workgroup of the older queue wins a freed CU; with both on side streams ("both_side") or cnet on the
+            # calling stream ("cnet_main"), cnet starts at t = 0.2 ms and both chains run at half speed beside each other.
+            # Under the tracer the phase then ends 50-75 us earlier (2.44 / 2.47 against 2.51 ms); untraced, interleaved on one
+            # box, the forward is no faster (129.2 / 129.2 against 129.8 / 129.9 pairs/s): the default stays.
+            order = os.environ.get("PRIORFLOW_ENC_ORDER", "fnet_main")
             if order == "fnet_main" or defer_cnet_join:
                 # fnet (the longer chain) stays on the calling stream and is enqueued first; cnet forks from an event
                 ev = torch.cuda.Event()

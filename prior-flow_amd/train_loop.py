@@ -1,0 +1,355 @@
+"""The refinement loop of the TRAINING step as ONE autograd node with a hand-written backward (round 4).
+
+``autograd.train_forward`` keeps torch autograd as the tape of the encoders and of the correlation pyramids, but the
+``iters`` refinement iterations (core/prior_raft.py:170-211: flows, warps, DCCL lookups, both update blocks, convex
+upsampling) no longer put ~60 nodes per iteration on that tape.  ``LoopFn`` runs them on a preallocated workspace
+(``LoopBuffers``: every activation of every iteration is kept, [iters][B*N][C] channel-last rows, because the backward needs
+them) and walks the iterations backwards itself:
+
+  * every ReLU lives in a convolution epilogue (forward: PF_EPI_RELU; backward: PF_EPI_MASK = data gradient x ReLU mask),
+    the GRU gates in PF_EPI_GRU_ZR / PF_EPI_GRU_Q with ``save_gates`` (r and q are operands of pf_gru_*_bwd), gradient
+    accumulation into a tensor with several consumers in PF_EPI_ADD; ``torch.cat`` is a column slice of a wider row buffer;
+  * the WEIGHT gradients are deferred: a convolution that runs in all ``iters`` iterations gets ONE pf_conv2d_wgrad launch
+    over the iters * B stored (input, output-gradient) images at the end of the backward instead of one launch per
+    iteration on a 48 x 64 map (core/update.py's 19 + 17 convolutions: 36 launches instead of 432 per step, each with
+    12x the pixels to split over the chip);
+  * coords1 is detached at every iteration (core/prior_raft.py:171,176), so an iteration's backward needs only the
+    gradient of its two predictions and of the hidden states it hands on.
+
+Reference lines: core/update.py:81-99 (BasicMotionEncoder), :117-136 (BasicUpdateBlock), :139-159 + :162-201 (ODDC),
+:35-60 (SepConvGRU), :6-14 (FlowHead); train_flow.py:131-135 (forward + loss.backward()).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import EPI_ADD, EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_MASK, EPI_RELU, PREC_BF16X3
+from .engine import Conv, pack_mfma
+
+
+class LoopBuffers:
+    """Activations and gradients of all iterations of one (B, H8, W8, iters) problem; allocated once per shape."""
+
+    def __init__(self, B: int, H8: int, W8: int, iters: int, device):
+        self.key = (B, H8, W8, iters, str(device))
+        N = B * H8 * W8
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)      # noqa: E731
+        it = iters
+        self.N = N
+        for t in "ab":
+            s: Dict[str, torch.Tensor] = {}
+            # ---- forward activations, one slice per iteration
+            s["corr"] = z(it, N, 324)
+            s["c1"] = z(it, N, 256)
+            s["cat"] = z(it, N, 272 if t == "a" else 256)          # a: [cor 128 | floA 64 | floB 64 | conf 16]; b: [cor 192 | flo 64]
+            s["x"] = z(it, N, 256)                                  # GRU input [inp | out | flow tails]
+            s["h"] = z(it + 1, N, 128)                              # hidden state entering iteration i; [it] = the last one
+            s["h1"] = z(it, N, 128)                                 # after the horizontal half-step
+            for k in "12":
+                s["z" + k] = z(it, N, 128)
+                s["rhr" + k] = z(it, N, 256)                        # [r*h | r]
+                s["q" + k] = z(it, N, 128)
+            s["fh"] = z(it, N, 256)
+            s["mh"] = z(it, N, 256)
+            s["mask"] = z(it, N, 576)
+            s["delta"] = z(it, N, 4)
+            s["c_pre"] = z(it, B, 2, H8, W8)                        # coords1 the iteration starts from
+            s["c_post"] = z(it, B, 2, H8, W8)                       # ... and ends with (the upsampling's flow)
+            # ---- output gradients of the convolutions (operands of the deferred weight gradients)
+            s["d_mask"] = z(it, N, 576)
+            s["d_mh"] = z(it, N, 256)
+            s["d_delta"] = z(it, N, 4)                              # columns 2, 3 stay zero (Cout 2 padded to 4)
+            s["d_fh"] = z(it, N, 256)
+            for k in "12":
+                s["d_q" + k] = z(it, N, 128)
+                s["d_zr" + k] = z(it, N, 256)
+            s["d_out"] = z(it, N, 128)                              # 124 / 126 live columns
+            s["d_cat"] = z(it, N, 272 if t == "a" else 256)
+            s["d_c1"] = z(it, N, 256)
+            # ---- scratch of one iteration's backward
+            s["F"] = [z(N, 512) for _ in range(4)]                  # [d(r*h) | d x | d h] of a half-step; two pairs, ping-pong
+            s["dz"] = z(N, 128)
+            s["d_corr"] = z(N, 324)
+            s["d_raw"] = z(N, 324)
+            s["d_flow"] = z(B, 2, H8, W8)
+            s["own"], s["raw"] = z(N, 324), z(N, 324)
+            setattr(self, t, s)
+        a, b = self.a, self.b
+        a["flow4"] = z(it, N, 4)                                    # [flow_A | flow_B_A]
+        a["t_a"], a["t_ba"] = z(it, N, 128), z(it, N, 128)          # 7x7 stem outputs
+        a["conf_in"], a["cf1"] = z(it, N, 8), z(it, N, 32)
+        a["d_t_a"], a["d_t_ba"], a["d_cf1"] = z(it, N, 128), z(it, N, 128), z(it, N, 32)
+        a["d_conf"] = z(N, 8)
+        a["flow_ba"] = z(B, 2, H8, W8)
+        b["flow2"] = z(it, N, 2)                                    # flow_B (pf_motion_prep writes 2-float rows)
+        b["t"], b["d_t"] = z(it, N, 128), z(it, N, 128)
+
+
+def _flat(t: torch.Tensor) -> torch.Tensor:
+    """[iters][N][C] -> [iters * N][C] (the iterations as extra images of the deferred weight gradient)."""
+    return t.view(-1, t.shape[-1])
+
+
+class _Packs:
+    """Forward / data-gradient packs of the update blocks' convolutions for one forward (cached per weight version by
+    autograd._pack) plus the (token, WeightGrad) pair of each."""
+
+    def __init__(self, model, zr_a, zr_b, gate_of):
+        from .autograd import _pack, _src_key
+        self.fwd: Dict[str, Conv] = {}
+        self.dg: Dict[str, Conv] = {}
+        self.acc: Dict[str, object] = {}
+        self.mods: Dict[str, object] = {}
+        ea, eb = model.ODDC.encoder, model.update_block.encoder
+        named = {"a.c1": ea.convc1_A, "a.c2": ea.convc2_A, "a.f2a": ea.convf2_A, "a.f2b": ea.convf2_B,
+                 "a.cf1": ea.conv_conf1, "a.cf2": ea.conv_conf2, "a.out": ea.conv_A,
+                 "b.c1": eb.convc1, "b.c2": eb.convc2, "b.f2": eb.convf2, "b.out": eb.conv}
+        for t, blk in (("a", model.ODDC), ("b", model.update_block)):
+            named[t + ".q1"], named[t + ".q2"] = blk.gru.convq1, blk.gru.convq2
+            named[t + ".fh1"], named[t + ".fh2"] = blk.flow_head.conv1, blk.flow_head.conv2
+            named[t + ".m0"], named[t + ".m2"] = blk.mask[0], blk.mask[2]
+        for name, m in named.items():
+            self.mods[name] = m
+            self.fwd[name] = _pack(m.weight, m.bias, "fwd")
+            self.dg[name] = _pack(m.weight, None, "dgrad")
+            self.acc[name] = gate_of(m)[1]
+        # fused z|r convolutions: forward pack of the concatenated weights; the data gradient with its OUTPUT channels
+        # reordered [x 256 | h 128] (so that d x and d h land next to each other in the half-step's scratch rows)
+        for t, zr in (("a", zr_a), ("b", zr_b)):
+            for k in "12":
+                w, bias, src, _tok, acc = zr[k]
+                self.fwd[f"{t}.zr{k}"] = _pack(w, bias, "fwd", src)
+                key = ("dgrad_xh",) + tuple(src)
+                wx = torch.cat([w[:, 128:], w[:, :128]], 1)
+                self.dg[f"{t}.zr{k}"] = _pack(wx, None, "dgrad", key)
+                self.acc[f"{t}.zr{k}"] = acc
+        self.stems = {"a.f1a": ea.convf1_A, "a.f1b": ea.convf1_B, "b.f1": eb.convf1}
+        self.stem_w = {n: (m.weight.detach().permute(2, 3, 1, 0).reshape(-1, m.weight.shape[0]).contiguous(),
+                           m.bias.detach().contiguous()) for n, m in self.stems.items()}
+        del _src_key
+
+
+def _conv(lib, cv: Conv, B, H8, W8, x, off0, c0, out, off_out, epi, **kw):
+    lib.conv2d([cv.desc(x, off0, c0, out, off_out, epi, **kw)], B, H8, W8, x)
+
+
+class LoopFn(torch.autograd.Function):
+    """(net_A, net_B, inp_A, inp_B, f1_A, f2_A, pyramid tokens, stem parameters, weight tokens) -> 2 * iters flow predictions."""
+
+    @staticmethod
+    def forward(ctx, cfg, net_a, net_b, inp_a, inp_b, f1a, f2a, tok_pa, tok_pb, *rest):
+        from .autograd import _rows, STATS
+        lib = _lib.load()
+        model, P, pyr_a, pyr_b, coords0, c1a, c1b, g_a2b_8, g_b2a_8, iters = (
+            cfg["model"], cfg["packs"], cfg["pyr_a"], cfg["pyr_b"], cfg["coords0"], cfg["c1a"], cfg["c1b"],
+            cfg["g_a2b_8"], cfg["g_b2a_8"], cfg["iters"])
+        B, _, H8, W8 = coords0.shape
+        dev = coords0.device
+        bufs: Optional[LoopBuffers] = getattr(model, "_loop_bufs", None)
+        if bufs is None or bufs.key != (B, H8, W8, iters, str(dev)):
+            bufs = model._loop_bufs = LoopBuffers(B, H8, W8, iters, dev)
+        A, Bb = bufs.a, bufs.b
+        N = bufs.N
+        f1r, f2r = _rows(f1a.detach()), _rows(f2a.detach())
+        A["h"][0].copy_(_rows(net_a.detach()))
+        Bb["h"][0].copy_(_rows(net_b.detach()))
+        A["x"][:, :, :128] = _rows(inp_a.detach())                  # the context features enter every iteration's GRU input
+        Bb["x"][:, :, :128] = _rows(inp_b.detach())
+        c1a, c1b = c1a.clone(), c1b.clone()
+        H, W = 8 * H8, 8 * W8
+        preds_a = [torch.empty(B, 2, H, W, device=dev) for _ in range(iters)]
+        preds_b = [torch.empty(B, 2, H, W, device=dev) for _ in range(iters)]
+        cv = lambda name, *a, **k: _conv(lib, P.fwd[name], B, H8, W8, *a, **k)      # noqa: E731
+        n_launch = 0
+        for i in range(iters):
+            A["c_pre"][i].copy_(c1a)
+            Bb["c_pre"][i].copy_(c1b)
+            # flows, flo_rotate(flow_B), both feature warps + groupwise correlations: one launch (prior_raft.py:171-182)
+            lib.motion_prep(c1a, c1b, g_a2b_8, g_b2a_8, f1r, f2r, A["flow4"][i], Bb["flow2"][i], A["conf_in"][i],
+                            A["x"][i], 252, Bb["x"][i], 254)
+            # DCCL lookups (prior_raft.py:185-188)
+            lib.dccl_lookup(c1a, pyr_a[0], pyr_b[0], g_b2a_8, A["own"], A["raw"])
+            lib.dccl_combine(A["own"], A["raw"], g_b2a_8, A["corr"][i], B, H8, W8)
+            lib.dccl_lookup(c1b, pyr_b[0], pyr_a[0], g_a2b_8, Bb["own"], Bb["raw"])
+            lib.dccl_combine(Bb["own"], Bb["raw"], g_a2b_8, Bb["corr"][i], B, H8, W8)
+            # ---- motion encoders (update.py:183-201, :91-99)
+            cv("a.c1", A["corr"][i], 0, 324, A["c1"][i], 0, EPI_RELU)
+            cv("b.c1", Bb["corr"][i], 0, 324, Bb["c1"][i], 0, EPI_RELU)
+            cv("a.c2", A["c1"][i], 0, 256, A["cat"][i], 0, EPI_RELU)
+            cv("b.c2", Bb["c1"][i], 0, 256, Bb["cat"][i], 0, EPI_RELU)
+            for name, src, off, dst in (("a.f1a", A["flow4"][i], 0, A["t_a"][i]), ("a.f1b", A["flow4"][i], 2, A["t_ba"][i]),
+                                        ("b.f1", Bb["flow2"][i], 0, Bb["t"][i])):
+                w, bias = P.stem_w[name]
+                lib.conv2d_small(src, False, off, 2, w, bias, dst, 0, 128, 7, 7, 1, True, B, H8, W8)
+            cv("a.f2a", A["t_a"][i], 0, 128, A["cat"][i], 128, EPI_RELU)
+            cv("a.f2b", A["t_ba"][i], 0, 128, A["cat"][i], 192, EPI_RELU)
+            cv("b.f2", Bb["t"][i], 0, 128, Bb["cat"][i], 192, EPI_RELU)
+            cv("a.cf1", A["conf_in"][i], 0, 8, A["cf1"][i], 0, EPI_RELU)
+            cv("a.cf2", A["cf1"][i], 0, 32, A["cat"][i], 256, EPI_RELU)
+            cv("a.out", A["cat"][i], 0, 272, A["x"][i], 128, EPI_RELU)
+            cv("b.out", Bb["cat"][i], 0, 256, Bb["x"][i], 128, EPI_RELU)
+            # ---- SepConvGRU (update.py:46-60), heads (update.py:13-14, :124-136)
+            for t, S in (("a", A), ("b", Bb)):
+                h0, h1, h2, x = S["h"][i], S["h1"][i], S["h"][i + 1], S["x"][i]
+                cv(t + ".zr1", h0, 0, 128, S["z1"][i], 0, EPI_GRU_ZR, in1=x, off1=0, c1=256, h=h0, aux=S["rhr1"][i], save_gates=True)
+                cv(t + ".q1", S["rhr1"][i], 0, 128, h1, 0, EPI_GRU_Q, in1=x, off1=0, c1=256, h=h0, z=S["z1"][i], aux=S["q1"][i], save_gates=True)
+                cv(t + ".zr2", h1, 0, 128, S["z2"][i], 0, EPI_GRU_ZR, in1=x, off1=0, c1=256, h=h1, aux=S["rhr2"][i], save_gates=True)
+                cv(t + ".q2", S["rhr2"][i], 0, 128, h2, 0, EPI_GRU_Q, in1=x, off1=0, c1=256, h=h1, z=S["z2"][i], aux=S["q2"][i], save_gates=True)
+                cv(t + ".fh1", h2, 0, 128, S["fh"][i], 0, EPI_RELU)
+                cv(t + ".fh2", S["fh"][i], 0, 256, S["delta"][i], 0, EPI_LINEAR)
+                cv(t + ".m0", h2, 0, 128, S["mh"][i], 0, EPI_RELU)
+                cv(t + ".m2", S["mh"][i], 0, 256, S["mask"][i], 0, EPI_LINEAR, scale=0.25)
+            lib.coords_add(c1a, A["delta"][i])                      # coords1 += delta_flow (prior_raft.py:193,196)
+            lib.coords_add(c1b, Bb["delta"][i])
+            A["c_post"][i].copy_(c1a)
+            Bb["c_post"][i].copy_(c1b)
+            lib.upsample_flow(c1a, A["mask"][i], preds_a[i])        # prior_raft.py:200-208
+            lib.upsample_flow(c1b, Bb["mask"][i], preds_b[i])
+            n_launch += 7 + 14 + 16 + 4
+        STATS["hip"] += n_launch
+        ctx.cfg, ctx.bufs = cfg, bufs
+        ctx.save_for_backward(f1r, f2r)
+        ctx.n_rest = len(rest)
+        return (*preds_a, *preds_b)
+
+    @staticmethod
+    def backward(ctx, *g_preds):
+        from .autograd import _nchw, STATS
+        lib = _lib.load()
+        cfg, bufs = ctx.cfg, ctx.bufs
+        P, pyr_a, pyr_b, coords0, g_a2b_8, g_b2a_8, iters = (cfg["packs"], cfg["pyr_a"], cfg["pyr_b"], cfg["coords0"],
+                                                             cfg["g_a2b_8"], cfg["g_b2a_8"], cfg["iters"])
+        f1r, f2r = ctx.saved_tensors
+        B, _, H8, W8 = coords0.shape
+        dev = coords0.device
+        A, Bb = bufs.a, bufs.b
+        N = bufs.N
+        dg = lambda name, *a, **k: _conv(lib, P.dg[name], B, H8, W8, *a, **k)       # noqa: E731
+        d_f1, d_f2 = torch.zeros_like(f1r), torch.zeros_like(f2r)
+        d_inp = {"a": torch.zeros(N, 128, device=dev), "b": torch.zeros(N, 128, device=dev)}
+        gp = {"a": g_preds[:iters], "b": g_preds[iters:]}
+        pg_a, pg_b = pyr_a[2].buffers(pyr_a[0]), pyr_b[2].buffers(pyr_b[0])
+        # gradient of the hidden state an iteration hands on: nothing reads the last one
+        gh: Dict[str, Optional[torch.Tensor]] = {"a": None, "b": None}
+        n_launch = 0
+        for i in range(iters - 1, -1, -1):
+            for t, S in (("a", A), ("b", Bb)):
+                g = gp[t][i]
+                Fq2, Fq1 = S["F"][2 * (i & 1)], S["F"][2 * (i & 1) + 1]     # ping-pong: gh of iteration i + 1 lives in the other pair
+                if gh[t] is None:
+                    Fq1[:, 384:].zero_()                                     # borrowed as the zero gradient of the last state
+                    ghv = Fq1[:, 384:]
+                else:
+                    ghv = gh[t]
+                # ---- heads (the two consumers of h2 add into the gradient the next iteration left for it)
+                if g is not None:
+                    S["d_flow"].zero_()
+                    lib.upsample_flow_bwd(S["c_post"][i], S["mask"][i], g.contiguous(), S["d_mask"][i], S["d_flow"])
+                    S["d_mask"][i].mul_(0.25)                                # mask = 0.25 * conv (update.py:134,157)
+                    lib.to_channel_last(S["d_flow"], 0, 2, S["d_delta"][i], 0)
+                    dg(t + ".m2", S["d_mask"][i], 0, 576, S["d_mh"][i], 0, EPI_MASK, h=S["mh"][i])
+                    dg(t + ".m0", S["d_mh"][i], 0, 256, ghv, 0, EPI_ADD, h=ghv)
+                    dg(t + ".fh2", S["d_delta"][i], 0, 4, S["d_fh"][i], 0, EPI_MASK, h=S["fh"][i])
+                    dg(t + ".fh1", S["d_fh"][i], 0, 256, ghv, 0, EPI_ADD, h=ghv)
+                    n_launch += 8
+                else:
+                    S["d_mask"][i].zero_(); S["d_mh"][i].zero_(); S["d_delta"][i].zero_(); S["d_fh"][i].zero_()
+                # ---- GRU, vertical then horizontal half-step (update.py:55-60, :48-53 in reverse)
+                x = S["x"][i]
+                for k, F, h_in, g_in in (("2", Fq2, S["h1"][i], ghv), ("1", Fq1, S["h"][i], None)):
+                    if g_in is None:
+                        g_in = Fq2[:, 384:]                                  # d h1 of the vertical half-step
+                    lib.gru_q_bwd(g_in, S["z" + k][i], S["q" + k][i], h_in, S["d_q" + k][i], S["dz"], F[:, 384:])
+                    dg(f"{t}.q{k}", S["d_q" + k][i], 0, 128, F, 0, EPI_LINEAR)                    # [d(r*h) | d x]
+                    lib.gru_zr_bwd(S["dz"], F[:, :128], S["z" + k][i], S["rhr" + k][i][:, 128:], h_in, S["d_zr" + k][i], F[:, 384:])
+                    dg(f"{t}.zr{k}", S["d_zr" + k][i], 0, 256, F, 128, EPI_ADD, h=F[:, 128:])       # [d x | d h] +=
+                    n_launch += 4
+                gh[t] = Fq1[:, 384:]
+                # d x = [d inp | d out | flows]: inp feeds every iteration, out = relu(conv) -> mask
+                dx = Fq1[:, 128:384] + Fq2[:, 128:384]
+                d_inp[t] += dx[:, :128]
+                wout = 124 if t == "a" else 126
+                S["d_out"][i][:, :wout] = dx[:, 128:128 + wout] * (x[:, 128:128 + wout] > 0)
+                # ---- motion encoder
+                ccat = 272 if t == "a" else 256
+                dg(t + ".out", S["d_out"][i], 0, 128 if t == "b" else 124, S["d_cat"][i], 0, EPI_MASK, h=S["cat"][i])
+                ncor = 128 if t == "a" else 192
+                dg(t + ".c2", S["d_cat"][i], 0, ncor, S["d_c1"][i], 0, EPI_MASK, h=S["c1"][i])
+                dg(t + ".c1", S["d_c1"][i], 0, 256, S["d_corr"], 0, EPI_LINEAR)
+                S["d_raw"].zero_()
+                g_back = g_b2a_8 if t == "a" else g_a2b_8
+                lib.dccl_combine_bwd(S["d_corr"], g_back, S["d_raw"], B, H8, W8)
+                lib.dccl_lookup_bwd(S["c_pre"][i], g_back, S["d_corr"], S["d_raw"], pg_a if t == "a" else pg_b, pg_b if t == "a" else pg_a)
+                n_launch += 5
+                if t == "a":
+                    dg("a.f2a", S["d_cat"][i], 128, 64, S["d_t_a"][i], 0, EPI_MASK, h=S["t_a"][i])
+                    dg("a.f2b", S["d_cat"][i], 192, 64, S["d_t_ba"][i], 0, EPI_MASK, h=S["t_ba"][i])
+                    dg("a.cf2", S["d_cat"][i], 256, 16, S["d_cf1"][i], 0, EPI_MASK, h=S["cf1"][i])
+                    dg("a.cf1", S["d_cf1"][i], 0, 32, S["d_conf"], 0, EPI_LINEAR)
+                    lib.warp_gcorr_bwd(f1r, f2r, S["c_pre"][i], False, S["d_conf"], 0, d_f1, d_f2)
+                    lib.to_nchw(S["flow4"][i], 2, 2, S["flow_ba"])
+                    lib.warp_gcorr_bwd(f1r, f2r, S["flow_ba"], True, S["d_conf"], 4, d_f1, d_f2)
+                    n_launch += 7
+                else:
+                    dg("b.f2", S["d_cat"][i], 192, 64, S["d_t"][i], 0, EPI_MASK, h=S["t"][i])
+                    n_launch += 1
+                del ccat
+        # ---- deferred weight gradients: one launch per convolution over the iters * B stored images
+        Bi = iters * B
+
+        def wg(name, x0, off0, c0, dy, off_dy, cout, x1=None, off1=0, c1=0):
+            m = P.fwd[name]
+            dw, db = P.acc[name].buffers((max(cout, m.cout) + 127) // 128 * 128, m.kh * m.kw, (c0 + c1 + 31) // 32 * 32, dev)
+            lib.conv2d_wgrad(_flat(x0), off0, c0, _flat(dy), off_dy, cout, dw, db, m.kh, m.kw, Bi, H8, W8,
+                             x1=None if x1 is None else _flat(x1), off1=off1, c1=c1)
+
+        for t, S in (("a", A), ("b", Bb)):
+            hs = S["h"]
+            wg(t + ".m2", S["mh"], 0, 256, S["d_mask"], 0, 576)
+            wg(t + ".m0", hs[1:], 0, 128, S["d_mh"], 0, 256)
+            wg(t + ".fh2", S["fh"], 0, 256, S["d_delta"], 0, 4)
+            wg(t + ".fh1", hs[1:], 0, 128, S["d_fh"], 0, 256)
+            wg(t + ".q2", S["rhr2"], 0, 128, S["d_q2"], 0, 128, x1=S["x"], off1=0, c1=256)
+            wg(t + ".zr2", S["h1"], 0, 128, S["d_zr2"], 0, 256, x1=S["x"], off1=0, c1=256)
+            wg(t + ".q1", S["rhr1"], 0, 128, S["d_q1"], 0, 128, x1=S["x"], off1=0, c1=256)
+            wg(t + ".zr1", hs[:iters], 0, 128, S["d_zr1"], 0, 256, x1=S["x"], off1=0, c1=256)
+            wg(t + ".c1", S["corr"], 0, 324, S["d_c1"], 0, 256)
+        wg("a.out", A["cat"], 0, 272, A["d_out"], 0, 124)
+        wg("b.out", Bb["cat"], 0, 256, Bb["d_out"], 0, 128)
+        wg("a.c2", A["c1"], 0, 256, A["d_cat"], 0, 128)
+        wg("b.c2", Bb["c1"], 0, 256, Bb["d_cat"], 0, 192)
+        wg("a.f2a", A["t_a"], 0, 128, A["d_cat"], 128, 64)
+        wg("a.f2b", A["t_ba"], 0, 128, A["d_cat"], 192, 64)
+        wg("b.f2", Bb["t"], 0, 128, Bb["d_cat"], 192, 64)
+        wg("a.cf2", A["cf1"], 0, 32, A["d_cat"], 256, 16)
+        wg("a.cf1", A["conf_in"], 0, 8, A["d_cf1"], 0, 32)
+        stem_grads = []
+        for name, x, off, dy in (("a.f1a", A["flow4"], 0, A["d_t_a"]), ("a.f1b", A["flow4"], 2, A["d_t_ba"]), ("b.f1", Bb["flow2"], 0, Bb["d_t"])):
+            m = P.stems[name]
+            dw, db = torch.zeros_like(m.weight), torch.zeros_like(m.bias)
+            lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, dw, db, 7, 7, 1, Bi, H8, W8)
+            stem_grads += [dw, db]
+        n_launch += 29 + 3
+        STATS["hip"] += n_launch
+        d_net_a, d_net_b = _nchw(gh["a"].contiguous(), B, H8, W8), _nchw(gh["b"].contiguous(), B, H8, W8)
+        zero = torch.zeros(1, device=dev)
+        return (None, d_net_a, d_net_b, _nchw(d_inp["a"], B, H8, W8), _nchw(d_inp["b"], B, H8, W8),
+                _nchw(d_f1, B, H8, W8), _nchw(d_f2, B, H8, W8), zero, zero, *stem_grads, *([zero] * (ctx.n_rest - 6)))
+
+
+def run_loop(model, lib, zr_a, zr_b, gate_of, net_a, net_b, inp_a, inp_b, f1a, f2a, pyr_a, pyr_b, coords0, c1a, c1b,
+             g_a2b_8, g_b2a_8, iters: int):
+    """The ``iters`` refinement iterations as one autograd node; returns (preds_A, preds_B)."""
+    P = _Packs(model, zr_a, zr_b, gate_of)
+    cfg = dict(model=model, packs=P, pyr_a=pyr_a, pyr_b=pyr_b, coords0=coords0, c1a=c1a, c1b=c1b, g_a2b_8=g_a2b_8,
+               g_b2a_8=g_b2a_8, iters=iters)
+    stems = []
+    for m in P.stems.values():
+        stems += [m.weight, m.bias]
+    # the weight tokens order this node's backward in front of every WeightGate's (which unpacks the accumulated gradients)
+    toks = [gate_of(m)[0] for m in P.mods.values()] + [zr[k][3] for zr in (zr_a, zr_b) for k in "12" if zr[k][3] is not None]
+    out = LoopFn.apply(cfg, net_a, net_b, inp_a, inp_b, f1a, f2a, pyr_a[1], pyr_b[1], *stems, *toks)
+    return list(out[:iters]), list(out[iters:])
