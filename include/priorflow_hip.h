@@ -81,6 +81,19 @@ int pf_corr_pyramid_bf16x3(const void* f1_split, const void* f2_split, float* lv
  * format of the PF_PREC_BF16X3 GEMMs.  hi = bf16(x) round-to-nearest-even, lo = bf16(x - hi). */
 int pf_split_bf16(const float* in, void* out, long rows, int C, void* stream);
 
+/* nn.Conv2d weights -> the PF_PREC_BF16X3 operand format of pf_conv2d, on the device, in one launch (what a training step
+ * does for every convolution after each optimizer step, train_flow.py:138-140; replaces ~9 PyTorch-ROCm kernels per pack).
+ * w0 [cout0][cin][kh][kw] and optionally w1 [cout1][cin][kh][kw] concatenated on the output channels (the fused z|r
+ * convolution of core/update.py:48-49); b0 / b1 their biases (NULL = zero).
+ *   mode 0: forward convolution: dst_w [cout_pad][kh*kw][cin_pad/32] x {bf16 hi[32], bf16 lo[32]}, dst_b [cout_pad].
+ *   mode 1: its data-gradient convolution (pf_conv2d_wgrad's comment): W'[c][o][ky][kx] = W[o][(c + cin_rot) % cin][kh-1-ky][kw-1-kx],
+ *           i.e. packed output channels = forward input channels rotated by cin_rot, packed input channels = forward output
+ *           channels; dst_b (optional) is zeroed.
+ * Padding rows / columns are written as zeros: dst needs no initialisation. */
+int pf_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, const float* b0, const float* b1,
+                         int cin, int kh, int kw, int mode, int cin_rot, void* dst_w, float* dst_b,
+                         int cout_pad, int cin_pad, void* stream);
+
 /* DCCL.__call__ steps 1-2 (core/corr.py:119-137): own-view 9x9x4 lookup and the raw
  * cross-view lookup through g_w2c.  coords: planar.  own_out/raw_out: channel-last, 324
  * channels = level*81 + a*9 + b (x += a-4, y += b-4), row stride ld >= 324. */

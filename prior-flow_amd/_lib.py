@@ -82,6 +82,7 @@ _SIGNATURES = {
     "pf_corr_pyramid": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_corr_pyramid_bf16x3": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_split_bf16": [_fp, _fp, C.c_long, _i, _fp],
+    "pf_pack_conv_weights": [_fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
     "pf_dccl_lookup_il": [_fp] * 13 + [_i, _i, _i, _i, _fp],
     "pf_dccl_lookup_pair": [C.c_void_p, _i, _i, _i, _i, _fp],
@@ -284,6 +285,23 @@ class PfLib:
         self._rc(self._dll.pf_split_bf16(_ptr(x), C.c_void_p(out.data_ptr()), x.shape[0], x.shape[-1],
                                          self._stream(x)), "pf_split_bf16")
         return out
+
+    def pack_conv_weights(self, w0, b0=None, w1=None, b1=None, mode=0, cin_rot=0, cout_pad_to=128):
+        """[Cout,Cin,KH,KW] weights (optionally two tensors concatenated on Cout) -> (bf16 split operand of pf_conv2d
+        [Cout_pad, KH*KW, Cin_pad/32, 2, 32], bias [Cout_pad]); mode 1: the data-gradient convolution's operand
+        (packed Cout = Cin of the forward conv rotated by cin_rot; packed Cin = forward Cout rounded up to 4, then 32)."""
+        self._chk(w0, w1, b0, b1)
+        cout0, cin, kh, kw = w0.shape
+        cout1 = 0 if w1 is None else w1.shape[0]
+        oc, ic = (cout0 + cout1, cin) if mode == 0 else (cin, cout0 + cout1)
+        op = (oc + cout_pad_to - 1) // cout_pad_to * cout_pad_to
+        cp = (ic + 31) // 32 * 32
+        dst_w = torch.empty(op, kh * kw, cp // 32, 2, 32, dtype=torch.bfloat16, device=w0.device)
+        dst_b = torch.empty(op, dtype=torch.float32, device=w0.device)
+        self._rc(self._dll.pf_pack_conv_weights(_ptr(w0), cout0, _ptr(w1), cout1, _ptr(b0), _ptr(b1), cin, kh, kw, mode, cin_rot,
+                                                C.c_void_p(dst_w.data_ptr()), _ptr(dst_b), op, cp, self._stream(w0)),
+                 "pf_pack_conv_weights")
+        return dst_w, dst_b
 
     def corr_pyramid_bf16x3(self, f1s, f2s, levels, B, H8, W8, Cch):
         self._chk(*levels)

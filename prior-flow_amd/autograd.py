@@ -70,26 +70,30 @@ def _src_key(*params: torch.Tensor) -> tuple:
     return tuple((p.data_ptr(), p._version) for p in params)
 
 
-def _pack(w: torch.Tensor, b: Optional[torch.Tensor], kind: str, src: Optional[tuple] = None):
-    # derived weights (the fused z|r tensors are rebuilt every forward) are keyed by their source parameters: the
-    # allocator may hand a new tensor the address of a freed one, so the tensor's own address proves nothing
+def _pack(w: torch.Tensor, b: Optional[torch.Tensor], kind: str, src: Optional[tuple] = None, w1: Optional[torch.Tensor] = None,
+          b1: Optional[torch.Tensor] = None, rot: int = 0):
+    """Packed operand of pf_conv2d for weights `w` (optionally `w1` concatenated on Cout: the fused z|r convolution):
+    kind "fwd" = the forward convolution (with bias b [| b1]), "dgrad" = its data-gradient convolution (flipped taps,
+    transposed channels, forward input channels rotated by `rot`, Cout padded to 4).  One pf_pack_conv_weights launch
+    (round 3 built the same bits with ~9 PyTorch-ROCm kernels per pack)."""
     if src is None:
-        src = _src_key(w) if b is None else _src_key(w, b)
-    key = (kind, src, tuple(w.shape), _lib.weights_epoch())
+        src = _src_key(*[t for t in (w, w1, b, b1) if t is not None])
+    cout = w.shape[0] + (0 if w1 is None else w1.shape[0])
+    _, cin, kh, kw = w.shape
+    key = (kind, rot, src, cout, tuple(w.shape[1:]), _lib.weights_epoch())
     hit = _PACKS.get(key)
     if hit is not None:
         return hit
     if len(_PACKS) > 256:           # one training step needs ~140 entries; stale ones go with the next refill
         _PACKS.clear()
-    cout, cin, kh, kw = w.shape
-    cp = (cout + 3) // 4 * 4
+    lib = _lib.load()
+    det = lambda t: None if t is None else t.detach().contiguous()      # noqa: E731
     if kind == "fwd":
-        wp, bp = pack_mfma(w.detach(), b.detach())
-        val = Conv(wp, bp, kh, kw, cin, cout, PREC_BF16X3)
-    else:           # data gradient: the forward kernel on flipped / transposed weights (Cout padded to 4 with zero rows)
-        wpad = torch.zeros(cp, cin, kh, kw, device=w.device)
-        wpad[:cout] = w.detach()
-        val = Conv.dgrad_of(wpad, PREC_BF16X3)
+        wp, bp = lib.pack_conv_weights(det(w), det(b), det(w1), det(b1), mode=0)
+        val = Conv(wp, bp, kh, kw, cin, cout, PREC_BF16X3, presplit=True)
+    else:           # the forward kernel on flipped / transposed weights (its input channels = Cout padded to 4 with zero rows)
+        wp, bp = lib.pack_conv_weights(det(w), None, det(w1), None, mode=1, cin_rot=rot)
+        val = Conv(wp, bp, kh, kw, (cout + 3) // 4 * 4, cin, PREC_BF16X3, presplit=True)
     _PACKS[key] = val
     return val
 
@@ -608,16 +612,30 @@ class HipGruBlend(torch.autograd.Function):
 
 
 class HipInstanceNorm(torch.autograd.Function):
-    """nn.InstanceNorm2d without affine / running statistics (core/extractor.py:112-113); backward = pf_norm_bwd."""
+    """nn.InstanceNorm2d without affine / running statistics (core/extractor.py:112-113), optionally with the ReLU that
+    follows it in BasicEncoder / ResidualBlock (core/extractor.py:41-42,144-146) in the same pass: statistics by
+    pf_channel_stats (deterministic two-stage fp64 reduction), y = [relu]((x - mean) * rstd) by pf_norm_act (ReLU form) or one
+    fused multiply-add; backward = pf_norm_bwd (its `relu` flag masks by the sign of the normalised value)."""
 
     @staticmethod
-    def forward(ctx, x):
-        mu = x.mean(dim=(2, 3), keepdim=True)
-        rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3), unbiased=False, keepdim=True) + 1e-5)
-        B, Cc = x.shape[:2]
-        ctx.save_for_backward(_rows(x), rstd.reshape(B, Cc).contiguous(), (-mu * rstd).reshape(B, Cc).contiguous())
-        ctx.shape = x.shape
-        return (x - mu) * rstd
+    def forward(ctx, x, relu=False):
+        lib = _lib.load()
+        B, Cc, H, W = x.shape
+        xr = _rows(x.detach())
+        scale = torch.empty(B, Cc, dtype=torch.float32, device=x.device)        # rstd
+        shift = torch.empty(B, Cc, dtype=torch.float32, device=x.device)        # -mean * rstd
+        nblk = 128
+        part = torch.empty(B * nblk * Cc * 2, dtype=torch.float64, device=x.device)
+        lib.channel_stats(xr, B, H * W, Cc, scale, shift, part, nblk, eps=1e-5)
+        ctx.save_for_backward(xr, scale, shift)
+        ctx.shape, ctx.relu = x.shape, bool(relu)
+        STATS["hip"] += 1
+        if relu:
+            out = torch.empty_like(xr)
+            lib.norm_act(xr, scale, shift, out, B, H * W, Cc)
+            STATS["hip"] += 1
+            return _nchw(out, B, H, W)
+        return torch.addcmul(shift.view(B, Cc, 1, 1), x.detach(), scale.view(B, Cc, 1, 1))
 
     @staticmethod
     def backward(ctx, g):
@@ -625,15 +643,18 @@ class HipInstanceNorm(torch.autograd.Function):
         xr, scale, shift = ctx.saved_tensors
         B, Cc, H, W = ctx.shape
         dx = torch.empty_like(xr)
-        lib.norm_bwd(_rows(g), xr, scale, shift, False, True, dx, B, H * W, Cc)
+        lib.norm_bwd(_rows(g), xr, scale, shift, ctx.relu, True, dx, B, H * W, Cc)
         STATS["hip"] += 1
-        return _nchw(dx, B, H, W)
+        return _nchw(dx, B, H, W), None
 
 
 # ---- module forwards (the parameter containers of modules.py carry no arithmetic of their own) ---------------
-def _norm(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+def _norm(m: nn.Module, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """norm layer `m` on x; relu=True: followed by the ReLU (one pass for InstanceNorm)."""
     if isinstance(m, nn.InstanceNorm2d):
-        return HipInstanceNorm.apply(x)
+        return HipInstanceNorm.apply(x, relu)
+    if relu:
+        return torch.relu(_norm(m, x))
     if isinstance(m, nn.BatchNorm2d):
         if not m.training and m.weight is not None:          # frozen statistics (freeze_bn): the reference's configuration
             return HipFrozenBatchNorm.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps)
@@ -645,11 +666,11 @@ def _norm(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
 
 def encoder_forward(enc, x: torch.Tensor) -> torch.Tensor:
     """BasicEncoder.forward (core/extractor.py:136-158) on one concatenated batch."""
-    x = torch.relu(_norm(enc.norm1, conv2d(x, enc.conv1)))
+    x = _norm(enc.norm1, conv2d(x, enc.conv1), relu=True)
     for layer in (enc.layer1, enc.layer2, enc.layer3):
         for blk in layer:                                     # ResidualBlock.forward (core/extractor.py:39-47)
-            y = torch.relu(_norm(blk.norm1, conv2d(x, blk.conv1)))
-            y = torch.relu(_norm(blk.norm2, conv2d(y, blk.conv2)))
+            y = _norm(blk.norm1, conv2d(x, blk.conv1), relu=True)
+            y = _norm(blk.norm2, conv2d(y, blk.conv2), relu=True)
             if blk.downsample is not None:
                 x = _norm(blk.norm3, conv2d(x, blk.downsample[0]))
             x = torch.relu(x + y)
@@ -659,18 +680,22 @@ def encoder_forward(enc, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def fuse_zr(gru) -> Dict[str, tuple]:
+def fuse_zr(gru, need_cat: bool = True) -> Dict[str, tuple]:
     """convz | convr of a SepConvGRU half share their input (core/update.py:48-49, :55-56): one convolution with
-    the output channels concatenated.  Built once per forward (values only); the gradient comes back through ONE
-    WeightGate over the four parameters, which splits the accumulated packed gradient by output-channel range."""
+    the output channels concatenated.  The gradient comes back through ONE WeightGate over the four parameters, which splits
+    the accumulated packed gradient by output-channel range.  Entry: (w, b, source key, token, WeightGrad, (convz, convr));
+    w / b (the concatenated tensors) only when `need_cat` -- the per-node tape (HipConv) takes them, the loop node packs
+    straight from the two modules."""
     out = {}
     for tag in ("1", "2"):
         cz, cr = getattr(gru, "convz" + tag), getattr(gru, "convr" + tag)
-        with torch.no_grad():
-            w, b = torch.cat([cz.weight, cr.weight], 0), torch.cat([cz.bias, cr.bias], 0)
+        w = b = None
+        if need_cat:
+            with torch.no_grad():
+                w, b = torch.cat([cz.weight, cr.weight], 0), torch.cat([cz.bias, cr.bias], 0)
         acc = WeightGrad()
         tok = WeightGate.apply(acc, cz.weight, cz.bias, cr.weight, cr.bias)
-        out[tag] = (w, b, _src_key(cz.weight, cr.weight, cz.bias, cr.bias), tok if tok.requires_grad else None, acc)
+        out[tag] = (w, b, _src_key(cz.weight, cr.weight, cz.bias, cr.bias), tok if tok.requires_grad else None, acc, (cz, cr))
     return out
 
 
@@ -678,7 +703,7 @@ def sepconv_gru(gru, zr: Dict[str, tuple], h: torch.Tensor, x: torch.Tensor) -> 
     """SepConvGRU.forward (core/update.py:45-60)."""
     for tag in ("1", "2"):
         hx = torch.cat([h, x], 1)
-        z, rh = HipGruGates.apply(HipConv.apply(hx, *zr[tag]), h)
+        z, rh = HipGruGates.apply(HipConv.apply(hx, *zr[tag][:5]), h)
         h = HipGruBlend.apply(z, conv2d(torch.cat([rh, x], 1), getattr(gru, "convq" + tag)), h)
     return h
 
@@ -770,16 +795,17 @@ def _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a
     pyr_a = corr_pyramid(f1a, f2a)                                                              # :151-159
     pyr_b = corr_pyramid(f1b, f2b)
 
-    zr_a, zr_b = fuse_zr(model.ODDC.gru), fuse_zr(model.update_block.gru)
+    import os
+    use_loop = (os.environ.get("PRIORFLOW_TRAIN_LOOP", "1") != "0" and all(p.requires_grad for p in model.ODDC.parameters())
+                and all(p.requires_grad for p in model.update_block.parameters()))
+    zr_a, zr_b = fuse_zr(model.ODDC.gru, not use_loop), fuse_zr(model.update_block.gru, not use_loop)
     c1a, c1b = coords0.clone(), coords0.clone()
     if init_flow is not None:                                                                   # :162-165
         with torch.no_grad():
             fl = init_flow.float().contiguous()
             c1a = c1a + fl
             c1b = c1b + lib.flo_rotate(fl, g_b2a_8, g_a2b_8, torch.empty_like(fl))
-    import os
-    if os.environ.get("PRIORFLOW_TRAIN_LOOP", "1") != "0" and all(p.requires_grad for p in model.ODDC.parameters()) \
-            and all(p.requires_grad for p in model.update_block.parameters()):
+    if use_loop:
         # round 4: the refinement iterations as ONE autograd node with a hand-written backward and deferred weight gradients
         from .train_loop import run_loop
         return run_loop(model, lib, zr_a, zr_b, gate_of, net_a, net_b, inp_a, inp_b, f1a, f2a, pyr_a, pyr_b, coords0,

@@ -835,6 +835,51 @@ PF_HD void pf_split_bf16_elem(long idx, const PfSplitArgs& a) {   // idx over ro
 }
 
 // ----------------------------------------------------------------------------------------------
+// Weight packing on the device (round 4).  nn.Conv2d weights [Cout][Cin][KH][KW] (one tensor, or two concatenated on Cout:
+// the fused z|r convolution of a SepConvGRU half, core/update.py:48-49) -> the PF_PREC_BF16X3 operand of pf_conv2d:
+// [Cout_pad][KH*KW][Cin_pad/32] x {bf16 hi[32], bf16 lo[32]}, zero padded, plus the padded bias vector.
+//   mode 0: the forward convolution.
+//   mode 1: the DATA-GRADIENT convolution dX = conv(dY, W'), W'[c][o][ky][kx] = W[o][(c + cin_rot) % Cin][KH-1-ky][KW-1-kx]:
+//           its output channels are the forward input channels (rotated by cin_rot), its input channels the forward output
+//           channels; no bias.
+// A training step re-packs every convolution of the model after each optimizer step; with torch ops that was ~9 small
+// kernels per pack (two fills, a permute copy, two bf16 casts, a subtract, a cat ...), ~800 launches per step.
+// One element = one (packed output channel, tap, packed input channel).
+// ----------------------------------------------------------------------------------------------
+struct PfPackWArgs {
+    const float* w0; const float* w1; const float* b0; const float* b1;
+    unsigned short* dst_w; float* dst_b;
+    int cout0, cout1, cin, kh, kw, mode, cin_rot, cout_pad, cin_pad;
+};
+PF_HD void pf_pack_conv_weights_elem(long idx, const PfPackWArgs& a) {
+    const int taps = a.kh * a.kw;
+    const int c = (int)(idx % a.cin_pad);
+    const int tap = (int)((idx / a.cin_pad) % taps);
+    const int o = (int)(idx / ((long)a.cin_pad * taps));
+    const int cout = a.cout0 + a.cout1;
+    float v = 0.f;
+    if (a.mode == 0) {
+        if (o < cout && c < a.cin) {
+            const float* w = o < a.cout0 ? a.w0 + (long)o * a.cin * taps : a.w1 + (long)(o - a.cout0) * a.cin * taps;
+            v = w[(long)c * taps + tap];
+        }
+        if (a.dst_b != nullptr && c == 0 && tap == 0)
+            a.dst_b[o] = o < a.cout0 ? (a.b0 ? a.b0[o] : 0.f) : (o < cout ? (a.b1 ? a.b1[o - a.cout0] : 0.f) : 0.f);
+    } else {
+        if (o < a.cin && c < cout) {
+            const int ci = (o + a.cin_rot) % a.cin;
+            const float* w = c < a.cout0 ? a.w0 + (long)c * a.cin * taps : a.w1 + (long)(c - a.cout0) * a.cin * taps;
+            v = w[(long)ci * taps + (taps - 1 - tap)];           // (KH-1-ky) * KW + (KW-1-kx) = taps - 1 - tap
+        }
+        if (a.dst_b != nullptr && c == 0 && tap == 0) a.dst_b[o] = 0.f;
+    }
+    unsigned short* d = a.dst_w + ((long)(o * taps + tap) * (a.cin_pad / 32) + c / 32) * 64 + (c % 32);
+    const unsigned short hi = pf_bf16_rne(v);
+    d[0] = hi;
+    d[32] = pf_bf16_rne(v - pf_bf16_to_f32(hi));
+}
+
+// ----------------------------------------------------------------------------------------------
 // Encoder glue (core/extractor.py:41-47, :144-150): out = relu( res' + relu(y*s + t) ) with
 // res' = res (identity shortcut) | res*rs + rt (normalised 1x1/2 shortcut) | absent.
 // y, res, out: channel-last [B*Np][C]; s,t,rs,rt: [B][C].  One call = 4 consecutive channels.

@@ -125,10 +125,11 @@ def pack_direct(w: torch.Tensor, b: torch.Tensor):
 class Conv:
     """One packed convolution (MFMA implicit-GEMM path)."""
 
-    def __init__(self, w, b, kh, kw, cin, cout, precision=PREC_F32):
+    def __init__(self, w, b, kh, kw, cin, cout, precision=PREC_F32, presplit=False):
+        """presplit: `w` already is the bf16 hi|lo operand (PfLib.pack_conv_weights)."""
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
         self.precision = precision
-        if precision == PREC_BF16X3:
+        if precision == PREC_BF16X3 and not presplit:
             self.w = split_bf16(w)
 
     @staticmethod

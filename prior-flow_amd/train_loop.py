@@ -26,8 +26,8 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import EPI_ADD, EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_MASK, EPI_RELU, PREC_BF16X3
-from .engine import Conv, pack_mfma
+from ._lib import EPI_ADD, EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, EPI_MASK, EPI_RELU
+from .engine import Conv
 
 
 class LoopBuffers:
@@ -98,7 +98,7 @@ class _Packs:
     autograd._pack) plus the (token, WeightGrad) pair of each."""
 
     def __init__(self, model, zr_a, zr_b, gate_of):
-        from .autograd import _pack, _src_key
+        from .autograd import _pack
         self.fwd: Dict[str, Conv] = {}
         self.dg: Dict[str, Conv] = {}
         self.acc: Dict[str, object] = {}
@@ -120,16 +120,13 @@ class _Packs:
         # reordered [x 256 | h 128] (so that d x and d h land next to each other in the half-step's scratch rows)
         for t, zr in (("a", zr_a), ("b", zr_b)):
             for k in "12":
-                w, bias, src, _tok, acc = zr[k]
-                self.fwd[f"{t}.zr{k}"] = _pack(w, bias, "fwd", src)
-                key = ("dgrad_xh",) + tuple(src)
-                wx = torch.cat([w[:, 128:], w[:, :128]], 1)
-                self.dg[f"{t}.zr{k}"] = _pack(wx, None, "dgrad", key)
+                _w, _b, src, _tok, acc, (cz, cr) = zr[k]
+                self.fwd[f"{t}.zr{k}"] = _pack(cz.weight, cz.bias, "fwd", src, w1=cr.weight, b1=cr.bias)
+                self.dg[f"{t}.zr{k}"] = _pack(cz.weight, None, "dgrad", src, w1=cr.weight, rot=128)
                 self.acc[f"{t}.zr{k}"] = acc
         self.stems = {"a.f1a": ea.convf1_A, "a.f1b": ea.convf1_B, "b.f1": eb.convf1}
         self.stem_w = {n: (m.weight.detach().permute(2, 3, 1, 0).reshape(-1, m.weight.shape[0]).contiguous(),
                            m.bias.detach().contiguous()) for n, m in self.stems.items()}
-        del _src_key
 
 
 def _conv(lib, cv: Conv, B, H8, W8, x, off0, c0, out, off_out, epi, **kw):

@@ -691,9 +691,36 @@ def case_norm_backward(lib, dev):
     check(uncl(dx.cpu(), B, H, W), x2.grad, 1e-6, "affine + relu backward")
 
 
+def case_pack_conv_weights(lib, dev):
+    """pf_pack_conv_weights against the torch packing it replaces (engine.pack_mfma + split_bf16, Conv.dgrad_of): forward and
+    data-gradient operands, one tensor and two concatenated on Cout (fused z|r), odd channel counts, a rotated channel order."""
+    from prior_flow_amd.engine import Conv, pack_mfma, split_bf16
+    g = torch.Generator().manual_seed(5)
+    for cout0, cout1, cin, kh, kw in ((124, 0, 272, 3, 3), (128, 128, 384, 1, 5), (2, 0, 256, 3, 3), (576, 0, 256, 1, 1), (32, 0, 8, 3, 3)):
+        w0 = (torch.rand(cout0, cin, kh, kw, generator=g) * 2 - 1).to(dev)
+        b0 = (torch.rand(cout0, generator=g) * 2 - 1).to(dev)
+        w1 = (torch.rand(cout1, cin, kh, kw, generator=g) * 2 - 1).to(dev) if cout1 else None
+        b1 = (torch.rand(cout1, generator=g) * 2 - 1).to(dev) if cout1 else None
+        w = w0 if w1 is None else torch.cat([w0, w1], 0)
+        b = b0 if b1 is None else torch.cat([b0, b1], 0)
+        wp, bp = pack_mfma(w, b)
+        got_w, got_b = lib.pack_conv_weights(w0, b0, w1, b1, mode=0)
+        assert torch.equal(got_w.cpu().view(torch.int16), split_bf16(wp).cpu().view(torch.int16)), ("fwd", cout0, cout1, cin)
+        assert torch.equal(got_b.cpu(), bp.cpu())
+        for rot in (0, 128 if cin > 128 else 0):
+            cp = (cout0 + cout1 + 3) // 4 * 4
+            wpad = torch.zeros(cp, cin, kh, kw, device=dev)
+            wpad[:cout0 + cout1] = torch.cat([w[:, rot:], w[:, :rot]], 1)
+            ref = Conv.dgrad_of(wpad, 1)            # PREC_BF16X3
+            got_w, got_b = lib.pack_conv_weights(w0, None, w1, None, mode=1, cin_rot=rot)
+            assert tuple(got_w.shape) == tuple(ref.w.shape), (got_w.shape, ref.w.shape)
+            assert torch.equal(got_w.cpu().view(torch.int16), ref.w.cpu().view(torch.int16)), ("dgrad", cout0, cout1, cin, rot)
+            assert float(got_b.abs().max()) == 0.0
+
+
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_normalise_images, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_motion_prep, case_conf_stem, case_upsample, case_coords_add, case_layout,
-                     case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16,
+                     case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16, case_pack_conv_weights,
                      case_flow_metrics, case_training_pieces, case_dccl_backward, case_upsample_backward,
                      case_warp_gcorr_backward, case_gru_gate_backward, case_norm_backward,
                      case_bad_args]
