@@ -414,6 +414,13 @@ int pf_gru_zr_bwd(const float* dz, int ld_dz, const float* d_rh, int ld_drh, con
                   const float* r, int ld_r, const float* h, int ld_h, float* dzr_pre, int ld_dzr,
                   float* dh, int ld_dh, long rows, int C, void* stream);
 
+/* Gradient of a SepConvGRU's input x = [inp (C) | out (wout) | flows] once both half-steps' data gradients exist
+ * (f1, f2: rows with leading dimensions, x's channel order): d_inp[., c] += f1 + f2 for c < C (inp = relu(cnet) feeds every
+ * iteration, core/prior_raft.py:196); d_out[., j] = (f1 + f2)[., C + j] where x[., C + j] > 0 else 0 (out = relu(conv),
+ * core/update.py:99,200). */
+int pf_gru_dx_finish(const float* f1, int ld_f1, const float* f2, int ld_f2, const float* x, int ld_x,
+                     float* d_inp, int ld_dinp, float* d_out, int ld_dout, long rows, int C, int wout, void* stream);
+
 /* Backward of build_pyramid (core/corr.py:99-111): level gradients g0..g3 ([B*N][H_i*W_i]) -> the dense volume
  * gradient, written in place into g0 (avg_pool2d backward with floor semantics for odd sizes). */
 int pf_pyramid_bwd(float* g0, const float* g1, const float* g2, const float* g3, int B, int H8, int W8, void* stream);

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "pf_corr_pyramid": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_corr_pyramid_bf16x3": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_split_bf16": [_fp, _fp, C.c_long, _i, _fp],
+    "pf_gru_dx_finish": [_fp, _i, _fp, _i, _fp, _i, _fp, _i, _fp, _i, C.c_long, _i, _i, _fp],
     "pf_pack_conv_weights": [_fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
     "pf_dccl_lookup_il": [_fp] * 13 + [_i, _i, _i, _i, _fp],
@@ -565,6 +566,13 @@ class PfLib:
         for t in (dz, d_rh, z, r, h, dzr_pre, dh):
             args += [_ptr(t), t.stride(0)]
         self._rc(self._dll.pf_gru_zr_bwd(*args, rows, Cc, self._stream(dz)), "pf_gru_zr_bwd")
+
+    def gru_dx_finish(self, f1, f2, x, d_inp, d_out, Cc, wout):
+        """d_inp += (f1 + f2)[:, :C]; d_out[:, :wout] = (f1 + f2)[:, C:C+wout] masked by x[:, C:C+wout] > 0 (row views)."""
+        self._chk_rows(f1, f2, x, d_inp, d_out)
+        self._rc(self._dll.pf_gru_dx_finish(_ptr(f1), f1.stride(0), _ptr(f2), f2.stride(0), _ptr(x), x.stride(0),
+                                            _ptr(d_inp), d_inp.stride(0), _ptr(d_out), d_out.stride(0), f1.shape[0], Cc, wout,
+                                            self._stream(f1)), "pf_gru_dx_finish")
 
     def dccl_combine_bwd(self, d_corr, g_back, d_raw, B, H8, W8):
         self._chk(d_corr, g_back, d_raw)

@@ -109,8 +109,9 @@ class WeightGrad:
 
     def buffers(self, op: int, taps: int, cin_pad: int, device):
         if self.dw is None:
-            self.dw = torch.zeros(op, taps, cin_pad, device=device)
-            self.db = torch.zeros(op, device=device)
+            both = torch.zeros(op * taps * cin_pad + op, device=device)         # one fill for the pair
+            self.dw = both[:op * taps * cin_pad].view(op, taps, cin_pad)
+            self.db = both[op * taps * cin_pad:]
         return self.dw, self.db
 
     def take(self):

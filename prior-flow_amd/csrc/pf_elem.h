@@ -525,6 +525,22 @@ PF_HD void pf_gru_zr_bwd_elem(long idx, const PfGruZrBwdArgs& a) {        // idx
     a.dh[row * a.ld_dh + c] = a.dh[row * a.ld_dh + c] + drh * r;
 }
 // ----------------------------------------------------------------------------------------------
+// Gradient of a SepConvGRU's input x = [inp (C) | out (wout) | flows] (core/update.py:155,133) after both half-steps
+// (training loop node, prior-flow_amd/train_loop.py): dx = f1 + f2 (the two half-steps' data gradients, columns of wider
+// scratch rows); d_inp += dx[:, :C] (inp feeds every iteration); d_out = dx[:, C:C+wout] where out > 0 else 0 (out is the
+// ReLU output of the motion encoder's last convolution, stored in x itself).  One element = one (row, column < C + wout).
+struct PfGruDxArgs {
+    const float* f1; const float* f2; const float* x; float* d_inp; float* d_out;
+    int ld_f1, ld_f2, ld_x, ld_dinp, ld_dout, C, wout;
+};
+PF_HD void pf_gru_dx_finish_elem(long idx, const PfGruDxArgs& a) {
+    const int w = a.C + a.wout;
+    const long row = idx / w; const int c = (int)(idx % w);
+    const float dx = a.f1[row * a.ld_f1 + c] + a.f2[row * a.ld_f2 + c];
+    if (c < a.C) a.d_inp[row * a.ld_dinp + c] = a.d_inp[row * a.ld_dinp + c] + dx;
+    else a.d_out[row * a.ld_dout + (c - a.C)] = a.x[row * a.ld_x + c] > 0.f ? dx : 0.f;
+}
+// ----------------------------------------------------------------------------------------------
 // Backward of  y = act(x * s[b,c] + t[b,c])  over channel-last rows [B*Np][C] (core/extractor.py:112-147):
 // s, t are the scale / shift of pf_channel_stats (InstanceNorm: s = rstd, t = -mean * rstd) or the folded
 // BatchNorm(eval) affine.  With xh = x*s + t and g = dy masked by the ReLU (xh > 0):

@@ -56,8 +56,7 @@ class LoopBuffers:
             s["mh"] = z(it, N, 256)
             s["mask"] = z(it, N, 576)
             s["delta"] = z(it, N, 4)
-            s["c_pre"] = z(it, B, 2, H8, W8)                        # coords1 the iteration starts from
-            s["c_post"] = z(it, B, 2, H8, W8)                       # ... and ends with (the upsampling's flow)
+            s["c"] = z(it + 1, B, 2, H8, W8)                        # coords1 entering iteration i; [i + 1] = leaving it
             # ---- output gradients of the convolutions (operands of the deferred weight gradients)
             s["d_mask"] = z(it, N, 576)
             s["d_mh"] = z(it, N, 256)
@@ -129,10 +128,6 @@ class _Packs:
                            m.bias.detach().contiguous()) for n, m in self.stems.items()}
 
 
-def _conv(lib, cv: Conv, B, H8, W8, x, off0, c0, out, off_out, epi, **kw):
-    lib.conv2d([cv.desc(x, off0, c0, out, off_out, epi, **kw)], B, H8, W8, x)
-
-
 class LoopFn(torch.autograd.Function):
     """(net_A, net_B, inp_A, inp_B, f1_A, f2_A, pyramid tokens, stem parameters, weight tokens) -> 2 * iters flow predictions."""
 
@@ -155,15 +150,19 @@ class LoopFn(torch.autograd.Function):
         Bb["h"][0].copy_(_rows(net_b.detach()))
         A["x"][:, :, :128] = _rows(inp_a.detach())                  # the context features enter every iteration's GRU input
         Bb["x"][:, :, :128] = _rows(inp_b.detach())
-        c1a, c1b = c1a.clone(), c1b.clone()
+        A["c"][0].copy_(c1a)
+        Bb["c"][0].copy_(c1b)
         H, W = 8 * H8, 8 * W8
         preds_a = [torch.empty(B, 2, H, W, device=dev) for _ in range(iters)]
         preds_b = [torch.empty(B, 2, H, W, device=dev) for _ in range(iters)]
-        cv = lambda name, *a, **k: _conv(lib, P.fwd[name], B, H8, W8, *a, **k)      # noqa: E731
+
+        def cv(*items):
+            """One launch: the same-geometry convolutions `items` = (name, x, off0, c0, out, off_out, epilogue, kwargs) as groups."""
+            lib.conv2d([P.fwd[n].desc(x, o0, c0, out, oo, epi, **kw) for n, x, o0, c0, out, oo, epi, kw in items], B, H8, W8, items[0][1])
+
         n_launch = 0
         for i in range(iters):
-            A["c_pre"][i].copy_(c1a)
-            Bb["c_pre"][i].copy_(c1b)
+            c1a, c1b = A["c"][i], Bb["c"][i]
             # flows, flo_rotate(flow_B), both feature warps + groupwise correlations: one launch (prior_raft.py:171-182)
             lib.motion_prep(c1a, c1b, g_a2b_8, g_b2a_8, f1r, f2r, A["flow4"][i], Bb["flow2"][i], A["conf_in"][i],
                             A["x"][i], 252, Bb["x"][i], 254)
@@ -172,40 +171,37 @@ class LoopFn(torch.autograd.Function):
             lib.dccl_combine(A["own"], A["raw"], g_b2a_8, A["corr"][i], B, H8, W8)
             lib.dccl_lookup(c1b, pyr_b[0], pyr_a[0], g_a2b_8, Bb["own"], Bb["raw"])
             lib.dccl_combine(Bb["own"], Bb["raw"], g_a2b_8, Bb["corr"][i], B, H8, W8)
-            # ---- motion encoders (update.py:183-201, :91-99)
-            cv("a.c1", A["corr"][i], 0, 324, A["c1"][i], 0, EPI_RELU)
-            cv("b.c1", Bb["corr"][i], 0, 324, Bb["c1"][i], 0, EPI_RELU)
-            cv("a.c2", A["c1"][i], 0, 256, A["cat"][i], 0, EPI_RELU)
-            cv("b.c2", Bb["c1"][i], 0, 256, Bb["cat"][i], 0, EPI_RELU)
+            # ---- motion encoders (update.py:183-201, :91-99); branch A and branch B of a shape are groups of one launch
+            cv(("a.c1", A["corr"][i], 0, 324, A["c1"][i], 0, EPI_RELU, {}), ("b.c1", Bb["corr"][i], 0, 324, Bb["c1"][i], 0, EPI_RELU, {}))
+            cv(("a.c2", A["c1"][i], 0, 256, A["cat"][i], 0, EPI_RELU, {}), ("b.c2", Bb["c1"][i], 0, 256, Bb["cat"][i], 0, EPI_RELU, {}))
             for name, src, off, dst in (("a.f1a", A["flow4"][i], 0, A["t_a"][i]), ("a.f1b", A["flow4"][i], 2, A["t_ba"][i]),
                                         ("b.f1", Bb["flow2"][i], 0, Bb["t"][i])):
                 w, bias = P.stem_w[name]
                 lib.conv2d_small(src, False, off, 2, w, bias, dst, 0, 128, 7, 7, 1, True, B, H8, W8)
-            cv("a.f2a", A["t_a"][i], 0, 128, A["cat"][i], 128, EPI_RELU)
-            cv("a.f2b", A["t_ba"][i], 0, 128, A["cat"][i], 192, EPI_RELU)
-            cv("b.f2", Bb["t"][i], 0, 128, Bb["cat"][i], 192, EPI_RELU)
-            cv("a.cf1", A["conf_in"][i], 0, 8, A["cf1"][i], 0, EPI_RELU)
-            cv("a.cf2", A["cf1"][i], 0, 32, A["cat"][i], 256, EPI_RELU)
-            cv("a.out", A["cat"][i], 0, 272, A["x"][i], 128, EPI_RELU)
-            cv("b.out", Bb["cat"][i], 0, 256, Bb["x"][i], 128, EPI_RELU)
+            cv(("a.f2a", A["t_a"][i], 0, 128, A["cat"][i], 128, EPI_RELU, {}), ("a.f2b", A["t_ba"][i], 0, 128, A["cat"][i], 192, EPI_RELU, {}),
+               ("b.f2", Bb["t"][i], 0, 128, Bb["cat"][i], 192, EPI_RELU, {}))
+            cv(("a.cf1", A["conf_in"][i], 0, 8, A["cf1"][i], 0, EPI_RELU, {}))
+            cv(("a.cf2", A["cf1"][i], 0, 32, A["cat"][i], 256, EPI_RELU, {}))
+            cv(("a.out", A["cat"][i], 0, 272, A["x"][i], 128, EPI_RELU, {}))
+            cv(("b.out", Bb["cat"][i], 0, 256, Bb["x"][i], 128, EPI_RELU, {}))
             # ---- SepConvGRU (update.py:46-60), heads (update.py:13-14, :124-136)
-            for t, S in (("a", A), ("b", Bb)):
-                h0, h1, h2, x = S["h"][i], S["h1"][i], S["h"][i + 1], S["x"][i]
-                cv(t + ".zr1", h0, 0, 128, S["z1"][i], 0, EPI_GRU_ZR, in1=x, off1=0, c1=256, h=h0, aux=S["rhr1"][i], save_gates=True)
-                cv(t + ".q1", S["rhr1"][i], 0, 128, h1, 0, EPI_GRU_Q, in1=x, off1=0, c1=256, h=h0, z=S["z1"][i], aux=S["q1"][i], save_gates=True)
-                cv(t + ".zr2", h1, 0, 128, S["z2"][i], 0, EPI_GRU_ZR, in1=x, off1=0, c1=256, h=h1, aux=S["rhr2"][i], save_gates=True)
-                cv(t + ".q2", S["rhr2"][i], 0, 128, h2, 0, EPI_GRU_Q, in1=x, off1=0, c1=256, h=h1, z=S["z2"][i], aux=S["q2"][i], save_gates=True)
-                cv(t + ".fh1", h2, 0, 128, S["fh"][i], 0, EPI_RELU)
-                cv(t + ".fh2", S["fh"][i], 0, 256, S["delta"][i], 0, EPI_LINEAR)
-                cv(t + ".m0", h2, 0, 128, S["mh"][i], 0, EPI_RELU)
-                cv(t + ".m2", S["mh"][i], 0, 256, S["mask"][i], 0, EPI_LINEAR, scale=0.25)
-            lib.coords_add(c1a, A["delta"][i])                      # coords1 += delta_flow (prior_raft.py:193,196)
-            lib.coords_add(c1b, Bb["delta"][i])
-            A["c_post"][i].copy_(c1a)
-            Bb["c_post"][i].copy_(c1b)
-            lib.upsample_flow(c1a, A["mask"][i], preds_a[i])        # prior_raft.py:200-208
-            lib.upsample_flow(c1b, Bb["mask"][i], preds_b[i])
-            n_launch += 7 + 14 + 16 + 4
+            SS = (("a", A), ("b", Bb))
+            for k, hin, hout in (("1", "h", "h1"), ("2", "h1", "h")):
+                hi = lambda S: S[hin][i]                                            # noqa: E731
+                ho = lambda S: S[hout][i + 1] if hout == "h" else S[hout][i]        # noqa: E731
+                cv(*[(t + ".zr" + k, hi(S), 0, 128, S["z" + k][i], 0, EPI_GRU_ZR,
+                      dict(in1=S["x"][i], off1=0, c1=256, h=hi(S), aux=S["rhr" + k][i], save_gates=True)) for t, S in SS])
+                cv(*[(t + ".q" + k, S["rhr" + k][i], 0, 128, ho(S), 0, EPI_GRU_Q,
+                      dict(in1=S["x"][i], off1=0, c1=256, h=hi(S), z=S["z" + k][i], aux=S["q" + k][i], save_gates=True)) for t, S in SS])
+            cv(*[(t + ".fh1", S["h"][i + 1], 0, 128, S["fh"][i], 0, EPI_RELU, {}) for t, S in SS])
+            cv(*[(t + ".fh2", S["fh"][i], 0, 256, S["delta"][i], 0, EPI_LINEAR, {}) for t, S in SS])
+            cv(*[(t + ".m0", S["h"][i + 1], 0, 128, S["mh"][i], 0, EPI_RELU, {}) for t, S in SS])
+            cv(*[(t + ".m2", S["mh"][i], 0, 256, S["mask"][i], 0, EPI_LINEAR, dict(scale=0.25)) for t, S in SS])
+            for S, preds in ((A, preds_a), (Bb, preds_b)):
+                S["c"][i + 1].copy_(S["c"][i])
+                lib.coords_add(S["c"][i + 1], S["delta"][i])          # coords1 += delta_flow (prior_raft.py:193,196)
+                lib.upsample_flow(S["c"][i + 1], S["mask"][i], preds[i])    # prior_raft.py:200-208
+            n_launch += 5 + 2 + 3 + 5 + 4 + 4 + 4
         STATS["hip"] += n_launch
         ctx.cfg, ctx.bufs = cfg, bufs
         ctx.save_for_backward(f1r, f2r)
@@ -224,76 +220,79 @@ class LoopFn(torch.autograd.Function):
         dev = coords0.device
         A, Bb = bufs.a, bufs.b
         N = bufs.N
-        dg = lambda name, *a, **k: _conv(lib, P.dg[name], B, H8, W8, *a, **k)       # noqa: E731
+        def dg(*items):
+            """One launch: the same-geometry data-gradient convolutions `items` = (name, dy, off, c, out, off_out, epilogue, kwargs)."""
+            lib.conv2d([P.dg[n].desc(x, o0, c0, out, oo, epi, **kw) for n, x, o0, c0, out, oo, epi, kw in items], B, H8, W8, items[0][1])
+
         d_f1, d_f2 = torch.zeros_like(f1r), torch.zeros_like(f2r)
         d_inp = {"a": torch.zeros(N, 128, device=dev), "b": torch.zeros(N, 128, device=dev)}
         gp = {"a": g_preds[:iters], "b": g_preds[iters:]}
         pg_a, pg_b = pyr_a[2].buffers(pyr_a[0]), pyr_b[2].buffers(pyr_b[0])
-        # gradient of the hidden state an iteration hands on: nothing reads the last one
-        gh: Dict[str, Optional[torch.Tensor]] = {"a": None, "b": None}
+        SS = (("a", A), ("b", Bb))
+        gh: Dict[str, Optional[torch.Tensor]] = {"a": None, "b": None}        # gradient of the hidden state an iteration hands on
         n_launch = 0
         for i in range(iters - 1, -1, -1):
-            for t, S in (("a", A), ("b", Bb)):
-                g = gp[t][i]
-                Fq2, Fq1 = S["F"][2 * (i & 1)], S["F"][2 * (i & 1) + 1]     # ping-pong: gh of iteration i + 1 lives in the other pair
+            Fq2 = {t: S["F"][2 * (i & 1)] for t, S in SS}             # ping-pong: gh of iteration i + 1 lives in the other pair
+            Fq1 = {t: S["F"][2 * (i & 1) + 1] for t, S in SS}
+            ghv = {}
+            for t, S in SS:
                 if gh[t] is None:
-                    Fq1[:, 384:].zero_()                                     # borrowed as the zero gradient of the last state
-                    ghv = Fq1[:, 384:]
+                    Fq1[t][:, 384:].zero_()                           # borrowed as the zero gradient of the last state
+                    ghv[t] = Fq1[t][:, 384:]
                 else:
-                    ghv = gh[t]
-                # ---- heads (the two consumers of h2 add into the gradient the next iteration left for it)
-                if g is not None:
-                    S["d_flow"].zero_()
-                    lib.upsample_flow_bwd(S["c_post"][i], S["mask"][i], g.contiguous(), S["d_mask"][i], S["d_flow"])
-                    S["d_mask"][i].mul_(0.25)                                # mask = 0.25 * conv (update.py:134,157)
-                    lib.to_channel_last(S["d_flow"], 0, 2, S["d_delta"][i], 0)
-                    dg(t + ".m2", S["d_mask"][i], 0, 576, S["d_mh"][i], 0, EPI_MASK, h=S["mh"][i])
-                    dg(t + ".m0", S["d_mh"][i], 0, 256, ghv, 0, EPI_ADD, h=ghv)
-                    dg(t + ".fh2", S["d_delta"][i], 0, 4, S["d_fh"][i], 0, EPI_MASK, h=S["fh"][i])
-                    dg(t + ".fh1", S["d_fh"][i], 0, 256, ghv, 0, EPI_ADD, h=ghv)
-                    n_launch += 8
-                else:
+                    ghv[t] = gh[t]
+            # ---- heads (the two consumers of h2 add into the gradient the next iteration left for it)
+            live = [(t, S) for t, S in SS if gp[t][i] is not None]
+            for t, S in SS:
+                if gp[t][i] is None:
                     S["d_mask"][i].zero_(); S["d_mh"][i].zero_(); S["d_delta"][i].zero_(); S["d_fh"][i].zero_()
-                # ---- GRU, vertical then horizontal half-step (update.py:55-60, :48-53 in reverse)
-                x = S["x"][i]
-                for k, F, h_in, g_in in (("2", Fq2, S["h1"][i], ghv), ("1", Fq1, S["h"][i], None)):
-                    if g_in is None:
-                        g_in = Fq2[:, 384:]                                  # d h1 of the vertical half-step
-                    lib.gru_q_bwd(g_in, S["z" + k][i], S["q" + k][i], h_in, S["d_q" + k][i], S["dz"], F[:, 384:])
-                    dg(f"{t}.q{k}", S["d_q" + k][i], 0, 128, F, 0, EPI_LINEAR)                    # [d(r*h) | d x]
-                    lib.gru_zr_bwd(S["dz"], F[:, :128], S["z" + k][i], S["rhr" + k][i][:, 128:], h_in, S["d_zr" + k][i], F[:, 384:])
-                    dg(f"{t}.zr{k}", S["d_zr" + k][i], 0, 256, F, 128, EPI_ADD, h=F[:, 128:])       # [d x | d h] +=
-                    n_launch += 4
-                gh[t] = Fq1[:, 384:]
+                    continue
+                S["d_flow"].zero_()
+                lib.upsample_flow_bwd(S["c"][i + 1], S["mask"][i], gp[t][i].contiguous(), S["d_mask"][i], S["d_flow"])
+                lib.to_channel_last(S["d_flow"], 0, 2, S["d_delta"][i], 0)
+                n_launch += 3
+            if live:
+                # mask = 0.25 * conv (update.py:134,157): the factor rides in the data gradient's epilogue; the weight
+                # gradient of that conv is scaled once, after the deferred launch
+                dg(*[(t + ".m2", S["d_mask"][i], 0, 576, S["d_mh"][i], 0, EPI_MASK, dict(h=S["mh"][i], scale=0.25)) for t, S in live])
+                dg(*[(t + ".m0", S["d_mh"][i], 0, 256, ghv[t], 0, EPI_ADD, dict(h=ghv[t])) for t, S in live])
+                dg(*[(t + ".fh2", S["d_delta"][i], 0, 4, S["d_fh"][i], 0, EPI_MASK, dict(h=S["fh"][i])) for t, S in live])
+                dg(*[(t + ".fh1", S["d_fh"][i], 0, 256, ghv[t], 0, EPI_ADD, dict(h=ghv[t])) for t, S in live])
+                n_launch += 4
+            # ---- GRU, vertical then horizontal half-step (update.py:55-60, :48-53 in reverse)
+            for k, F, hname in (("2", Fq2, "h1"), ("1", Fq1, "h")):
+                for t, S in SS:
+                    g_in = ghv[t] if k == "2" else Fq2[t][:, 384:]     # d h2 from the heads / d h1 of the vertical half-step
+                    lib.gru_q_bwd(g_in, S["z" + k][i], S["q" + k][i], S[hname][i], S["d_q" + k][i], S["dz"], F[t][:, 384:])
+                dg(*[(f"{t}.q{k}", S["d_q" + k][i], 0, 128, F[t], 0, EPI_LINEAR, {}) for t, S in SS])               # [d(r*h) | d x]
+                for t, S in SS:
+                    lib.gru_zr_bwd(S["dz"], F[t][:, :128], S["z" + k][i], S["rhr" + k][i][:, 128:], S[hname][i], S["d_zr" + k][i], F[t][:, 384:])
+                dg(*[(f"{t}.zr{k}", S["d_zr" + k][i], 0, 256, F[t], 128, EPI_ADD, dict(h=F[t][:, 128:])) for t, S in SS])   # [d x | d h] +=
+                n_launch += 6
+            for t, S in SS:
+                gh[t] = Fq1[t][:, 384:]
                 # d x = [d inp | d out | flows]: inp feeds every iteration, out = relu(conv) -> mask
-                dx = Fq1[:, 128:384] + Fq2[:, 128:384]
-                d_inp[t] += dx[:, :128]
-                wout = 124 if t == "a" else 126
-                S["d_out"][i][:, :wout] = dx[:, 128:128 + wout] * (x[:, 128:128 + wout] > 0)
-                # ---- motion encoder
-                ccat = 272 if t == "a" else 256
-                dg(t + ".out", S["d_out"][i], 0, 128 if t == "b" else 124, S["d_cat"][i], 0, EPI_MASK, h=S["cat"][i])
-                ncor = 128 if t == "a" else 192
-                dg(t + ".c2", S["d_cat"][i], 0, ncor, S["d_c1"][i], 0, EPI_MASK, h=S["c1"][i])
-                dg(t + ".c1", S["d_c1"][i], 0, 256, S["d_corr"], 0, EPI_LINEAR)
+                lib.gru_dx_finish(Fq1[t][:, 128:384], Fq2[t][:, 128:384], S["x"][i], d_inp[t], S["d_out"][i], 128, 124 if t == "a" else 126)
+            # ---- motion encoders
+            dg(("a.out", A["d_out"][i], 0, 124, A["d_cat"][i], 0, EPI_MASK, dict(h=A["cat"][i])))
+            dg(("b.out", Bb["d_out"][i], 0, 128, Bb["d_cat"][i], 0, EPI_MASK, dict(h=Bb["cat"][i])))
+            dg(("a.c2", A["d_cat"][i], 0, 128, A["d_c1"][i], 0, EPI_MASK, dict(h=A["c1"][i])))
+            dg(("b.c2", Bb["d_cat"][i], 0, 192, Bb["d_c1"][i], 0, EPI_MASK, dict(h=Bb["c1"][i])))
+            dg(*[(t + ".c1", S["d_c1"][i], 0, 256, S["d_corr"], 0, EPI_LINEAR, {}) for t, S in SS])
+            dg(("a.f2a", A["d_cat"][i], 128, 64, A["d_t_a"][i], 0, EPI_MASK, dict(h=A["t_a"][i])),
+               ("a.f2b", A["d_cat"][i], 192, 64, A["d_t_ba"][i], 0, EPI_MASK, dict(h=A["t_ba"][i])),
+               ("b.f2", Bb["d_cat"][i], 192, 64, Bb["d_t"][i], 0, EPI_MASK, dict(h=Bb["t"][i])))
+            dg(("a.cf2", A["d_cat"][i], 256, 16, A["d_cf1"][i], 0, EPI_MASK, dict(h=A["cf1"][i])))
+            dg(("a.cf1", A["d_cf1"][i], 0, 32, A["d_conf"], 0, EPI_LINEAR, {}))
+            for t, S in SS:
                 S["d_raw"].zero_()
                 g_back = g_b2a_8 if t == "a" else g_a2b_8
                 lib.dccl_combine_bwd(S["d_corr"], g_back, S["d_raw"], B, H8, W8)
-                lib.dccl_lookup_bwd(S["c_pre"][i], g_back, S["d_corr"], S["d_raw"], pg_a if t == "a" else pg_b, pg_b if t == "a" else pg_a)
-                n_launch += 5
-                if t == "a":
-                    dg("a.f2a", S["d_cat"][i], 128, 64, S["d_t_a"][i], 0, EPI_MASK, h=S["t_a"][i])
-                    dg("a.f2b", S["d_cat"][i], 192, 64, S["d_t_ba"][i], 0, EPI_MASK, h=S["t_ba"][i])
-                    dg("a.cf2", S["d_cat"][i], 256, 16, S["d_cf1"][i], 0, EPI_MASK, h=S["cf1"][i])
-                    dg("a.cf1", S["d_cf1"][i], 0, 32, S["d_conf"], 0, EPI_LINEAR)
-                    lib.warp_gcorr_bwd(f1r, f2r, S["c_pre"][i], False, S["d_conf"], 0, d_f1, d_f2)
-                    lib.to_nchw(S["flow4"][i], 2, 2, S["flow_ba"])
-                    lib.warp_gcorr_bwd(f1r, f2r, S["flow_ba"], True, S["d_conf"], 4, d_f1, d_f2)
-                    n_launch += 7
-                else:
-                    dg("b.f2", S["d_cat"][i], 192, 64, S["d_t"][i], 0, EPI_MASK, h=S["t"][i])
-                    n_launch += 1
-                del ccat
+                lib.dccl_lookup_bwd(S["c"][i], g_back, S["d_corr"], S["d_raw"], pg_a if t == "a" else pg_b, pg_b if t == "a" else pg_a)
+            lib.warp_gcorr_bwd(f1r, f2r, A["c"][i], False, A["d_conf"], 0, d_f1, d_f2)
+            lib.to_nchw(A["flow4"][i], 2, 2, A["flow_ba"])
+            lib.warp_gcorr_bwd(f1r, f2r, A["flow_ba"], True, A["d_conf"], 4, d_f1, d_f2)
+            n_launch += 2 + 8 + 4 + 3
         # ---- deferred weight gradients: one launch per convolution over the iters * B stored images
         Bi = iters * B
 
@@ -323,6 +322,9 @@ class LoopFn(torch.autograd.Function):
         wg("b.f2", Bb["t"], 0, 128, Bb["d_cat"], 192, 64)
         wg("a.cf2", A["cf1"], 0, 32, A["d_cat"], 256, 16)
         wg("a.cf1", A["conf_in"], 0, 8, A["d_cf1"], 0, 32)
+        for t in "ab":          # mask = 0.25 * conv: the output gradient stored for m2 is the un-scaled one
+            dw, db = P.acc[t + ".m2"].dw, P.acc[t + ".m2"].db
+            torch._foreach_mul_([dw, db], 0.25)
         stem_grads = []
         for name, x, off, dy in (("a.f1a", A["flow4"], 0, A["d_t_a"]), ("a.f1b", A["flow4"], 2, A["d_t_ba"]), ("b.f1", Bb["flow2"], 0, Bb["d_t"])):
             m = P.stems[name]
