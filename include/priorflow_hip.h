@@ -212,7 +212,9 @@ typedef struct pf_conv_desc {
      * 32-channel chunk, the 128 bytes {bf16 hi[32], bf16 lo[32]} with hi = bf16(x) (round to nearest even) and
      * lo = bf16(x - hi): [rows][lds chunks][128 B] -- exactly what the kernels otherwise compute from fp32 while staging,
      * so results are bit-identical.  Channels past the logical width of a row are zero.
-     *   in0_split / in1_split (with lds0 / lds1 chunks per row; off0 / off1 / c0 must be multiples of 32): when EVERY group of
+     *   in0_split / in1_split (with lds0 / lds1 chunks per row; off0 / off1 / c0 must be multiples of 32; a last segment whose
+     *     width is not a multiple of 32 must end at the end of its twin's row -- the kernel copies whole chunks and relies on
+     *     the zero columns past the logical width, PF_ERR_BAD_SHAPE otherwise): when EVERY group of
      *     a stride-1 3x3 / 1x5 / 5x1 launch without in_scale / stats_out provides them, the operands go global -> LDS by DMA
      *     (pf_conv_dma_kernel: no VALU split, no ds_write) and in0 / in1 may be NULL; other launches ignore them and need in0.
      *   out_split (lds_out chunks per row; off_out % 32 == 0): the epilogue also writes the split twin of `out` at the same

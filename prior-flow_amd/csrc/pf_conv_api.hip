@@ -26,6 +26,11 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
         if ((d.in0_split || d.in1_split || d.out_split || d.aux_split) && d.precision != PF_PREC_BF16X3) return PF_ERR_BAD_ARG;
         if (d.in0_split && ((d.off0 & 31) || d.lds0 * 32 < d.off0 + d.c0)) return PF_ERR_BAD_SHAPE;
         if (d.in1_split && d.c1 > 0 && ((d.off1 & 31) || (d.c0 & 31) || d.lds1 * 32 < d.off1 + d.c1)) return PF_ERR_BAD_SHAPE;
+        // The all-DMA kernel copies whole 32-channel chunks: a slice that ends inside a chunk must end at the END OF THE ROW, where
+        // the twin's columns past the logical width are zero by contract (anywhere else it would multiply a neighbour's live
+        // columns -- possibly Inf / NaN -- by the zero-padded weights)
+        if (d.in0_split && d.c1 == 0 && (d.c0 & 31) && d.off0 + ((d.c0 + 31) & ~31) != d.lds0 * 32) return PF_ERR_BAD_SHAPE;
+        if (d.in1_split && d.c1 > 0 && (d.c1 & 31) && d.off1 + ((d.c1 + 31) & ~31) != d.lds1 * 32) return PF_ERR_BAD_SHAPE;
         if (d.out_split && ((d.off_out & 31) || d.lds_out <= 0)) return PF_ERR_BAD_SHAPE;
         if (d.aux_split && d.lds_aux * 32 < 128) return PF_ERR_BAD_SHAPE;
         if (d.pre && (d.off_pre < 0 || d.off_pre + d.cout > d.ld_pre)) return PF_ERR_BAD_SHAPE;

@@ -887,8 +887,9 @@ int launch_upsample_bwd(const PfUpsampleBwdArgs& a, long total, void* stream) {
 #ifdef PF_LOOKUP_WAVES
 #define PF_LOOKUP_LAUNCH(a, total, stream) launch_lookup(a, total, stream)
 #else
-// the wave-cooperative window kernel (pf_lookup.hip) takes the launch unless PRIORFLOW_LOOKUP_WIN=0; pf_lookup_elem is the
-// scalar statement it is bit-identical to (and what the host emulation runs)
+// the wave-cooperative window kernel (pf_lookup.hip) is OPT-IN (PRIORFLOW_LOOKUP_WIN=1; pf_lookup_win_launch answers -100
+// otherwise: it measured 45 us against 28 us per launch, profiles/r3_final_ab_lookup_win.txt); pf_lookup_elem, the per-thread
+// kernel, is the default, the scalar statement the window kernel is bit-identical to, and what the host emulation runs
 int pf_lookup_win_launch(const PfLookupArgs& a, void* stream);
 static int pf_lookup_dispatch(const PfLookupArgs& a, long total, void* stream) {
     const int rc = pf_lookup_win_launch(a, stream);

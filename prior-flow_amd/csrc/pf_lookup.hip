@@ -101,8 +101,20 @@ __global__ void __launch_bounds__(64 * LW_WAVES) pf_lookup_win_kernel(const PfLo
         }
     }
     const GeoY* const geoy = reinterpret_cast<const GeoY*>(geo);
+    // The phases hand data from lane to lane through wave-private LDS.  A wave's LDS operations are processed in issue order, but
+    // the compiler must not move a phase's reads above the previous phase's writes of OTHER lanes: a wave-level fence + barrier at
+    // every hand-over states the dependency instead of relying on the emitted order.
+    auto wave_sync = []() __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+    };
+    wave_sync();                                                          // P0 -> P1
 
     for (int pass = 0; pass < 2; ++pass) {
+        if (pass) wave_sync();                                            // P2 of the previous pass has read the windows: P1 may rewrite them
         // ---- P1: windows of levels 2*pass, 2*pass + 1 (180 own pairs + 180 grid quads) ----------------------------------
         for (int id = lane; id < LW_OWN; id += 64) {
             const int ll = id / 90, slot = (id % 90) / 9, i = id % 9;
@@ -123,6 +135,7 @@ __global__ void __launch_bounds__(64 * LW_WAVES) pf_lookup_win_kernel(const PfLo
             }
             grdw[id] = q;
         }
+        wave_sync();                                                      // P1 -> P2
         // ---- P2: one lane per tap (162 taps) ----------------------------------------------------------------------------
         for (int id = lane; id < 2 * PF_TAPS; id += 64) {
             const int ll = id / PF_TAPS, k = id % PF_TAPS, ta = k / 9, tb = k % 9;

@@ -303,11 +303,10 @@ class Workspace:
         lib.sample_grid(self.g_a2b, r_a2b)
         lib.sample_grid(self.g_a2b_8, r_a2b)
         lib.sample_grid(self.g_b2a_8, r_b2a)
-        # the lookups' cross-view grid also interleaved per pixel [N][2]: one 16-byte load per bilinear row pair
-        # (PRIORFLOW_GRID_IL=0 keeps the planar loads: A/B knob, results are bit-identical)
-        il = os.environ.get("PRIORFLOW_GRID_IL", "1") != "0"
-        self.g_a2b_8_il = self.g_a2b_8.reshape(2, -1).t().contiguous() if il else None
-        self.g_b2a_8_il = self.g_b2a_8.reshape(2, -1).t().contiguous() if il else None
+        # the lookups' cross-view grid also interleaved per pixel [N][2]: one 16-byte load per bilinear row pair (the planar
+        # form stays in the C-ABI: g_w2c_il = NULL; results are bit-identical)
+        self.g_a2b_8_il = self.g_a2b_8.reshape(2, -1).t().contiguous()
+        self.g_b2a_8_il = self.g_b2a_8.reshape(2, -1).t().contiguous()
         # ---- encoders' side
         # fnet output of the 4 images (f1A, f2A, f1B, f2B), one row block each
         self.f_all = z(4 * rows, 256)
@@ -444,17 +443,8 @@ class Engine:
             self.lib.split_bf16(ws.f_all, ws.f_split)          # all four feature maps at once
             rows = ws.B * ws.N
             fs = [ws.f_split[i * rows:(i + 1) * rows] for i in range(4)]
-            if self.side is not None and os.environ.get("PRIORFLOW_CORR_PAR", "0") == "1":
-                # A/B knob: the two volumes on two queues (one launch's store phase under the other's GEMM phase)
-                main, sb = torch.cuda.current_stream(), self.side[1]
-                ev = torch.cuda.Event()
-                ev.record(main)
-                self.lib.corr_pyramid_bf16x3(fs[0], fs[1], ws.pyr_a, ws.B, ws.H8, ws.W8, 256)
-                sb.wait_event(ev)
-                with torch.cuda.stream(sb):
-                    self.lib.corr_pyramid_bf16x3(fs[2], fs[3], ws.pyr_b, ws.B, ws.H8, ws.W8, 256)
-                main.wait_stream(sb)
-                return
+            # (the two volumes on two queues -- one launch's store phase under the other's GEMM phase -- measured 138.9 against
+            # 139.1 pairs/s in round 3 and was removed)
             self.lib.corr_pyramid_bf16x3(fs[0], fs[1], ws.pyr_a, ws.B, ws.H8, ws.W8, 256)
             self.lib.corr_pyramid_bf16x3(fs[2], fs[3], ws.pyr_b, ws.B, ws.H8, ws.W8, 256)
             return
@@ -569,17 +559,10 @@ class Engine:
             if not fused:
                 lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
 
-        if need_b and os.environ.get("PRIORFLOW_LOOKUP_PAIR", "0") == "1":
-            # A/B knob, off by default: both branches' lookups as ONE grid (pf_dccl_lookup_pair) instead of two launches on
-            # two queues.  Bit-identical; measured 132.0 / 131.9 against 133.3 / 132.3 pairs/s (same box): the cross-queue
-            # join it removes is paid for by B's lookup no longer starting before A's chain needs the chip.
-            self._await_b(torch.cuda.current_stream(), keep=True)
-            lib.dccl_lookup_pair([(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il),
-                                  (ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b, ws.g_a2b_8_il)])
-            if not fused:
-                lib.dccl_combine(ws.own, ws.raw, ws.g_b2a_8, ws.corr_a, B, H8, W8)
-                lib.dccl_combine(ws.own_b, ws.raw_b, ws.g_a2b_8, ws.corr_b, B, H8, W8)
-        elif need_b and self.forks & 4:
+        # (both branches' lookups as ONE grid, pf_dccl_lookup_pair, measured 132.0 / 131.9 against 133.3 / 132.3 pairs/s in round 3:
+        # the cross-queue join it removes is paid for by B's lookup no longer starting before A's chain needs the chip.  The
+        # entry point stays in the library -- bit-identical, tested -- but the engine no longer carries the switch.)
+        if need_b and self.forks & 4:
             # the two branches' lookups are independent gather chains: B's runs beside A's
             main, sb = torch.cuda.current_stream(), self.side[2]
             a_first = bool(self.order & 4)
@@ -755,13 +738,8 @@ class Engine:
             d.append(P["a.m2"].desc(ws.mh_a, 0, 256, ws.mask_a, 0, EPI_LINEAR, scale=0.25))
         if mask_b and need_b:
             d.append(P["b.m2"].desc(ws.mh_b, 0, 256, ws.mask_b, 0, EPI_LINEAR, scale=0.25))
-        if need_b and not d and os.environ.get("PRIORFLOW_STRIP_PAIR", "0") == "1":
-            # A/B knob, off: both branches' FlowHead tails as ONE launch on the calling stream (pf_flow_head_out_pair), so that
-            # branch B's coords need no cross-queue hop of their own.  Bit-identical; measured 128.8 / 129.4 against 130.8 / 130.8
-            # pairs/s (same box): the hop it removes costs less than running the two tails back to back.
-            lib.flow_head_out_pair(ws.fh_a, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a,
-                                   ws.fh_b, P["b.fh2w"], P["b.fh2b"], ws.c1b, ws.delta_b, 256)
-            return c
+        # (both FlowHead tails as one launch on the calling stream, pf_flow_head_out_pair, measured 128.8 / 129.4 against 130.8 /
+        # 130.8 pairs/s in round 3; the entry point stays in the library, the engine switch is gone)
         if self.forks & 8 and (need_b or d):
             # three independent tails of the heads: flow_out A | flow_out B | mask convs
             main = torch.cuda.current_stream()

@@ -110,7 +110,7 @@ class PriOr_RAFT(nn.Module):
             self._graphs.clear()
         return self._enc_plans
 
-    def _encode(self, image1, image2, ws: Workspace, eng: Engine, defer_cnet_join: bool = False):
+    def _encode(self, image1, image2, ws: Workspace, eng: Engine):
         """Normalise, rotate to view B, run cnet / fnet (core/prior_raft.py:109-149) and leave the
         features in the workspace (channel-last): f1A,f2A,f1B,f2B; net = tanh(cnet[:128]),
         inp = relu(cnet[128:]) for both views."""
@@ -136,7 +136,7 @@ class PriOr_RAFT(nn.Module):
             # Under the tracer the phase then ends 50-75 us earlier (2.44 / 2.47 against 2.51 ms); untraced, interleaved on one
             # box, the forward is no faster (129.2 / 129.2 against 129.8 / 129.9 pairs/s): the default stays.
             order = os.environ.get("PRIORFLOW_ENC_ORDER", "fnet_main")
-            if order == "fnet_main" or defer_cnet_join:
+            if order == "fnet_main":
                 # fnet (the longer chain) stays on the calling stream and is enqueued first; cnet forks from an event
                 ev = torch.cuda.Event()
                 ev.record(cur)
@@ -144,8 +144,6 @@ class PriOr_RAFT(nn.Module):
                 s1.wait_event(ev)
                 with torch.cuda.stream(s1):
                     cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
-                if defer_cnet_join:
-                    return s1           # the caller keeps working on fnet's results and joins cnet's stream later
                 cur.wait_stream(s1)
             elif order == "cnet_main":
                 ev = torch.cuda.Event()
@@ -176,18 +174,10 @@ class PriOr_RAFT(nn.Module):
     def _run(self, ws: Workspace, image1, image2, iters, init_flow, test_mode, out_a, out_b):
         eng = Engine(self._lib(), self._streams() if self.use_streams else None)
         P = self._weights()
-        # PRIORFLOW_CNET_TAIL=1 (A/B knob, off): cnet is not joined at the end of the encoder stage but in front of the iterations.
-        # Measured 133.1 / 133.3 against 133.7 / 133.3 pairs/s at B=1 and 172.3 / 173.4 against 173.8 / 172.5 at batch 32: the
-        # chip is full either way.
-        cnet_stream = self._encode(image1, image2, ws, eng, defer_cnet_join=os.environ.get("PRIORFLOW_CNET_TAIL", "0") == "1")
-        if cnet_stream is not None:
-            # cnet (and the hoisted context convs that follow it, MFMA-bound) keep running on their stream while the calling
-            # stream builds the two corr volumes from fnet's features (store-bound); joined in front of the iterations
-            eng.build_pyramids(ws, P["precision"])
-            with torch.cuda.stream(cnet_stream):
-                eng.hoist_context(ws, P)
-            torch.cuda.current_stream().wait_stream(cnet_stream)
-        elif self.use_streams and eng.hoist(P) and os.environ.get("PRIORFLOW_HOIST_SIDE", "1") != "0":
+        # (joining cnet in front of the iterations instead of after the encoders -- its tail beside the corr build -- measured
+        # 133.1 / 133.3 against 133.7 / 133.3 pairs/s in round 3 and was removed)
+        self._encode(image1, image2, ws, eng)
+        if self.use_streams and eng.hoist(P):
             # the hoisted context convs (MFMA-bound) run beside the corr build (store-bound); the corr build stays on the calling
             # stream and is enqueued first
             cur, side = torch.cuda.current_stream(), self._streams()[0]

@@ -675,3 +675,29 @@ def _lookup_window_case(lib, dev, shape):
         for k in range(4):
             assert torch.isfinite(out[k]).all()
             assert torch.equal(out[k], out[4 + k]), (k, il is not None, float((out[k] - out[4 + k]).abs().max()))
+
+
+@pytest.mark.gpu
+def test_conv_twin_slice_must_end_at_the_row_end_or_on_a_chunk(lib, dev):
+    """the all-DMA kernel copies whole 32-channel chunks of a split twin, so an operand slice whose width is not a
+    multiple of 32 is only legal when it ends at the end of the twin's row (where the columns past the logical width are zero by
+    contract).  A 16-channel slice in the middle of a wider row would multiply its neighbour's live columns by zero weights --
+    wrong the moment they hold Inf / NaN -- and is rejected; the same slice at the row end runs and ignores poisoned fp32 data
+    outside the twin."""
+    from prior_flow_amd._lib import EPI_LINEAR, PREC_BF16X3, PfError
+    from prior_flow_amd.engine import Conv, pack_mfma, split_twin
+    B, H8, W8 = 1, 16, 32
+    N = B * H8 * W8
+    torch.manual_seed(3)
+    x = torch.rand(N, 80, device=dev) * 2 - 1                    # 2.5 chunks: [64 live | 16 live | 16 zero padding]
+    xs = lib.split_bf16(torch.cat([x, torch.zeros(N, 16, device=dev)], 1), split_twin(N, 96, dev))
+    w = (torch.rand(64, 16, 3, 3, device=dev) * 2 - 1) * 0.1
+    cv = Conv(*pack_mfma(w, torch.zeros(64, device=dev)), 3, 3, 16, 64, PREC_BF16X3)
+    out = torch.zeros(N, 64, device=dev)
+    # 16 channels at offset 64 of a 96-column twin: ends at the row end (64 + 32 == 96) -> legal
+    lib.conv2d([cv.desc(None, 64, 16, out, 0, EPI_LINEAR, in0s=xs)], B, H8, W8, out)
+    ref = torch.nn.functional.conv2d(x[:, 64:80].reshape(B, H8, W8, 16).permute(0, 3, 1, 2), w, padding=1)
+    assert float((out.reshape(B, H8, W8, 64).permute(0, 3, 1, 2) - ref).abs().max()) < 1e-3
+    # the same 16 channels at offset 32 (columns 32..47 of the row, live columns 48..63 behind them) -> rejected
+    with pytest.raises(PfError):
+        lib.conv2d([cv.desc(None, 32, 16, out, 0, EPI_LINEAR, in0s=xs)], B, H8, W8, out)
