@@ -271,6 +271,16 @@ int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8
  * 16 + 1 | 16 + 2: the launch has pre-split operands and takes the all-DMA kernel (pf_conv_dma_kernel) with that tile. */
 int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8);
 
+/* The encoders' first convolution (core/extractor.py:122, :144: conv1 7x7 stride 2 pad 3, 3 -> 64) straight from the NCHW
+ * image, PF_PREC_BF16X3 arithmetic on the matrix cores with K = the 7x7x3 patch (176 padded) instead of the 512 of the
+ * space-to-depth form: img [Bn][3][H][W] (H, W even) -> out rows [Bn * H/2 * W/2][64] fp32 (may be NULL with out_split) and / or
+ * the split twin out_split [rows][2 chunks][128 B] (see pf_conv_desc); relu != 0: ReLU epilogue (the BatchNorm-folded cnet
+ * stem).  weight: 64 rows of 704 bytes -- per 8-k piece {bf16 hi[8], bf16 lo[8]}, k = ky * 24 + kx * 3 + c, zero padded
+ * (engine.pack_stem7x7 builds it); bias [64].  stats_out (optional): fp64 per-tile sum / sum of squares of the stored values,
+ * [Bn][ceil(H/16) * ceil(W/64)][64][2] -- the partials pf_channel_stats_final reduces (8-row x 32-column output tiles). */
+int pf_enc_stem(const float* img, const void* weight, const float* bias, float* out, void* out_split, int relu,
+                double* stats_out, int Bn, int H, int W, void* stream);
+
 /* Tiny-Cin direct convolution (7x7 2->128, 3x3 8->32, 3x3 32->16; core/update.py:171-178,87).
  * Weights packed [KH*KW][Cin][Cout]. */
 int pf_conv2d_direct(const float* in, int ld_in, int off_in, int cin,

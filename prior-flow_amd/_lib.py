@@ -82,6 +82,7 @@ _SIGNATURES = {
     "pf_corr_pyramid": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_corr_pyramid_bf16x3": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_split_bf16": [_fp, _fp, C.c_long, _i, _fp],
+    "pf_enc_stem": [_fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_gru_dx_finish": [_fp, _i, _fp, _i, _fp, _i, _fp, _i, _fp, _i, C.c_long, _i, _i, _fp],
     "pf_pack_conv_weights": [_fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
@@ -422,6 +423,17 @@ class PfLib:
                                            _ptr(weight), _ptr(bias), _ptr(out), out.shape[-1], off_out, cout,
                                            kh, kw, stride, int(relu), B, Hout, Wout, self._stream(x)),
                  "pf_conv2d_small")
+
+    def enc_stem(self, images, weight, bias, out=None, out_split=None, relu=False, stats=None):
+        """The encoders' 7x7 / 2 stem from NCHW images [Bn,3,H,W] (pf_enc_stem); weight from engine.pack_stem7x7."""
+        self._chk(images, bias, out)
+        Bn, Cc, H, W = images.shape
+        if Cc != 3 or weight.dtype != torch.bfloat16 or weight.numel() != 64 * 352 or not weight.is_contiguous():
+            raise PfError("enc_stem: images must be [Bn,3,H,W] and weight the 64 x 704-byte pack of engine.pack_stem7x7")
+        sp, _ = _twin(out_split)
+        self._rc(self._dll.pf_enc_stem(_ptr(images), C.c_void_p(weight.data_ptr()), _ptr(bias), _ptr(out), sp, int(relu),
+                                       None if stats is None else C.c_void_p(stats.data_ptr()), Bn, H, W, self._stream(images)),
+                 "pf_enc_stem")
 
     def conv2d_wgrad_small(self, x, nchw, off_in, cin, dy, off_dy, cout, dw, db, kh, kw, stride, B, Hout, Wout):
         """dw [Cout,Cin,KH,KW] (+= ), db [Cout] (+= or None) of a small-Cin convolution; x NCHW planes or channel-last."""

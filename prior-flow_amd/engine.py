@@ -109,6 +109,18 @@ def stem_s2d_weight(w: torch.Tensor) -> torch.Tensor:
     return w2
 
 
+def pack_stem7x7(w: torch.Tensor) -> torch.Tensor:
+    """7x7 3 -> 64 stem weights [64,3,7,7] -> the operand of pf_enc_stem: K axis k = ky * 24 + kx * 3 + c (a patch row's 21
+    interleaved floats padded to 24), 176 padded, per 8-k piece {bf16 hi[8], bf16 lo[8]}: bf16 [64][22][2][8]."""
+    assert tuple(w.shape) == (64, 3, 7, 7)
+    wk = torch.zeros(64, 7, 24, dtype=torch.float32, device=w.device)
+    wk[:, :, :21] = w.detach().float().permute(0, 2, 3, 1).reshape(64, 7, 21)
+    wk = torch.cat([wk.reshape(64, 168), torch.zeros(64, 8, device=w.device)], 1)
+    hi = wk.to(torch.bfloat16)
+    lo = (wk - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi.view(64, 22, 1, 8), lo.view(64, 22, 1, 8)], 2).contiguous()
+
+
 def default_precision() -> int:
     """PRIORFLOW_PRECISION=fp32 selects the exact-fp32 MFMA path; default is the 3-pass bf16
     split (same parity class: SURVEY.md §7 measured 2e-5 EPE for split-x3 update blocks)."""
@@ -816,9 +828,14 @@ class EncoderPlan:
         self.stem = DirectConv(enc.conv1)                      # [49][3][64]  (exact-fp32 mode)
         # bf16x3 mode: the stem as a 4x4 stride-1 conv over the space-to-depth image (halo kernel)
         self.stem_s2d = None
+        # round 4: the stem straight from the NCHW image (pf_enc_stem, K = 176 instead of 512 and no space-to-depth pass);
+        # PRIORFLOW_STEM_DIRECT=0 keeps the space-to-depth form (A/B knob; same products, another summation order)
+        self.stem_direct = precision == PREC_BF16X3 and os.environ.get("PRIORFLOW_STEM_DIRECT", "1") != "0"
         if precision == PREC_BF16X3:
             wp, bp = pack_mfma(stem_s2d_weight(enc.conv1.weight), enc.conv1.bias)
             self.stem_s2d = Conv(wp, bp, 4, 4, 12, 64, precision)
+            self.stem_w7 = pack_stem7x7(enc.conv1.weight)
+            self.stem_b7 = enc.conv1.bias.detach().float().contiguous()
         self.blocks = []
         for layer, stride in ((enc.layer1, 1), (enc.layer2, 2), (enc.layer3, 2)):
             for i, blk in enumerate(layer):
@@ -841,6 +858,9 @@ class EncoderPlan:
                      and os.environ.get("PRIORFLOW_PRESPLIT", "1") != "0")
         if self.fold:
             self.f_stem = Conv.folded(enc.conv1, enc.norm1, precision, weight=stem_s2d_weight(enc.conv1.weight))
+            sc = (enc.norm1.weight / torch.sqrt(enc.norm1.running_var + enc.norm1.eps)).detach().float()
+            self.f_stem_w7 = pack_stem7x7(enc.conv1.weight.detach().float() * sc.view(-1, 1, 1, 1))      # Conv.folded's arithmetic
+            self.f_stem_b7 = self.f_stem.b[:64].contiguous()
             self.f_blocks = []
             for blk_mod, item in zip([b for layer in (enc.layer1, enc.layer2, enc.layer3) for b in layer], self.blocks):
                 f = {"stride": item["stride"], "cin": item["cin"], "cout": item["cout"],
@@ -922,7 +942,15 @@ class EncoderPlan:
         # applies it to the skip input (one 2 x 134 MB pass less per 4 images); the stem's statistics live in slot 2 until then
         stem_folded = self.precision == PREC_BF16X3 and self.kind != "batch" and os.environ.get("PRIORFLOW_FOLD_STEM", "1") != "0"
         slot0 = 2 if stem_folded else 0
-        if self.stem_s2d is not None:
+        if self.stem_direct and self.kind != "batch" and Bn * ((h + 7) // 8) * ((w + 31) // 32) * 64 * 2 <= bufs["part"].numel():
+            nblk = ((h + 7) // 8) * ((w + 31) // 32)
+            lib.enc_stem(images, self.stem_w7, self.stem_b7, out=a0[0], stats=bufs["part"])
+            sc, sh = bufs["sc"][slot0][: Bn * 64].view(Bn, 64), bufs["sh"][slot0][: Bn * 64].view(Bn, 64)
+            lib.channel_stats_final(bufs["part"], Bn, h * w, 64, nblk, sc, sh)
+        elif self.stem_direct:
+            lib.enc_stem(images, self.stem_w7, self.stem_b7, out=a0[0])
+            sc, sh = self._affine(self.norm1, a0[0], Bn, h * w, 64, slot0)
+        elif self.stem_s2d is not None:
             lib.space_to_depth2(images, bufs["s2d"])
             sc, sh = self._conv_norm(self.stem_s2d, self.norm1, bufs["s2d"], 12, a0[0], Bn, h, w, 64, slot0)
         else:
@@ -993,9 +1021,12 @@ class EncoderPlan:
         self._alloc_folded(Bn, H, W)
         bufs = self._bufs
         h, w = H // 2, W // 2
-        lib.space_to_depth2(images, bufs["s2d"])
         x, xs = bufs["x0"][0], bufs["xs0"][0]
-        lib.conv2d([self.f_stem.desc(bufs["s2d"], 0, 12, x, 0, EPI_RELU, outs=xs)], Bn, h, w, x)
+        if self.stem_direct:
+            lib.enc_stem(images, self.f_stem_w7, self.f_stem_b7, out=x, out_split=xs, relu=True)
+        else:
+            lib.space_to_depth2(images, bufs["s2d"])
+            lib.conv2d([self.f_stem.desc(bufs["s2d"], 0, 12, x, 0, EPI_RELU, outs=xs)], Bn, h, w, x)
         lvl, cur = 0, 0
         for f in self.f_blocks:
             cin, cout, st = f["cin"], f["cout"], f["stride"]

@@ -701,3 +701,44 @@ def test_conv_twin_slice_must_end_at_the_row_end_or_on_a_chunk(lib, dev):
     # the same 16 channels at offset 32 (columns 32..47 of the row, live columns 48..63 behind them) -> rejected
     with pytest.raises(PfError):
         lib.conv2d([cv.desc(None, 32, 16, out, 0, EPI_LINEAR, in0s=xs)], B, H8, W8, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 128, 256), (1, 136, 216), (3, 64, 80)])
+def test_enc_stem_matches_conv2d(lib, dev, shape):
+    """pf_enc_stem (round 4: the encoders' 7x7 / 2 stem from the NCHW image, K = the 7x7x3 patch) against torch's fp32 conv2d
+    (core/extractor.py:122,144) on full and ragged tile grids: values to the bf16x3 class (1e-4 of the largest output), the ReLU
+    form, the split twin bit-equal to pf_split_bf16 of the fp32 output, and the fused InstanceNorm statistics against the
+    mean / variance of the stored output."""
+    from prior_flow_amd.engine import pack_stem7x7, split_twin
+    Bn, H, W = shape
+    torch.manual_seed(17)
+    img = (torch.rand(Bn, 3, H, W, device=dev) * 2 - 1)
+    w = (torch.rand(64, 3, 7, 7, device=dev) * 2 - 1) * 0.2
+    b = (torch.rand(64, device=dev) * 2 - 1) * 0.3
+    ref = torch.nn.functional.conv2d(img, w, b, stride=2, padding=3)                  # [Bn,64,H/2,W/2]
+    h, w2 = H // 2, W // 2
+    rows = Bn * h * w2
+    wp = pack_stem7x7(w)
+    nblk = ((h + 7) // 8) * ((w2 + 31) // 32)
+    for relu in (False, True):
+        out = torch.full((rows, 64), float("nan"), device=dev)
+        tw = split_twin(rows, 64, dev)
+        part = torch.zeros(Bn * nblk * 64 * 2, dtype=torch.float64, device=dev)
+        lib.enc_stem(img, wp, b, out=out, out_split=tw, relu=relu, stats=part)
+        want = ref.relu() if relu else ref
+        got = out.view(Bn, h, w2, 64).permute(0, 3, 1, 2)
+        assert torch.isfinite(out).all()
+        assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max()), float((got - want).abs().max())
+        assert torch.equal(lib.split_bf16(out, split_twin(rows, 64, dev)), tw)
+        sc, sh = torch.empty(Bn, 64, device=dev), torch.empty(Bn, 64, device=dev)
+        lib.channel_stats_final(part, Bn, h * w2, 64, nblk, sc, sh)
+        o3 = out.view(Bn, h * w2, 64).double()
+        mean, var = o3.mean(1), o3.var(1, unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        assert float((sc.double() - rstd).abs().max()) < 1e-5 * float(rstd.abs().max())
+        assert float((sh.double() + mean * rstd).abs().max()) < 1e-5 * float((mean * rstd).abs().max() + 1.0)
+    # twin only (cnet's folded form): no fp32 rows
+    tw2 = split_twin(rows, 64, dev)
+    lib.enc_stem(img, wp, b, out=None, out_split=tw2, relu=True)
+    assert torch.equal(tw2, tw)
