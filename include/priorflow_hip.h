@@ -392,6 +392,12 @@ int pf_sum_squares(const float* x, long n, double* partials, int nblk, void* str
  * g*grad_scale (the clip coefficient), decoupled weight decay, bias-corrected update; step counts from 1. */
 int pf_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, float beta1, float beta2,
                   float eps, double weight_decay, int step, float grad_scale, void* stream);
+/* The same update with the step-dependent scalars in device memory: hyper[4] = {1 - lr * weight_decay, lr / (1 - beta1^step),
+ * sqrt(1 - beta2^step), grad_scale} (rounded from double like pf_adamw_step does).  Every launch argument is then constant
+ * over the steps, so the call can sit in a captured HIP graph of the whole training step (train.GraphedTrainStep): the host
+ * rewrites hyper[0..2] between replays, a kernel of the graph writes the clip coefficient hyper[3]. */
+int pf_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
+                      const float* hyper, void* stream);
 
 /* Backward of pf_dccl_combine / pf_dccl_lookup (autograd through DCCL.__call__, core/corr.py:113-144; coords
  * are detached, core/prior_raft.py:171,176): d_corr -> d_raw (rotate-back transposed; d_own = d_corr), then

@@ -123,6 +123,7 @@ _SIGNATURES = {
     "pf_sum_squares": [_fp, C.c_long, _fp, _i, _fp],
     "pf_adamw_step": [_fp, _fp, _fp, _fp, C.c_long, C.c_double, C.c_float, C.c_float, C.c_float, C.c_double, _i,
                       C.c_float, _fp],
+    "pf_adamw_step_dev": [_fp, _fp, _fp, _fp, C.c_long, C.c_float, C.c_float, C.c_float, _fp, _fp],
     "pf_flow_metrics": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_region_sums": [_fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
 }
@@ -635,6 +636,14 @@ class PfLib:
             raise PfError("adamw_step: buffers must have the same size")
         self._rc(self._dll.pf_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps,
                                          weight_decay, step, grad_scale, self._stream(p)), "pf_adamw_step")
+
+    def adamw_step_dev(self, p, g, m, v, beta1, beta2, eps, hyper):
+        """pf_adamw_step with {decay, step_size, sqrt_bc2, grad_scale} read from the device tensor `hyper` (4 floats)."""
+        self._chk(p, g, m, v, hyper)
+        if not (p.numel() == g.numel() == m.numel() == v.numel()) or hyper.numel() < 4:
+            raise PfError("adamw_step_dev: buffers must have the same size and hyper 4 floats")
+        self._rc(self._dll.pf_adamw_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), beta1, beta2, eps, _ptr(hyper),
+                                             self._stream(p)), "pf_adamw_step_dev")
 
     def flow_metrics(self, pred, gt, epe=None, sd=None, cosine=False):
         """pred, gt: NCHW [B,2,H,W]; epe / sd: [B,H,W] outputs (either optional); cosine: the 'Cosine' form of the distance."""

@@ -781,17 +781,45 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
         coords0 = torch.cat([xs, ys], 1).contiguous()                                           # :50-56
 
     _TAPE.gates = {}
+    # The pack cache serves ONE tape (a convolution that runs 2 x iters times packs once; the backward's data-gradient packs are
+    # made on demand): its keys -- parameter address + version + weights epoch -- cannot tell a new model apart whose parameters
+    # the allocator placed where a freed model's were, so nothing is carried from one forward to the next.
+    _PACKS.clear()
     try:
         return _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a_8, iters, init_flow)
     finally:
         _TAPE.gates = None
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a_8, iters, init_flow):
-    cnet = encoder_forward(model.cnet, torch.cat([i1, i1b], 0))                                 # :133-142
-    net_a, inp_a = torch.tanh(cnet[:B, :128]), torch.relu(cnet[:B, 128:])
-    net_b, inp_b = torch.tanh(cnet[B:, :128]), torch.relu(cnet[B:, 128:])
+    import os
+    side = None
+    if os.environ.get("PRIORFLOW_TRAIN_FORK", "1") != "0":
+        # cnet beside fnet on a side stream (round 4): at the training crop an encoder launch fills a fraction of the chip, and
+        # autograd runs every backward node on its forward node's stream, so the two encoders' backwards overlap as well
+        # (inside train.GraphedTrainStep the fork / join become parallel branches of the captured graph)
+        side = getattr(model, "_train_side_stream", None)
+        if side is None:
+            side = model._train_side_stream = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+    with torch.cuda.stream(side) if side is not None else _NullCtx():
+        cnet = encoder_forward(model.cnet, torch.cat([i1, i1b], 0))                             # :133-142
+        net_a, inp_a = torch.tanh(cnet[:B, :128]), torch.relu(cnet[:B, 128:])
+        net_b, inp_b = torch.tanh(cnet[B:, :128]), torch.relu(cnet[B:, 128:])
     fm = encoder_forward(model.fnet, torch.cat([i1, i2, i1b, i2b], 0)).float()                  # :144-149
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+        for t in (net_a, inp_a, net_b, inp_b):
+            t.record_stream(torch.cuda.current_stream())
     f1a, f2a, f1b, f2b = fm[:B], fm[B:2 * B], fm[2 * B:3 * B], fm[3 * B:]
     pyr_a = corr_pyramid(f1a, f2a)                                                              # :151-159
     pyr_b = corr_pyramid(f1b, f2b)

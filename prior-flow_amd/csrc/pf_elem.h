@@ -1056,6 +1056,16 @@ PF_HD void pf_adamw_elem(long i, const PfAdamWArgs& a) {
     a.p[i] = p; a.m[i] = m; a.v[i] = v;
 }
 
+// The same update with its step-dependent scalars read from DEVICE memory (hyper = {decay, step_size, sqrt_bc2, gscale}): the
+// launch arguments are then the same at every step, which is what a captured HIP graph of the training step needs -- the host
+// (or, for the clip coefficient, a kernel of the graph) rewrites the four floats between replays.
+struct PfAdamWDevArgs { float* p; const float* g; float* m; float* v; long n; float b1, b2, eps; const float* hyper; };
+PF_HD void pf_adamw_dev_elem(long i, const PfAdamWDevArgs& a) {
+    PfAdamWArgs b; b.p = a.p; b.g = a.g; b.m = a.m; b.v = a.v; b.n = a.n; b.b1 = a.b1; b.b2 = a.b2; b.eps = a.eps;
+    b.decay = a.hyper[0]; b.step_size = a.hyper[1]; b.sqrt_bc2 = a.hyper[2]; b.gscale = a.hyper[3];
+    pf_adamw_elem(i, b);
+}
+
 // channel-last -> NCHW (debug / boundary export)
 struct PfToNchwArgs { const float* in; float* out; int B, C, N, ld_in, c_in_off; };
 PF_HD void pf_to_nchw_elem(long idx, const PfToNchwArgs& a) {   // idx over B*C*N

@@ -38,11 +38,13 @@ class uniform_loss:
         self.H, self.W = H, W
         self.uniform_mask = torch.from_numpy(spherical_mask(H, W)).float().to(self.device).contiguous()   # H x W
         self.grads: List[torch.Tensor] = []
+        self._w: Dict[tuple, torch.Tensor] = {}        # gamma ** (n - i - 1) per (n, gamma), on the device
 
     @torch.no_grad()
     def __call__(self, flow_preds: Sequence[torch.Tensor], flow_gt: torch.Tensor, valid: torch.Tensor,
                  gamma: float = 0.8, extro_info: str = "", max_flow: float = MAX_FLOW,
-                 need_grads: bool = True) -> Tuple[torch.Tensor, Dict[str, float]]:
+                 need_grads: bool = True, lazy: bool = False) -> Tuple[torch.Tensor, Dict[str, float]]:
+        """lazy: the metrics stay 0-dim device tensors (no host synchronisation: what a captured HIP graph of the step needs)."""
         n = len(flow_preds)
         gt = flow_gt.float().contiguous()
         vd = valid.float().contiguous()
@@ -59,8 +61,15 @@ class uniform_loss:
             if need_grads:
                 self.grads.append(g)
         tot = part.sum(dim=(1, 2))                                     # [n, 6]
-        w = torch.tensor(weights, dtype=torch.float64, device=gt.device)
-        flow_loss = (w * tot[:, 0]).sum().float()
+        wk = (n, float(gamma), str(gt.device))
+        if wk not in self._w:                                          # (built outside any graph capture: a host -> device copy)
+            self._w[wk] = torch.tensor(weights, dtype=torch.float64, device=gt.device)
+        flow_loss = (self._w[wk] * tot[:, 0]).sum().float()
+        if lazy:
+            last = tot[-1]
+            nv = last[2].clamp(min=1.0)
+            return flow_loss, {extro_info + "epe": last[1] / nv, extro_info + "1px": last[3] / nv,
+                               extro_info + "3px": last[4] / nv, extro_info + "5px": last[5] / nv}
         last = tot[-1].tolist()
         nv = max(last[2], 1.0)
         metrics = {extro_info + "epe": last[1] / nv, extro_info + "1px": last[3] / nv,
@@ -242,3 +251,88 @@ def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criteri
     if optimizer.step_count % SYNC_CHECK_EVERY == 1:      # first step and every SYNC_CHECK_EVERY after it
         optimizer.assert_in_sync(group)
     return loss_a + loss_b, {**metrics_a, **metrics_b, "grad_norm": norm}
+
+
+class GraphedTrainStep:
+    """The whole optimisation step -- zero_grad, GT rotation, forward of both branches, sequence loss, backward, clip, fused
+    AdamW (train_flow.py:120-141) -- captured ONCE into a HIP graph and replayed: at the reference's training crop the step is
+    ~2 300 launches of 5-80 us each, and the host (autograd's Python nodes, ctypes calls) is as slow as the GPU; a replay costs
+    the host nothing.  What changes from step to step lives in device memory: the four inputs (static buffers copied into),
+    the step-dependent AdamW scalars and the clip coefficient (``pf_adamw_step_dev``: hyper = {1 - lr * wd, lr / bc1, sqrt(bc2),
+    clip coefficient}; the first three are written by the host before a replay, the last by the graph itself from
+    ``pf_sum_squares``).  Single process only: with more than one rank the gradient all-reduce sits between backward and clip, and
+    ``train_step`` (eager) is the path; ``add_noise`` (host-side numpy draw, train_flow.py:127-130) likewise.
+
+        step = GraphedTrainStep(model, optimizer, scheduler, criterion, iters=12)
+        loss, metrics = step(image1, image2, flow_gt, valid)        # 0-dim device tensors; float(...) them when needed
+
+    The first ``warmup`` calls run the eager ``train_step`` (lazy initialisations, allocator warm-up); the next call captures
+    (recording executes nothing) and replays."""
+
+    def __init__(self, model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criterion: uniform_loss, iters: int = 12,
+                 gamma: float = 0.8, clip: float = 1.0, warmup: int = 2):
+        self.model, self.opt, self.sched, self.crit = model, optimizer, scheduler, criterion
+        self.iters, self.gamma, self.clip, self.warmup = iters, gamma, clip, warmup
+        self.calls = 0
+        self.graph = None
+        self.static = None
+        self.out = None
+        dev = optimizer.flat.device
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+
+    def _body(self):
+        """One step on the static inputs; every value that leaves it is a device tensor."""
+        net = getattr(self.model, "module", self.model)
+        opt, crit = self.opt, self.crit
+        i1, i2, gt, valid = self.static
+        opt.grad.zero_()
+        gt_b, valid_b = rotate_gt(gt)
+        preds_a, preds_b = net(i1, i2, iters=self.iters)
+        loss_a, m_a = crit(preds_a, gt, valid, self.gamma, extro_info="A-", lazy=True)
+        seeds = list(crit.grads)
+        loss_b, m_b = crit(preds_b, gt_b, valid_b, self.gamma, extro_info="B-", lazy=True)
+        seeds += list(crit.grads)
+        torch.autograd.backward(list(preds_a) + list(preds_b), seeds)
+        with torch.no_grad():
+            opt.lib.sum_squares(opt.grad, opt._norm_part)
+            norm = opt._norm_part.sum().sqrt()
+            # clip_grad_norm_: coefficient min(1, max_norm / (norm + 1e-6)), applied inside the AdamW kernel
+            self.hyper[3:4].copy_((self.clip / (norm + 1e-6)).clamp(max=1.0).float().reshape(1))
+            g = opt.param_groups[0]
+            opt.lib.adamw_step_dev(opt.flat, opt.grad, opt.exp_avg, opt.exp_avg_sq, g["betas"][0], g["betas"][1], g["eps"], self.hyper)
+        return loss_a + loss_b, {**m_a, **m_b, "grad_norm": norm.float()}
+
+    def _set_hyper(self):
+        g = self.opt.param_groups[0]
+        lr, wd, (b1, b2) = float(g["lr"]), float(g["weight_decay"]), g["betas"]
+        t = self.opt.step_count + 1
+        self._hyper_host[0] = 1.0 - lr * wd
+        self._hyper_host[1] = lr / (1.0 - b1 ** t)
+        self._hyper_host[2] = math.sqrt(1.0 - b2 ** t)
+        self.hyper[:3].copy_(self._hyper_host, non_blocking=True)
+
+    def __call__(self, image1, image2, flow_gt, valid):
+        self.calls += 1
+        if self.calls <= self.warmup:
+            loss, m = train_step(self.model, self.opt, self.sched, self.crit, image1, image2, flow_gt, valid, iters=self.iters,
+                                 gamma=self.gamma, clip=self.clip)
+            return loss, m
+        self.opt._check_aliases()
+        if self.graph is None:
+            self.static = tuple(t.detach().float().contiguous().clone() for t in (image1, image2, flow_gt, valid))
+            self._set_hyper()
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._body()
+        else:
+            for dst, src in zip(self.static, (image1, image2, flow_gt, valid)):
+                dst.copy_(src)
+            self._set_hyper()
+        self.graph.replay()
+        self.opt.step_count += 1
+        self.opt.grad_scale = 1.0
+        _lib.bump_weights_epoch()       # the graph wrote the parameters through raw pointers: drop packed copies
+        self.sched.step()
+        return self.out

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--graph", action="store_true", help="the step as one captured HIP graph (train.GraphedTrainStep; single rank)")
     a = ap.parse_args()
     import torch.distributed as dist
     from prior_flow_amd import autograd as ag
@@ -53,11 +54,16 @@ def main():
     crit = tr.uniform_loss(H, W, device=dev)
     losses = []
 
+    graphed = tr.GraphedTrainStep(model, opt, sched, crit, iters=a.iters, clip=1.0, warmup=1) if a.graph and world == 1 else None
+
     def step():
-        loss, m = tr.train_step(model, opt, sched, crit, i1, i2, gt, valid, iters=a.iters, clip=1.0)
+        if graphed is not None:
+            loss, m = graphed(i1, i2, gt, valid)
+        else:
+            loss, m = tr.train_step(model, opt, sched, crit, i1, i2, gt, valid, iters=a.iters, clip=1.0)
         losses.append(float(loss))
 
-    for _ in range(a.warmup):
+    for _ in range(a.warmup + (2 if graphed is not None else 0)):      # graphed: one eager step, the capture, one replay
         step()
     ag.STATS["hip"] = ag.STATS["torch"] = 0
     torch.cuda.synchronize()
@@ -76,7 +82,8 @@ def main():
         ms = float(dt) / a.steps * 1e3
         print(json.dumps({"metric": "training pairs/sec (forward+backward+AdamW)", "value": round(world * a.batch / (ms / 1e3), 3),
                           "unit": "pairs/s", "n_gpus": world, "ms_per_step": round(ms, 2), "steps": a.steps,
-                          "config": {"workload": f"train_step {H}x{W} iters={a.iters} batch/GPU={a.batch}"},
+                          "config": {"workload": f"train_step {H}x{W} iters={a.iters} batch/GPU={a.batch}",
+                                     "hip_graph": graphed is not None},
                           "hip_launches_per_step": ag.STATS["hip"] // a.steps,
                           "torch_conv_launches_per_step": ag.STATS["torch"] // a.steps,
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
