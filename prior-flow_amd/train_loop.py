@@ -87,6 +87,13 @@ class LoopBuffers:
         b["t"], b["d_t"] = z(it, N, 128), z(it, N, 128)
 
 
+def _side_stream(model) -> torch.cuda.Stream:
+    s = getattr(model, "_loop_side_stream", None)
+    if s is None:
+        s = model._loop_side_stream = torch.cuda.Stream()
+    return s
+
+
 def _flat(t: torch.Tensor) -> torch.Tensor:
     """[iters][N][C] -> [iters * N][C] (the iterations as extra images of the deferred weight gradient)."""
     return t.view(-1, t.shape[-1])
@@ -160,12 +167,32 @@ class LoopFn(torch.autograd.Function):
             """One launch: the same-geometry convolutions `items` = (name, x, off0, c0, out, off_out, epilogue, kwargs) as groups."""
             lib.conv2d([P.fwd[n].desc(x, o0, c0, out, oo, epi, **kw) for n, x, o0, c0, out, oo, epi, kw in items], B, H8, W8, items[0][1])
 
+        # Two chains per iteration (round 4, like the inference engine's forks): the flow / confidence stems run on a side stream
+        # beside the lookups and the correlation convolutions, and the convex upsampling of iteration i beside iteration i + 1.
+        # Eagerly that is host overhead for little; inside train.GraphedTrainStep they are parallel branches of the captured graph,
+        # and at the training crop a launch fills a fraction of the chip.
+        main, side = torch.cuda.current_stream(), _side_stream(model)
+        side.wait_stream(main)
         n_launch = 0
         for i in range(iters):
             c1a, c1b = A["c"][i], Bb["c"][i]
             # flows, flo_rotate(flow_B), both feature warps + groupwise correlations: one launch (prior_raft.py:171-182)
             lib.motion_prep(c1a, c1b, g_a2b_8, g_b2a_8, f1r, f2r, A["flow4"][i], Bb["flow2"][i], A["conf_in"][i],
                             A["x"][i], 252, Bb["x"][i], 254)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                for name, src, off, dst in (("a.f1a", A["flow4"][i], 0, A["t_a"][i]), ("a.f1b", A["flow4"][i], 2, A["t_ba"][i]),
+                                            ("b.f1", Bb["flow2"][i], 0, Bb["t"][i])):
+                    w, bias = P.stem_w[name]
+                    lib.conv2d_small(src, False, off, 2, w, bias, dst, 0, 128, 7, 7, 1, True, B, H8, W8)
+                cv(("a.f2a", A["t_a"][i], 0, 128, A["cat"][i], 128, EPI_RELU, {}), ("a.f2b", A["t_ba"][i], 0, 128, A["cat"][i], 192, EPI_RELU, {}),
+                   ("b.f2", Bb["t"][i], 0, 128, Bb["cat"][i], 192, EPI_RELU, {}))
+                cv(("a.cf1", A["conf_in"][i], 0, 8, A["cf1"][i], 0, EPI_RELU, {}))
+                cv(("a.cf2", A["cf1"][i], 0, 32, A["cat"][i], 256, EPI_RELU, {}))
+                stems_done = torch.cuda.Event()
+                stems_done.record(side)
             # DCCL lookups (prior_raft.py:185-188)
             lib.dccl_lookup(c1a, pyr_a[0], pyr_b[0], g_b2a_8, A["own"], A["raw"])
             lib.dccl_combine(A["own"], A["raw"], g_b2a_8, A["corr"][i], B, H8, W8)
@@ -174,14 +201,7 @@ class LoopFn(torch.autograd.Function):
             # ---- motion encoders (update.py:183-201, :91-99); branch A and branch B of a shape are groups of one launch
             cv(("a.c1", A["corr"][i], 0, 324, A["c1"][i], 0, EPI_RELU, {}), ("b.c1", Bb["corr"][i], 0, 324, Bb["c1"][i], 0, EPI_RELU, {}))
             cv(("a.c2", A["c1"][i], 0, 256, A["cat"][i], 0, EPI_RELU, {}), ("b.c2", Bb["c1"][i], 0, 256, Bb["cat"][i], 0, EPI_RELU, {}))
-            for name, src, off, dst in (("a.f1a", A["flow4"][i], 0, A["t_a"][i]), ("a.f1b", A["flow4"][i], 2, A["t_ba"][i]),
-                                        ("b.f1", Bb["flow2"][i], 0, Bb["t"][i])):
-                w, bias = P.stem_w[name]
-                lib.conv2d_small(src, False, off, 2, w, bias, dst, 0, 128, 7, 7, 1, True, B, H8, W8)
-            cv(("a.f2a", A["t_a"][i], 0, 128, A["cat"][i], 128, EPI_RELU, {}), ("a.f2b", A["t_ba"][i], 0, 128, A["cat"][i], 192, EPI_RELU, {}),
-               ("b.f2", Bb["t"][i], 0, 128, Bb["cat"][i], 192, EPI_RELU, {}))
-            cv(("a.cf1", A["conf_in"][i], 0, 8, A["cf1"][i], 0, EPI_RELU, {}))
-            cv(("a.cf2", A["cf1"][i], 0, 32, A["cat"][i], 256, EPI_RELU, {}))
+            main.wait_event(stems_done)
             cv(("a.out", A["cat"][i], 0, 272, A["x"][i], 128, EPI_RELU, {}))
             cv(("b.out", Bb["cat"][i], 0, 256, Bb["x"][i], 128, EPI_RELU, {}))
             # ---- SepConvGRU (update.py:46-60), heads (update.py:13-14, :124-136)
@@ -197,11 +217,17 @@ class LoopFn(torch.autograd.Function):
             cv(*[(t + ".fh2", S["fh"][i], 0, 256, S["delta"][i], 0, EPI_LINEAR, {}) for t, S in SS])
             cv(*[(t + ".m0", S["h"][i + 1], 0, 128, S["mh"][i], 0, EPI_RELU, {}) for t, S in SS])
             cv(*[(t + ".m2", S["mh"][i], 0, 256, S["mask"][i], 0, EPI_LINEAR, dict(scale=0.25)) for t, S in SS])
-            for S, preds in ((A, preds_a), (Bb, preds_b)):
+            for S in (A, Bb):
                 S["c"][i + 1].copy_(S["c"][i])
                 lib.coords_add(S["c"][i + 1], S["delta"][i])          # coords1 += delta_flow (prior_raft.py:193,196)
-                lib.upsample_flow(S["c"][i + 1], S["mask"][i], preds[i])    # prior_raft.py:200-208
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                lib.upsample_flow(A["c"][i + 1], A["mask"][i], preds_a[i])      # prior_raft.py:200-208
+                lib.upsample_flow(Bb["c"][i + 1], Bb["mask"][i], preds_b[i])
             n_launch += 5 + 2 + 3 + 5 + 4 + 4 + 4
+        main.wait_stream(side)
         STATS["hip"] += n_launch
         ctx.cfg, ctx.bufs = cfg, bufs
         ctx.save_for_backward(f1r, f2r)
@@ -230,6 +256,10 @@ class LoopFn(torch.autograd.Function):
         pg_a, pg_b = pyr_a[2].buffers(pyr_a[0]), pyr_b[2].buffers(pyr_b[0])
         SS = (("a", A), ("b", Bb))
         gh: Dict[str, Optional[torch.Tensor]] = {"a": None, "b": None}        # gradient of the hidden state an iteration hands on
+        # The hidden-state chain (heads, GRU) is the only dependency between iterations; the motion encoders' data gradients, the
+        # DCCL and warp backwards of iteration i hang off it and run on a side stream beside the chain of iteration i - 1.
+        main, side = torch.cuda.current_stream(), _side_stream(cfg["model"])
+        side.wait_stream(main)
         n_launch = 0
         for i in range(iters - 1, -1, -1):
             Fq2 = {t: S["F"][2 * (i & 1)] for t, S in SS}             # ping-pong: gh of iteration i + 1 lives in the other pair
@@ -273,25 +303,29 @@ class LoopFn(torch.autograd.Function):
                 gh[t] = Fq1[t][:, 384:]
                 # d x = [d inp | d out | flows]: inp feeds every iteration, out = relu(conv) -> mask
                 lib.gru_dx_finish(Fq1[t][:, 128:384], Fq2[t][:, 128:384], S["x"][i], d_inp[t], S["d_out"][i], 128, 124 if t == "a" else 126)
-            # ---- motion encoders
-            dg(("a.out", A["d_out"][i], 0, 124, A["d_cat"][i], 0, EPI_MASK, dict(h=A["cat"][i])))
-            dg(("b.out", Bb["d_out"][i], 0, 128, Bb["d_cat"][i], 0, EPI_MASK, dict(h=Bb["cat"][i])))
-            dg(("a.c2", A["d_cat"][i], 0, 128, A["d_c1"][i], 0, EPI_MASK, dict(h=A["c1"][i])))
-            dg(("b.c2", Bb["d_cat"][i], 0, 192, Bb["d_c1"][i], 0, EPI_MASK, dict(h=Bb["c1"][i])))
-            dg(*[(t + ".c1", S["d_c1"][i], 0, 256, S["d_corr"], 0, EPI_LINEAR, {}) for t, S in SS])
-            dg(("a.f2a", A["d_cat"][i], 128, 64, A["d_t_a"][i], 0, EPI_MASK, dict(h=A["t_a"][i])),
-               ("a.f2b", A["d_cat"][i], 192, 64, A["d_t_ba"][i], 0, EPI_MASK, dict(h=A["t_ba"][i])),
-               ("b.f2", Bb["d_cat"][i], 192, 64, Bb["d_t"][i], 0, EPI_MASK, dict(h=Bb["t"][i])))
-            dg(("a.cf2", A["d_cat"][i], 256, 16, A["d_cf1"][i], 0, EPI_MASK, dict(h=A["cf1"][i])))
-            dg(("a.cf1", A["d_cf1"][i], 0, 32, A["d_conf"], 0, EPI_LINEAR, {}))
-            for t, S in SS:
-                S["d_raw"].zero_()
-                g_back = g_b2a_8 if t == "a" else g_a2b_8
-                lib.dccl_combine_bwd(S["d_corr"], g_back, S["d_raw"], B, H8, W8)
-                lib.dccl_lookup_bwd(S["c"][i], g_back, S["d_corr"], S["d_raw"], pg_a if t == "a" else pg_b, pg_b if t == "a" else pg_a)
-            lib.warp_gcorr_bwd(f1r, f2r, A["c"][i], False, A["d_conf"], 0, d_f1, d_f2)
-            lib.to_nchw(A["flow4"][i], 2, 2, A["flow_ba"])
-            lib.warp_gcorr_bwd(f1r, f2r, A["flow_ba"], True, A["d_conf"], 4, d_f1, d_f2)
+            # ---- motion encoders, DCCL, warps: beside the next (earlier) iteration's chain
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                dg(("a.out", A["d_out"][i], 0, 124, A["d_cat"][i], 0, EPI_MASK, dict(h=A["cat"][i])))
+                dg(("b.out", Bb["d_out"][i], 0, 128, Bb["d_cat"][i], 0, EPI_MASK, dict(h=Bb["cat"][i])))
+                dg(("a.c2", A["d_cat"][i], 0, 128, A["d_c1"][i], 0, EPI_MASK, dict(h=A["c1"][i])))
+                dg(("b.c2", Bb["d_cat"][i], 0, 192, Bb["d_c1"][i], 0, EPI_MASK, dict(h=Bb["c1"][i])))
+                dg(*[(t + ".c1", S["d_c1"][i], 0, 256, S["d_corr"], 0, EPI_LINEAR, {}) for t, S in SS])
+                dg(("a.f2a", A["d_cat"][i], 128, 64, A["d_t_a"][i], 0, EPI_MASK, dict(h=A["t_a"][i])),
+                   ("a.f2b", A["d_cat"][i], 192, 64, A["d_t_ba"][i], 0, EPI_MASK, dict(h=A["t_ba"][i])),
+                   ("b.f2", Bb["d_cat"][i], 192, 64, Bb["d_t"][i], 0, EPI_MASK, dict(h=Bb["t"][i])))
+                dg(("a.cf2", A["d_cat"][i], 256, 16, A["d_cf1"][i], 0, EPI_MASK, dict(h=A["cf1"][i])))
+                dg(("a.cf1", A["d_cf1"][i], 0, 32, A["d_conf"], 0, EPI_LINEAR, {}))
+                for t, S in SS:
+                    S["d_raw"].zero_()
+                    g_back = g_b2a_8 if t == "a" else g_a2b_8
+                    lib.dccl_combine_bwd(S["d_corr"], g_back, S["d_raw"], B, H8, W8)
+                    lib.dccl_lookup_bwd(S["c"][i], g_back, S["d_corr"], S["d_raw"], pg_a if t == "a" else pg_b, pg_b if t == "a" else pg_a)
+                lib.warp_gcorr_bwd(f1r, f2r, A["c"][i], False, A["d_conf"], 0, d_f1, d_f2)
+                lib.to_nchw(A["flow4"][i], 2, 2, A["flow_ba"])
+                lib.warp_gcorr_bwd(f1r, f2r, A["flow_ba"], True, A["d_conf"], 4, d_f1, d_f2)
             n_launch += 2 + 8 + 4 + 3
         # ---- deferred weight gradients: one launch per convolution over the iters * B stored images
         Bi = iters * B
@@ -302,6 +336,8 @@ class LoopFn(torch.autograd.Function):
             lib.conv2d_wgrad(_flat(x0), off0, c0, _flat(dy), off_dy, cout, dw, db, m.kh, m.kw, Bi, H8, W8,
                              x1=None if x1 is None else _flat(x1), off1=off1, c1=c1)
 
+        # (the chain's convolutions first: their output gradients were produced on this stream; the side stream is joined in
+        # front of the motion encoders' weight gradients)
         for t, S in (("a", A), ("b", Bb)):
             hs = S["h"]
             wg(t + ".m2", S["mh"], 0, 256, S["d_mask"], 0, 576)
@@ -312,9 +348,11 @@ class LoopFn(torch.autograd.Function):
             wg(t + ".zr2", S["h1"], 0, 128, S["d_zr2"], 0, 256, x1=S["x"], off1=0, c1=256)
             wg(t + ".q1", S["rhr1"], 0, 128, S["d_q1"], 0, 128, x1=S["x"], off1=0, c1=256)
             wg(t + ".zr1", hs[:iters], 0, 128, S["d_zr1"], 0, 256, x1=S["x"], off1=0, c1=256)
-            wg(t + ".c1", S["corr"], 0, 324, S["d_c1"], 0, 256)
         wg("a.out", A["cat"], 0, 272, A["d_out"], 0, 124)
         wg("b.out", Bb["cat"], 0, 256, Bb["d_out"], 0, 128)
+        main.wait_stream(side)
+        for t, S in (("a", A), ("b", Bb)):
+            wg(t + ".c1", S["corr"], 0, 324, S["d_c1"], 0, 256)
         wg("a.c2", A["c1"], 0, 256, A["d_cat"], 0, 128)
         wg("b.c2", Bb["c1"], 0, 256, Bb["d_cat"], 0, 192)
         wg("a.f2a", A["t_a"], 0, 128, A["d_cat"], 128, 64)
