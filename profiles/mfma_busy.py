@@ -10,21 +10,23 @@ import glob
 import json
 import sys
 
-acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+import statistics
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        a = acc[r["Kernel_Name"]][r["Counter_Name"]]
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, c in acc.items():
-    if "pf_conv" not in k and "pf_corr" not in k and "pf_combine_conv" not in k:
+    if "pf_conv" not in k and "pf_corr" not in k and "pf_combine_conv" not in k and "pf_enc_stem" not in k:
         continue
     if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
         continue
-    n = c["SQ_VALU_MFMA_BUSY_CYCLES"][0]
-    busy = c["SQ_VALU_MFMA_BUSY_CYCLES"][1] / n
-    gui = c["GRBM_GUI_ACTIVE"][1] / c["GRBM_GUI_ACTIVE"][0]
+    # MEDIAN over the launches (round 3 used the mean: the first corr-build launch of a process counted 4x the GRBM cycles of the
+    # others -- first-touch page faults of the 373 MB volume -- and the kernel's entry read 0.071 instead of ~0.27)
+    n = len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+    busy = statistics.median(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+    gui = statistics.median(c["GRBM_GUI_ACTIVE"])
     out[k[:110]] = {"launches": n, "mfma_busy_cycles_per_launch": busy, "grbm_gui_active_per_launch": gui,
                     "mfma_busy_fraction": busy / (1024.0 * gui / 8.0)}
 json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, bench.py --no-graph (single stream), B=1 512x1024 iters=12",

@@ -32,7 +32,7 @@ rd, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(rd) | set(wr)):
     if not any(t in k for t in ("pf_conv", "pf_corr", "Lookup", "Combine", "pf_combine", "pf_stem7x7", "pf_small_conv", "pf_norm_act",
-                                "pf_stats", "pf_motion_prep", "pf_conf_stem")):
+                                "pf_stats", "pf_motion_prep", "pf_conf_stem", "pf_enc_stem")):
         continue
     n = max(rd.get(k, [0])[0], wr.get(k, [0])[0])
     fetch = 2.0 * 1024.0 * rd[k][1] / rd[k][0] if k in rd and rd[k][0] else None
