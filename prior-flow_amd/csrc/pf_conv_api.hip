@@ -110,6 +110,11 @@ static int conv_dma_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g
         if (grp.d[i].stats_out != nullptr || grp.d[i].in_scale != nullptr) return 0;
     if (tile_id == 5) return 2;            // Cout <= 64 on a big map (3x3 by conv_tile's rule): the 256 px x 64 channel tile
     const long wgs256 = (long)(g.M / g.N) * ((g.H + 7) / 8) * ((g.W + 31) / 32) * ngroups * ((max_cout + 63) / 64);
+    // round 4: the 256 px x 64 channel tile for the 1x5 / 5x1 convolutions with Cout > 128 (the GRU's fused z|r) too: half the
+    // weight bytes staged per output, twice the halo; +0.2 % at B = 1, +0.6 % at batch 32 (profiles/r4_ab_gru_tile.txt);
+    // PRIORFLOW_DMA_GRU_WN1=0 restores the 128 px x 128 channel tile
+    static const bool gru_wn1 = [] { const char* e = getenv("PRIORFLOW_DMA_GRU_WN1"); return !(e && e[0] == '0'); }();
+    if (gru_wn1 && g.kh != 3 && max_cout > 128 && wgs256 >= 256) return 2;
     return (g.kh == 3 && max_cout > 64 && wgs256 >= 256) ? 2 : 1;
 }
 

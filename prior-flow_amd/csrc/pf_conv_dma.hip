@@ -497,7 +497,7 @@ int launch_conv_dma_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int
 
 // One translation unit per kernel shape (PF_DMA_PART = 0..6, compiled in parallel by __graft_entry__.build_hip: an unrolled
 // K-step body takes about a minute per instantiation) plus the dispatcher (PF_DMA_PART = 7).
-//   part: 0 <2,3,3,1>  1 <2,3,3,2>  2 <2,1,5,2>  3 <2,5,1,2>  4 <1,3,3,2>  5 <1,1,5,2>  6 <1,5,1,2>      (<NT, KH, KW, WN>)
+//   part: 0 <2,3,3,1>  1 <2,3,3,2>  2 <2,1,5,2>  3 <2,5,1,2>  4 <1,3,3,2>  5 <1,1,5,2>  6 <1,5,1,2>  8 <2,1,5,1>  9 <2,5,1,1>   (<NT, KH, KW, WN>)
 #ifndef PF_DMA_PART
 #error "compile pf_conv_dma.hip with -DPF_DMA_PART=0..7"
 #endif
@@ -520,17 +520,26 @@ PF_DMA_DEFINE_PART(4, 1, 3, 3, 2)
 PF_DMA_DEFINE_PART(5, 1, 1, 5, 2)
 #elif PF_DMA_PART == 6
 PF_DMA_DEFINE_PART(6, 1, 5, 1, 2)
+#elif PF_DMA_PART == 8
+PF_DMA_DEFINE_PART(8, 2, 1, 5, 1)
+#elif PF_DMA_PART == 9
+PF_DMA_DEFINE_PART(9, 2, 5, 1, 1)
 #else
 #define PF_DMA_DECLARE_PART(N) int pf_conv_dma_part##N##_launch(const pfconv::ConvGroups&, int, const pfconv::ConvGeom&, int, hipStream_t);
 PF_DMA_DECLARE_PART(0) PF_DMA_DECLARE_PART(1) PF_DMA_DECLARE_PART(2) PF_DMA_DECLARE_PART(3)
-PF_DMA_DECLARE_PART(4) PF_DMA_DECLARE_PART(5) PF_DMA_DECLARE_PART(6)
+PF_DMA_DECLARE_PART(4) PF_DMA_DECLARE_PART(5) PF_DMA_DECLARE_PART(6) PF_DMA_DECLARE_PART(8) PF_DMA_DECLARE_PART(9)
 
 int pf_conv_dma_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, int nt, int roles,
                        hipStream_t stream) {
     for (int i = 0; i < ngroups; ++i)
         if (!grp.d[i].zeros || grp.d[i].zeros_bytes < 128 * (grp.d[i].lds0 > grp.d[i].lds1 ? grp.d[i].lds0 : grp.d[i].lds1)) return PF_ERR_BAD_ARG;
     const bool k33 = g.kh == 3 && g.kw == 3, k15 = g.kh == 1 && g.kw == 5, k51 = g.kh == 5 && g.kw == 1;
-    if (roles == 2) return k33 ? pf_conv_dma_part0_launch(grp, ngroups, g, max_cout, stream) : PF_ERR_BAD_SHAPE;
+    if (roles == 2) {           // 256 px x 64 channels per workgroup: half the weight bytes staged per output, twice the halo
+        if (k33) return pf_conv_dma_part0_launch(grp, ngroups, g, max_cout, stream);
+        if (k15) return pf_conv_dma_part8_launch(grp, ngroups, g, max_cout, stream);
+        if (k51) return pf_conv_dma_part9_launch(grp, ngroups, g, max_cout, stream);
+        return PF_ERR_BAD_SHAPE;
+    }
     if (nt == 2) {
         if (k33) return pf_conv_dma_part1_launch(grp, ngroups, g, max_cout, stream);
         if (k15) return pf_conv_dma_part2_launch(grp, ngroups, g, max_cout, stream);
