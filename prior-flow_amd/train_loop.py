@@ -35,6 +35,7 @@ class LoopBuffers:
 
     def __init__(self, B: int, H8: int, W8: int, iters: int, device):
         self.key = (B, H8, W8, iters, str(device))
+        self.generation = 0           # bumped by every forward that fills the buffers; a backward checks it still owns them
         N = B * H8 * W8
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)      # noqa: E731
         it = iters
@@ -150,6 +151,7 @@ class LoopFn(torch.autograd.Function):
         bufs: Optional[LoopBuffers] = getattr(model, "_loop_bufs", None)
         if bufs is None or bufs.key != (B, H8, W8, iters, str(dev)):
             bufs = model._loop_bufs = LoopBuffers(B, H8, W8, iters, dev)
+        bufs.generation += 1
         A, Bb = bufs.a, bufs.b
         N = bufs.N
         f1r, f2r = _rows(f1a.detach()), _rows(f2a.detach())
@@ -229,7 +231,7 @@ class LoopFn(torch.autograd.Function):
             n_launch += 5 + 2 + 3 + 5 + 4 + 4 + 4
         main.wait_stream(side)
         STATS["hip"] += n_launch
-        ctx.cfg, ctx.bufs = cfg, bufs
+        ctx.cfg, ctx.bufs, ctx.generation = cfg, bufs, bufs.generation
         ctx.save_for_backward(f1r, f2r)
         ctx.n_rest = len(rest)
         return (*preds_a, *preds_b)
@@ -239,6 +241,10 @@ class LoopFn(torch.autograd.Function):
         from .autograd import _nchw, STATS
         lib = _lib.load()
         cfg, bufs = ctx.cfg, ctx.bufs
+        if bufs.generation != ctx.generation:
+            raise _lib.PfError("the training loop's activation workspace was refilled by a later forward before this backward ran "
+                               "(one workspace per model and shape): run backward before the next forward, or set "
+                               "PRIORFLOW_TRAIN_LOOP=0 for the per-node tape, which keeps its activations per call")
         P, pyr_a, pyr_b, coords0, g_a2b_8, g_b2a_8, iters = (cfg["packs"], cfg["pyr_a"], cfg["pyr_b"], cfg["coords0"],
                                                              cfg["g_a2b_8"], cfg["g_b2a_8"], cfg["iters"])
         f1r, f2r = ctx.saved_tensors
