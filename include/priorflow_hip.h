@@ -203,10 +203,11 @@ typedef struct pf_conv_desc {
      * (the previous layer's Instance/BatchNorm folded into this conv): x' = relu?(x*s + t).
      * [B][c0+c1] floats each; NULL = none.  Halo-kernel convolutions only (3x3/1x5/5x1, bf16x3). */
     const float* in_scale; const float* in_shift; int in_relu;
-    /* optional InstanceNorm statistics of THIS conv's output, fused into its epilogue (halo-kernel
-     * tiles 3/4/5 with PF_EPI_LINEAR only): stats_out[((image*nblk + tile)*cout + c)*2 + {0,1}] =
-     * fp64 sum / sum of squares of output channel c over one workgroup tile, nblk = tiles per image =
-     * ceil(H8/TH)*ceil(W8/32), TH = 8 for tile 5 else 4.  Finish with pf_channel_stats_final.  NULL = none. */
+    /* optional InstanceNorm statistics of THIS conv's output, fused into its epilogue (PF_EPI_LINEAR only):
+     * stats_out[((image*nblk + tile)*cout + c)*2 + {0,1}] = fp64 sum / sum of squares of output channel c over one workgroup
+     * tile.  Halo-kernel tiles 3/4/5: nblk = tiles per image = ceil(H8/TH)*ceil(W8/32), TH = 8 for tile 5 else 4.  Generic
+     * kernel (pf_conv2d_tile 0/1/2, bf16x3; the stride-2 layers): tiles of BM = 128/64/64 consecutive pixels, nblk = H8*W8/BM,
+     * which must divide (PF_ERR_BAD_SHAPE otherwise).  Finish with pf_channel_stats_final.  NULL = none. */
     double* stats_out;
     /* Pre-split activations (PF_PREC_BF16X3 only).  A "split twin" of a channel-last map holds, per pixel row and per
      * 32-channel chunk, the 128 bytes {bf16 hi[32], bf16 lo[32]} with hi = bf16(x) (round to nearest even) and

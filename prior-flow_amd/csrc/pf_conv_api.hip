@@ -141,9 +141,10 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
     hipStream_t s = (hipStream_t)stream;
     const bool split = descs[0].precision == PF_PREC_BF16X3;
     const int tile_id = conv_tile(g, ngroups, max_cout, descs[0].precision);
-    for (int i = 0; i < ngroups; ++i) {     // the input affine and the fused statistics are implemented by the halo kernel only
-        if (descs[i].in_scale && tile_id < 3) return PF_ERR_BAD_SHAPE;
-        if (descs[i].stats_out && (tile_id < 3 || descs[i].epilogue != PF_EPI_LINEAR)) return PF_ERR_BAD_SHAPE;
+    for (int i = 0; i < ngroups; ++i) {     // the input affine is implemented by the halo kernel only; the fused statistics by the
+        if (descs[i].in_scale && tile_id < 3) return PF_ERR_BAD_SHAPE;      // halo kernel and (round 4) by the generic one when its
+        if (descs[i].stats_out && descs[i].epilogue != PF_EPI_LINEAR) return PF_ERR_BAD_SHAPE;     // M tiles do not straddle images
+        if (descs[i].stats_out && tile_id < 3 && (!split || (g.N % (tile_id == 0 ? 128 : 64)) != 0)) return PF_ERR_BAD_SHAPE;
     }
     if (const int roles = conv_dma_choice(grp, ngroups, g, max_cout, tile_id))      // pre-split operands: the all-DMA kernel
         return pf_conv_dma_launch(grp, ngroups, g, max_cout, tile_id == 4 ? 2 : 1, roles, s);

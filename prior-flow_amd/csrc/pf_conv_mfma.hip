@@ -216,6 +216,45 @@ pf_conv_mfma_kernel(const ConvGroups groups, const ConvGeom g) {
 
     // ---- epilogue: acc[t][r] = D[row (r&3)+8(r>>2)+4h][col lane&31] ---------------------------
     tile_epilogue<NT, true>(d, acc, n0 + 32 * NT * wn, li, (long)m0 + 32 * wm + 4 * lh, g.M);
+    if (d.stats_out != nullptr) {
+        // InstanceNorm statistics of this tile's stored values (round 4: the stride-2 layers of fnet used to pay a separate
+        // pf_stats_partial pass over their output): fp64 sum / sum of squares per channel over the workgroup's BM pixels,
+        // partial [m tile][cout][2].  The launcher only passes stats_out when N % BM == 0 (a tile never straddles two images), so
+        // m tile = image * (N / BM) + tile in image: the [image][nblk] order pf_channel_stats_final reads.
+        __syncthreads();                                   // every wave has left the K loop: the operand LDS is free
+        double* red = reinterpret_cast<double*>(smem);     // [4 waves][32 * NT channels][2]
+        const long prow = (long)m0 + 32 * wm + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = n0 + 32 * NT * wn + 32 * t + li;
+            const float bias = j < d.cout ? d.bias[j] : 0.f;
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double v = (prow + (r & 3) + 8 * (r >> 2) < (long)g.M) ? (double)((acc[t][r] + bias) * d.scale) : 0.0;
+                s1 += v; s2 += v * v;
+            }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if ((lane >> 5) == 0) {
+                red[((wave * (32 * NT)) + 32 * t + li) * 2 + 0] = s1;
+                red[((wave * (32 * NT)) + 32 * t + li) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < d.cout) {
+            const int cw = tid / (32 * NT), cl = tid % (32 * NT);      // channel part (wn) and slot inside it
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int y = 0; y < WM; ++y) {                               // the waves (pixel rows) of this part, in order
+                const int wv = y * WN + cw;
+                s1 += red[(wv * (32 * NT) + cl) * 2 + 0];
+                s2 += red[(wv * (32 * NT) + cl) * 2 + 1];
+            }
+            double* o = d.stats_out + ((long)blockIdx.x * d.cout + n0 + tid) * 2;
+            o[0] = s1; o[1] = s2;
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -891,9 +891,12 @@ class EncoderPlan:
             if tile >= 3:
                 th = 8 if tile == 5 else 4
                 nblk = ((h + th - 1) // th) * ((w + 31) // 32)
-                if Bn * nblk * cout * 2 <= bufs["part"].numel():
-                    d.stats_out = bufs["part"].data_ptr()
-                    fused = True
+            else:           # generic kernel (the stride-2 layers): tiles of 128 / 64 / 64 consecutive pixels (round 4)
+                bm = 128 if tile == 0 else 64
+                nblk = (h * w) // bm if tile >= 0 and (h * w) % bm == 0 else 0
+            if nblk > 0 and Bn * nblk * cout * 2 <= bufs["part"].numel():
+                d.stats_out = bufs["part"].data_ptr()
+                fused = True
         lib.conv2d([d], Bn, h, w, x)
         if not fused:
             return self._affine(norm, y, Bn, h * w, cout, slot)
@@ -986,8 +989,7 @@ class EncoderPlan:
                 s2, t2 = self._conv_norm(blk["c2"], blk["n2"], o, cout, y2, Bn, h, w, cout, 1)
             if st != 1:
                 # shortcut: norm3(conv1x1/2(x)); reuse y1 (conv2 has consumed it) for the raw shortcut
-                lib.conv2d([blk["ds"].desc(x, 0, cin, y1, 0, EPI_LINEAR, stride=st)], Bn, h, w, x)
-                s3, t3 = self._affine(blk["n3"], y1, Bn, Np, cout, 2)
+                s3, t3 = self._conv_norm(blk["ds"], blk["n3"], x, cin, y1, Bn, h, w, cout, 2, stride=st)
                 lib.norm_act(y2, s2, t2, o, Bn, Np, cout, res=y1, rs=s3, rt=t3)
             elif first:
                 lib.norm_act(y2, s2, t2, o, Bn, Np, cout, res=x, rs=s0, rt=t0, res_relu=True)
