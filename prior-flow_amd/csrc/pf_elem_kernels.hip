@@ -91,7 +91,10 @@ __global__ void __launch_bounds__(kBlock) pf_warp_gcorr_wave(const PfWarpGcorrAr
 //            i = 0..3, i.e. the four channels that lane 16 i + j of pf_warp_gcorr_wave holds, and the sums run through the
 //            same xor-butterfly over 16 lanes: the results are bit-identical to that kernel's, the loads are 256-byte
 //            contiguous per pixel, and the row of f1 is loaded once for both warps.
-constexpr int MP_PIX = 32;
+#ifndef PF_MP_PIX
+#define PF_MP_PIX 32            // (16 -- two workgroups per CU at B = 1 -- measured the same: 11.3 vs 11.7 us alone, 131.1 vs 131.6 pairs/s; its 35 us in the replay is sharing the chip with both lookups)
+#endif
+constexpr int MP_PIX = PF_MP_PIX;
 __global__ void __launch_bounds__(256) pf_motion_prep_kernel(const PfMotionPrepArgs a, const long rows) {
     __shared__ float corner[4][MP_PIX][2];
     __shared__ float flows[MP_PIX][6];
