@@ -81,6 +81,17 @@ int pf_corr_pyramid_bf16x3(const void* f1_split, const void* f2_split, float* lv
  * format of the PF_PREC_BF16X3 GEMMs.  hi = bf16(x) round-to-nearest-even, lo = bf16(x - hi). */
 int pf_split_bf16(const float* in, void* out, long rows, int C, void* stream);
 
+/* Training: the packed weight / bias gradients of several convolutions (pf_conv2d_wgrad's dw / db) added into the parameters'
+ * own gradient tensors, PF_UNPACK_MAX_JOBS (16) convolutions per launch -- what optimizer-side autograd does per parameter with
+ * a permute copy, a clone and two accumulation adds (train_flow.py:135 loss.backward() on the reference):
+ *   gw[o][c][tap] += scale * dw[o_off + o][tap][c]   (gw: [cout][cin][kh][kw], taps = kh*kw)      gb[o] += scale * db[o_off + o]
+ * o_off: first packed row of this module inside a fused convolution (convz|convr); gb / db may be NULL together. */
+typedef struct pf_unpack_job {
+    const float* dw; const float* db; float* gw; float* gb;
+    int cout, cin, taps, cin_pad, o_off; float scale;
+} pf_unpack_job;
+int pf_unpack_wgrads(const pf_unpack_job* jobs, int n, void* stream);
+
 /* nn.Conv2d weights -> the PF_PREC_BF16X3 operand format of pf_conv2d, on the device, in one launch (what a training step
  * does for every convolution after each optimizer step, train_flow.py:138-140; replaces ~9 PyTorch-ROCm kernels per pack).
  * w0 [cout0][cin][kh][kw] and optionally w1 [cout1][cin][kh][kw] concatenated on the output channels (the fused z|r

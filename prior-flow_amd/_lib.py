@@ -36,6 +36,12 @@ class LookupDesc(C.Structure):
                 ("g_w2c_il", C.c_void_p), ("own_out", C.c_void_p), ("raw_out", C.c_void_p)]
 
 
+class UnpackJob(C.Structure):
+    """Mirror of ``pf_unpack_job`` (include/priorflow_hip.h)."""
+    _fields_ = [("dw", _fp), ("db", _fp), ("gw", _fp), ("gb", _fp),
+                ("cout", _i), ("cin", _i), ("taps", _i), ("cin_pad", _i), ("o_off", _i), ("scale", C.c_float)]
+
+
 class ConvDesc(C.Structure):
     """Mirror of ``pf_conv_desc`` (include/priorflow_hip.h)."""
     _fields_ = [
@@ -85,6 +91,7 @@ _SIGNATURES = {
     "pf_enc_stem": [_fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_gru_dx_finish": [_fp, _i, _fp, _i, _fp, _i, _fp, _i, _fp, _i, C.c_long, _i, _i, _fp],
     "pf_pack_conv_weights": [_fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _fp],
+    "pf_unpack_wgrads": [C.POINTER(UnpackJob), _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
     "pf_dccl_lookup_il": [_fp] * 13 + [_i, _i, _i, _i, _fp],
     "pf_dccl_lookup_pair": [C.c_void_p, _i, _i, _i, _i, _fp],
@@ -305,6 +312,19 @@ class PfLib:
                                                 C.c_void_p(dst_w.data_ptr()), _ptr(dst_b), op, cp, self._stream(w0)),
                  "pf_pack_conv_weights")
         return dst_w, dst_b
+
+    def unpack_wgrads(self, jobs):
+        """jobs: [(dw, db, gw, gb | None, cout, cin, taps, cin_pad, o_off, scale)]: gw += scale * unpacked(dw), gb += scale * db."""
+        if not jobs:
+            return
+        arr = (UnpackJob * len(jobs))()
+        for q, (dw, db, gw, gb, cout, cin, taps, cin_pad, o_off, scale) in zip(arr, jobs):
+            self._chk(dw, db, gw, gb)
+            if gw.numel() != cout * cin * taps or (gb is not None and gb.numel() != cout):
+                raise PfError("pf_unpack_wgrads: gradient tensor does not match the convolution's shape")
+            q.dw, q.db, q.gw, q.gb = _ptr(dw), _ptr(db), _ptr(gw), _ptr(gb)
+            q.cout, q.cin, q.taps, q.cin_pad, q.o_off, q.scale = cout, cin, taps, cin_pad, o_off, scale
+        self._rc(self._dll.pf_unpack_wgrads(arr, len(jobs), self._stream(jobs[0][0])), "pf_unpack_wgrads")
 
     def corr_pyramid_bf16x3(self, f1s, f2s, levels, B, H8, W8, Cch):
         self._chk(*levels)

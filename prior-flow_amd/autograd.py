@@ -98,6 +98,63 @@ def _pack(w: torch.Tensor, b: Optional[torch.Tensor], kind: str, src: Optional[t
     return val
 
 
+class GradSink:
+    """Direct route of the convolutions' weight / bias gradients into the parameters' ``.grad`` tensors (the views of
+    FlatAdamW's flat gradient buffer), switched on by ``train.train_step`` / ``GraphedTrainStep`` around forward + backward.
+    Without it every convolution hands autograd a fresh (dW, db): a zero fill of the packed buffer, a permute copy, a clone and two
+    accumulation adds -- five PyTorch kernels per convolution, ~290 per step.  With it the packed buffers are slices of ONE arena
+    (one fill per step), the autograd nodes return None for the parameters, and ``flush()`` adds all of them into the ``.grad``
+    tensors with ceil(n / 16) launches of pf_unpack_wgrads after the backward pass."""
+
+    def __init__(self):
+        self.active = False
+        self.arena: Optional[torch.Tensor] = None
+        self.used = 0
+        self.want = 0
+        self.jobs: list = []
+        self.keep: list = []
+
+    def begin(self, params) -> bool:
+        """Starts a step; False (and stays off) unless every parameter carries a contiguous fp32 ``.grad`` already."""
+        self.active = all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in params)
+        self.jobs, self.keep, self.used = [], [], 0
+        if not self.active:
+            return False
+        dev = params[0].device
+        if self.arena is None or self.arena.numel() < self.want or self.arena.device != dev:
+            self.arena = torch.zeros(max(self.want, 1), device=dev) if self.want else None
+        elif self.arena is not None:
+            self.arena.zero_()
+        self.want = 0
+        return True
+
+    def packed(self, op: int, taps: int, cin_pad: int, device):
+        """Zeroed (dw [op, taps, cin_pad], db [op]) for pf_conv2d_wgrad to accumulate into."""
+        n = op * taps * cin_pad + op
+        self.want += n
+        if self.arena is not None and self.used + n <= self.arena.numel() and self.arena.device == device:
+            both = self.arena[self.used:self.used + n]
+            self.used += n
+        else:                                   # first step (arena not sized yet) or a model that grew: a buffer of its own
+            both = torch.zeros(n, device=device)
+            self.keep.append(both)
+        return both[:op * taps * cin_pad].view(op, taps, cin_pad), both[op * taps * cin_pad:]
+
+    def add(self, dw, db, w, b, o_off: int = 0, scale: float = 1.0):
+        cout, cin, kh, kw = w.shape
+        self.jobs.append((dw, db, w.grad, None if b is None else b.grad, cout, cin, kh * kw, dw.shape[2], o_off, float(scale)))
+
+    def flush(self):
+        """Adds every registered packed gradient into its parameters' ``.grad``; ends the step."""
+        if self.active and self.jobs:
+            _lib.load().unpack_wgrads(self.jobs)
+            STATS["hip"] += (len(self.jobs) + 15) // 16
+        self.jobs, self.keep, self.active = [], [], False
+
+
+SINK = GradSink()
+
+
 class WeightGrad:
     """Packed weight / bias gradient of ONE convolution, accumulated over all its uses in a backward pass
     (pf_conv2d_wgrad accumulates): a conv of the update blocks runs `iters` times, and handing autograd a fresh
@@ -106,12 +163,16 @@ class WeightGrad:
     def __init__(self):
         self.dw: Optional[torch.Tensor] = None
         self.db: Optional[torch.Tensor] = None
+        self.scale = 1.0                                  # applied when the gradient is handed over (mask head: 0.25)
 
     def buffers(self, op: int, taps: int, cin_pad: int, device):
         if self.dw is None:
-            both = torch.zeros(op * taps * cin_pad + op, device=device)         # one fill for the pair
-            self.dw = both[:op * taps * cin_pad].view(op, taps, cin_pad)
-            self.db = both[op * taps * cin_pad:]
+            if SINK.active:
+                self.dw, self.db = SINK.packed(op, taps, cin_pad, device)
+            else:
+                both = torch.zeros(op * taps * cin_pad + op, device=device)         # one fill for the pair
+                self.dw = both[:op * taps * cin_pad].view(op, taps, cin_pad)
+                self.db = both[op * taps * cin_pad:]
         return self.dw, self.db
 
     def take(self):
@@ -129,15 +190,25 @@ class WeightGate(torch.autograd.Function):
     def forward(ctx, acc, *params):
         ctx.acc = acc
         ctx.shapes = [tuple(p.shape) for p in params[0::2]]
+        ctx.params = params                                  # python references (for GradSink), not saved tensors
         ctx.set_materialize_grads(False)
         return torch.empty(1, device=params[0].device)      # a token: its value is never read
 
     @staticmethod
     def backward(ctx, _):
+        scale = ctx.acc.scale
         got = ctx.acc.take()
         if got is None:
             return (None,) * (1 + 2 * len(ctx.shapes))
         dw, db = got
+        if SINK.active:
+            o = 0
+            for w, b in zip(ctx.params[0::2], ctx.params[1::2]):
+                SINK.add(dw, db, w, b, o_off=o, scale=scale)
+                o += w.shape[0]
+            return (None,) * (1 + 2 * len(ctx.shapes))
+        if scale != 1.0:
+            torch._foreach_mul_([dw, db], scale)
         grads, o = [], 0
         for cout, cin, kh, kw in ctx.shapes:
             grads += [Conv.unpack_wgrad(dw[o:o + cout], cout, cin, kh, kw), db[o:o + cout].clone()]
@@ -163,6 +234,7 @@ class HipConv(torch.autograd.Function):
         out = (torch.empty if cp == cout else torch.zeros)(B * H * W, cp, device=x.device)
         lib.conv2d([cv.desc(xr, 0, C, out, 0, EPI_LINEAR)], B, H, W, xr)
         ctx.save_for_backward(xr, w)
+        ctx.wb = (w, b)
         ctx.shape = (B, C, H, W, cout, kh, kw, cp)
         STATS["hip"] += 1
         return _nchw(out if cp == cout else out[:, :cout].contiguous(), B, H, W)
@@ -189,6 +261,11 @@ class HipConv(torch.autograd.Function):
             dw, db = ctx.acc.buffers(op, kh * kw, (C + 31) // 32 * 32, gy.device)
             lib.conv2d_wgrad(xr, 0, C, dy, 0, cp, dw, db, kh, kw, B, H, W)
             return dx, None, None, None, None, None
+        if SINK.active:
+            dw, db = SINK.packed(op, kh * kw, (C + 31) // 32 * 32, gy.device)
+            lib.conv2d_wgrad(xr, 0, C, dy, 0, cp, dw, db, kh, kw, B, H, W)
+            SINK.add(dw, db, *ctx.wb)
+            return dx, None, None, None, None, None
         dw = torch.zeros(op, kh * kw, (C + 31) // 32 * 32, device=gy.device)
         db = torch.zeros(op, device=gy.device)
         lib.conv2d_wgrad(xr, 0, C, dy, 0, cp, dw, db, kh, kw, B, H, W)
@@ -212,6 +289,7 @@ class HipConvS2(torch.autograd.Function):
         out = torch.empty(B * Ho * Wo, cout, device=x.device)
         lib.conv2d([cv.desc(xr, 0, C, out, 0, EPI_LINEAR, stride=2)], B, Ho, Wo, xr)
         ctx.save_for_backward(xr, w)
+        ctx.wb = (w, b)
         ctx.shape = (B, C, H, W, cout, kh, kw)
         STATS["hip"] += 1
         return _nchw(out, B, Ho, Wo)
@@ -231,10 +309,15 @@ class HipConvS2(torch.autograd.Function):
             lib.conv2d([dg.desc(dyu, 0, cout, dxr, 0, EPI_LINEAR)], B, H, W, dyu)
             dx = _nchw(dxr, B, H, W)
         op = (cout + 127) // 128 * 128
+        STATS["hip"] += 2
+        if SINK.active:
+            dw, db = SINK.packed(op, kh * kw, (C + 31) // 32 * 32, gy.device)
+            lib.conv2d_wgrad(xr, 0, C, dyu, 0, cout, dw, db, kh, kw, B, H, W)
+            SINK.add(dw, db, *ctx.wb)
+            return dx, None, None
         dw = torch.zeros(op, kh * kw, (C + 31) // 32 * 32, device=gy.device)
         db = torch.zeros(op, device=gy.device)
         lib.conv2d_wgrad(xr, 0, C, dyu, 0, cout, dw, db, kh, kw, B, H, W)
-        STATS["hip"] += 2
         # every zero of dYu adds 0 to db, so the column sums over the stuffed map are the bias gradient
         return dx, Conv.unpack_wgrad(dw, cout, C, kh, kw), db[:cout].clone()
 
@@ -255,6 +338,7 @@ class HipSmallConv(torch.autograd.Function):
         out = torch.empty(B * Ho * Wo, cout, device=x.device)
         lib.conv2d_small(xin, True, 0, C, wp, b.detach().contiguous(), out, 0, cout, kh, kw, stride, False, B, Ho, Wo)
         ctx.save_for_backward(xin)
+        ctx.wb = (w, b)
         ctx.shape = (B, C, Ho, Wo, cout, kh, kw, stride)
         STATS["hip"] += 1
         return _nchw(out, B, Ho, Wo)
@@ -266,10 +350,14 @@ class HipSmallConv(torch.autograd.Function):
         lib = _lib.load()
         (xin,) = ctx.saved_tensors
         B, C, Ho, Wo, cout, kh, kw, stride = ctx.shape
+        STATS["hip"] += 1
+        if SINK.active:                          # the kernel accumulates in the parameter layout: straight into .grad
+            w, b = ctx.wb
+            lib.conv2d_wgrad_small(xin, True, 0, C, _rows(gy), 0, cout, w.grad, b.grad, kh, kw, stride, B, Ho, Wo)
+            return None, None, None, None
         dw = torch.zeros(cout, C, kh, kw, device=gy.device)
         db = torch.zeros(cout, device=gy.device)
         lib.conv2d_wgrad_small(xin, True, 0, C, _rows(gy), 0, cout, dw, db, kh, kw, stride, B, Ho, Wo)
-        STATS["hip"] += 1
         return None, dw, db, None
 
 

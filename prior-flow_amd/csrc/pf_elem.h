@@ -896,6 +896,41 @@ PF_HD void pf_pack_conv_weights_elem(long idx, const PfPackWArgs& a) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// Training: packed weight / bias gradients -> the parameters' own gradient tensors, several convolutions per launch.
+//   gw[o][c][tap] += scale * dw[o_off + o][tap][c]      gb[o] += scale * db[o_off + o]
+// dw: pf_conv2d_wgrad's layout [Cout_pad128][taps][cin_pad]; gw: [cout][cin][KH][KW] (the .grad of an nn.Conv2d weight, a view
+// of the optimiser's flat gradient buffer).  o_off selects the rows of one module inside a fused convolution (convz|convr).
+// One call = one element of one job; job j owns the indices [start[j], start[j+1]): cout*cin*taps weight elements, then cout
+// bias elements.
+// ----------------------------------------------------------------------------------------------
+#define PF_UNPACK_MAX_JOBS 16
+struct PfUnpackJob {
+    const float* dw; const float* db; float* gw; float* gb;
+    int cout, cin, taps, cin_pad, o_off; float scale;
+};
+struct PfUnpackArgs {
+    PfUnpackJob job[PF_UNPACK_MAX_JOBS];
+    long start[PF_UNPACK_MAX_JOBS + 1];
+    int n;
+};
+PF_HD void pf_unpack_wgrads_elem(long idx, const PfUnpackArgs& a) {
+    int j = 0;
+    while (j + 1 < a.n && idx >= a.start[j + 1]) ++j;
+    const PfUnpackJob& q = a.job[j];
+    long i = idx - a.start[j];
+    const long nw = (long)q.cout * q.cin * q.taps;
+    if (i < nw) {
+        const int tap = (int)(i % q.taps);
+        const int c = (int)((i / q.taps) % q.cin);
+        const int o = (int)(i / ((long)q.taps * q.cin));
+        q.gw[i] += q.scale * q.dw[((long)(q.o_off + o) * q.taps + tap) * q.cin_pad + c];
+    } else if (q.gb != nullptr) {
+        i -= nw;
+        q.gb[i] += q.scale * q.db[q.o_off + i];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Encoder glue (core/extractor.py:41-47, :144-150): out = relu( res' + relu(y*s + t) ) with
 // res' = res (identity shortcut) | res*rs + rt (normalised 1x1/2 shortcut) | absent.
 // y, res, out: channel-last [B*Np][C]; s,t,rs,rt: [B][C].  One call = 4 consecutive channels.

@@ -18,6 +18,7 @@ Mirrors, with the reference's names and argument meaning:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Sequence, Tuple
 
 import torch
@@ -237,13 +238,17 @@ def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criteri
         stdv = float(np.random.uniform(0.0, 5.0))
         image1 = (image1 + stdv * torch.randn(*image1.shape, device=image1.device)).clamp(0.0, 255.0)
         image2 = (image2 + stdv * torch.randn(*image2.shape, device=image2.device)).clamp(0.0, 255.0)
-    preds_a, preds_b = net(image1, image2, iters=iters)
-    loss_a, metrics_a = criterion(preds_a, flow_gt, valid, gamma, extro_info="A-")
-    seeds = list(criterion.grads)
-    loss_b, metrics_b = criterion(preds_b, flow_gt_b, valid_b, gamma, extro_info="B-")
-    seeds += list(criterion.grads)
-    # loss.backward(): the criterion has already produced d loss / d prediction for every prediction
-    torch.autograd.backward(list(preds_a) + list(preds_b), seeds)
+    sink = _grad_sink(optimizer)
+    try:
+        preds_a, preds_b = net(image1, image2, iters=iters)
+        loss_a, metrics_a = criterion(preds_a, flow_gt, valid, gamma, extro_info="A-")
+        seeds = list(criterion.grads)
+        loss_b, metrics_b = criterion(preds_b, flow_gt_b, valid_b, gamma, extro_info="B-")
+        seeds += list(criterion.grads)
+        # loss.backward(): the criterion has already produced d loss / d prediction for every prediction
+        torch.autograd.backward(list(preds_a) + list(preds_b), seeds)
+    finally:
+        sink.flush()
     parallel.all_reduce_sum_(optimizer.grad, group)
     norm = clip_grad_norm_(optimizer, clip)
     optimizer.step()
@@ -251,6 +256,17 @@ def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criteri
     if optimizer.step_count % SYNC_CHECK_EVERY == 1:      # first step and every SYNC_CHECK_EVERY after it
         optimizer.assert_in_sync(group)
     return loss_a + loss_b, {**metrics_a, **metrics_b, "grad_norm": norm}
+
+
+def _grad_sink(optimizer):
+    """Starts autograd.GradSink for one step (the convolutions' weight gradients go straight into the ``.grad`` views of the flat
+    buffer; PRIORFLOW_GRAD_SINK=0: through autograd's own accumulation as in round 3).  Call ``.flush()`` after backward."""
+    from .autograd import SINK
+    if os.environ.get("PRIORFLOW_GRAD_SINK", "1") != "0":
+        SINK.begin(optimizer.params)
+    else:
+        SINK.active = False
+    return SINK
 
 
 class GraphedTrainStep:
@@ -288,12 +304,16 @@ class GraphedTrainStep:
         i1, i2, gt, valid = self.static
         opt.grad.zero_()
         gt_b, valid_b = rotate_gt(gt)
-        preds_a, preds_b = net(i1, i2, iters=self.iters)
-        loss_a, m_a = crit(preds_a, gt, valid, self.gamma, extro_info="A-", lazy=True)
-        seeds = list(crit.grads)
-        loss_b, m_b = crit(preds_b, gt_b, valid_b, self.gamma, extro_info="B-", lazy=True)
-        seeds += list(crit.grads)
-        torch.autograd.backward(list(preds_a) + list(preds_b), seeds)
+        sink = _grad_sink(opt)
+        try:
+            preds_a, preds_b = net(i1, i2, iters=self.iters)
+            loss_a, m_a = crit(preds_a, gt, valid, self.gamma, extro_info="A-", lazy=True)
+            seeds = list(crit.grads)
+            loss_b, m_b = crit(preds_b, gt_b, valid_b, self.gamma, extro_info="B-", lazy=True)
+            seeds += list(crit.grads)
+            torch.autograd.backward(list(preds_a) + list(preds_b), seeds)
+        finally:
+            sink.flush()
         with torch.no_grad():
             opt.lib.sum_squares(opt.grad, opt._norm_part)
             norm = opt._norm_part.sum().sqrt()

@@ -238,7 +238,7 @@ class LoopFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *g_preds):
-        from .autograd import _nchw, STATS
+        from .autograd import _nchw, SINK, STATS
         lib = _lib.load()
         cfg, bufs = ctx.cfg, ctx.bufs
         if bufs.generation != ctx.generation:
@@ -367,11 +367,14 @@ class LoopFn(torch.autograd.Function):
         wg("a.cf2", A["cf1"], 0, 32, A["d_cat"], 256, 16)
         wg("a.cf1", A["conf_in"], 0, 8, A["d_cf1"], 0, 32)
         for t in "ab":          # mask = 0.25 * conv: the output gradient stored for m2 is the un-scaled one
-            dw, db = P.acc[t + ".m2"].dw, P.acc[t + ".m2"].db
-            torch._foreach_mul_([dw, db], 0.25)
+            P.acc[t + ".m2"].scale = 0.25
         stem_grads = []
         for name, x, off, dy in (("a.f1a", A["flow4"], 0, A["d_t_a"]), ("a.f1b", A["flow4"], 2, A["d_t_ba"]), ("b.f1", Bb["flow2"], 0, Bb["d_t"])):
             m = P.stems[name]
+            if SINK.active:     # accumulated in the parameter layout: straight into .grad
+                lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, m.weight.grad, m.bias.grad, 7, 7, 1, Bi, H8, W8)
+                stem_grads += [None, None]
+                continue
             dw, db = torch.zeros_like(m.weight), torch.zeros_like(m.bias)
             lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, dw, db, 7, 7, 1, Bi, H8, W8)
             stem_grads += [dw, db]
