@@ -425,6 +425,18 @@ int pf_warp_gcorr_bwd(const float* f1, const float* f2, const float* coords, int
 int pf_upsample_flow_bwd(const float* coords1, const float* mask, int ld, const float* g, float* d_mask, int ld_d,
                          float* d_flow, int B, int H8, int W8, void* stream);
 
+/* nn.BatchNorm2d with frozen statistics (freeze_bn, train_flow.py:107-108: the context encoder in every stage but `chairs`),
+ * optionally with the ReLU behind it (core/extractor.py:41-42,144-146), on channel-last rows [rows][C], one launch:
+ *   out = [relu]( x*s + t ),  s = gamma * rsqrt(var + eps),  t = beta - mean * s. */
+int pf_bn_frozen_fwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* var,
+                     float eps, int relu, float* out, long rows, int C, void* stream);
+/* Its backward: g_m = relu ? (x*s + t > 0 ? dy : 0) : dy;  dx = s * g_m;  dgamma[c] (+)= sum g_m * (x - mean) * rsqrt(var + eps),
+ * dbeta[c] (+)= sum g_m (accumulate != 0: added to what is there -- the parameters' .grad).  Deterministic fp64 sums through
+ * `partials` (nblk*C*2 doubles, nblk <= rows).  Three launches. */
+int pf_bn_frozen_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                     const float* var, float eps, int relu, double* partials, int nblk, float* dx,
+                     float* dgamma, float* dbeta, int accumulate, long rows, int C, void* stream);
+
 /* Backward of y = act(x * scale[b,c] + shift[b,c]) on channel-last rows [B*Np][C] (the encoders' norm + ReLU,
  * core/extractor.py:112-147; scale / shift as produced by pf_channel_stats or the folded BatchNorm affine).
  * relu != 0: dy is masked where x*scale+shift <= 0.  instance != 0: InstanceNorm backward,

@@ -24,10 +24,9 @@ _i = C.c_int
 
 
 def _norm_bwd_blocks(Np: int) -> int:
-    """Pixel chunks of pf_norm_bwd's two-stage reduction: ~sqrt(Np), so the partial pass (one thread per chunk and channel)
-    and the final pass (one thread per channel, looping over the chunks) are equally long serial loops.  (Np // 64 made
-    the final pass of a 192x256 map a 768-step loop: 88 us per call.)"""
-    return max(1, min(Np, int(round(Np ** 0.5))))
+    """Pixel chunks of pf_norm_bwd's two-stage reduction: >= 16 pixels per partial sum, at most 1024 chunks per image (the
+    partial pass runs one thread per chunk and channel; the final pass sums the chunks of one (image, channel) with one wave)."""
+    return max(1, min(Np // 16, 1024))
 
 
 class LookupDesc(C.Structure):
@@ -92,6 +91,8 @@ _SIGNATURES = {
     "pf_gru_dx_finish": [_fp, _i, _fp, _i, _fp, _i, _fp, _i, _fp, _i, C.c_long, _i, _i, _fp],
     "pf_pack_conv_weights": [_fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _fp],
     "pf_unpack_wgrads": [C.POINTER(UnpackJob), _i, _fp],
+    "pf_bn_frozen_fwd": [_fp, _fp, _fp, _fp, _fp, C.c_float, _i, _fp, C.c_long, _i, _fp],
+    "pf_bn_frozen_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, C.c_float, _i, _fp, _i, _fp, _fp, _fp, _i, C.c_long, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
     "pf_dccl_lookup_il": [_fp] * 13 + [_i, _i, _i, _i, _fp],
     "pf_dccl_lookup_pair": [C.c_void_p, _i, _i, _i, _i, _fp],
@@ -581,6 +582,24 @@ class PfLib:
         self._rc(self._dll.pf_norm_bwd(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), 0, 1, _ptr(part), nblk, _ptr(coef),
                                        _ptr(scratch), B, Np, Cc, self._stream(dy)), "pf_norm_bwd")
         return coef.view(B, Cc, 2)
+
+    def bn_frozen_fwd(self, x, gamma, beta, mean, var, eps, relu, out):
+        """out = [relu](frozen BatchNorm(x)) on channel-last rows [rows, C]."""
+        self._chk(x, gamma, beta, mean, var, out)
+        rows, Cc = x.shape
+        self._rc(self._dll.pf_bn_frozen_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), float(eps), int(bool(relu)),
+                                            _ptr(out), rows, Cc, self._stream(x)), "pf_bn_frozen_fwd")
+        return out
+
+    def bn_frozen_bwd(self, dy, x, gamma, beta, mean, var, eps, relu, dx, dgamma, dbeta, accumulate):
+        self._chk(dy, x, gamma, beta, mean, var, dx, dgamma, dbeta)
+        rows, Cc = x.shape
+        nblk = int(max(1, min(rows // 16, 2048)))        # >= 16 rows per partial sum; 2048 x C threads fill the chip at the encoder sizes
+        part = torch.empty(nblk * Cc * 2, dtype=torch.float64, device=dy.device)
+        self._rc(self._dll.pf_bn_frozen_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), float(eps),
+                                            int(bool(relu)), C.c_void_p(part.data_ptr()), nblk, _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                            int(bool(accumulate)), rows, Cc, self._stream(dy)), "pf_bn_frozen_bwd")
+        return dx
 
     def gru_q_bwd(self, dh_new, z, q, h, dq_pre, dz, dh):
         """Stage Q of the GRU gate backward; every argument a channel-last [rows, >=C] view (C = dh_new.shape[-1])."""

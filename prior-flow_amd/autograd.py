@@ -35,6 +35,7 @@ and ``torch.autograd.grad`` all see ordinary gradients.
 from __future__ import annotations
 
 import math
+import os
 import threading
 from typing import Dict, List, Optional, Tuple
 
@@ -393,6 +394,41 @@ class HipFrozenBatchNorm(torch.autograd.Function):
         return _nchw(dx, B, H, W), dgamma, dbeta, None, None, None
 
 
+class HipFrozenBnAct(torch.autograd.Function):
+    """HipFrozenBatchNorm [+ the ReLU behind it] in one launch forward (pf_bn_frozen_fwd) and three backward (pf_bn_frozen_bwd:
+    masked sums -> d gamma / d beta, dx), instead of ~8 + ~15 elementwise PyTorch kernels per layer.  With the GradSink on,
+    d gamma / d beta are added straight into the parameters' .grad."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps, relu):
+        lib = _lib.load()
+        B, Cc, H, W = x.shape
+        xr = _rows(x.detach())
+        out = torch.empty_like(xr)
+        lib.bn_frozen_fwd(xr, gamma.detach(), beta.detach(), mean, var, eps, relu, out)
+        ctx.save_for_backward(xr, mean, var)
+        ctx.gb = (gamma, beta)
+        ctx.cfg = (x.shape, float(eps), bool(relu))
+        STATS["hip"] += 1
+        return _nchw(out, B, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        xr, mean, var = ctx.saved_tensors
+        gamma, beta = ctx.gb
+        (B, Cc, H, W), eps, relu = ctx.cfg
+        dx = torch.empty_like(xr)
+        sink = SINK.active and gamma.grad is not None and beta.grad is not None
+        dgamma = gamma.grad if sink else torch.empty_like(gamma)
+        dbeta = beta.grad if sink else torch.empty_like(beta)
+        lib.bn_frozen_bwd(_rows(g), xr, gamma.detach(), beta.detach(), mean, var, eps, relu, dx, dgamma, dbeta, sink)
+        STATS["hip"] += 3
+        if sink:
+            return _nchw(dx, B, H, W), None, None, None, None, None, None
+        return _nchw(dx, B, H, W), dgamma, dbeta, None, None, None, None
+
+
 class HipBatchNormTrain(torch.autograd.Function):
     """nn.BatchNorm2d in training mode (batch statistics; the reference's `chairs` stage leaves BatchNorm unfrozen,
     train_flow.py:107-108).  The statistics run over the whole batch, i.e. the channel-last rows [B*H*W][C] are ONE image of
@@ -738,14 +774,20 @@ class HipInstanceNorm(torch.autograd.Function):
 
 
 # ---- module forwards (the parameter containers of modules.py carry no arithmetic of their own) ---------------
+_FUSED_BN = os.environ.get("PRIORFLOW_TRAIN_BN_FUSED", "1") != "0"
+
+
 def _norm(m: nn.Module, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
     """norm layer `m` on x; relu=True: followed by the ReLU (one pass for InstanceNorm)."""
     if isinstance(m, nn.InstanceNorm2d):
         return HipInstanceNorm.apply(x, relu)
+    if isinstance(m, nn.BatchNorm2d) and not m.training and m.weight is not None and _FUSED_BN:
+        # frozen statistics (freeze_bn): the reference's configuration
+        return HipFrozenBnAct.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps, relu)
     if relu:
         return torch.relu(_norm(m, x))
     if isinstance(m, nn.BatchNorm2d):
-        if not m.training and m.weight is not None:          # frozen statistics (freeze_bn): the reference's configuration
+        if not m.training and m.weight is not None:          # PRIORFLOW_TRAIN_BN_FUSED=0: round 3's elementwise form
             return HipFrozenBatchNorm.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps)
         if m.training and m.weight is not None:               # batch statistics (the `chairs` stage)
             return HipBatchNormTrain.apply(x, m.weight, m.bias, m)

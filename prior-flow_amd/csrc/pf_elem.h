@@ -607,6 +607,66 @@ PF_HD void pf_norm_bwd_apply_elem(long idx, const PfNormBwdArgs& a) {       // i
         a.dx[idx] = s * g;
     }
 }
+// ----------------------------------------------------------------------------------------------
+// BatchNorm2d with frozen statistics (freeze_bn, train_flow.py:107-108; the context encoder's norm, core/extractor.py:114-115),
+// optionally with the ReLU behind it, on channel-last rows [rows][C]:
+//   forward   out = [relu]( x*s + t ),  s = gamma * rsqrt(var + eps),  t = beta - mean * s
+//   backward  g_m = relu ? (x*s + t > 0 ? g : 0) : g;   dx = s * g_m;   d gamma = sum g_m * xhat,  d beta = sum g_m,
+//             xhat = (x - mean) * rsqrt(var + eps);  the sums: fp64 partials per (row block, channel), fixed order.
+// ----------------------------------------------------------------------------------------------
+struct PfBnArgs {
+    const float* x; const float* dy; const float* gamma; const float* beta; const float* mean; const float* var;
+    float* out;            // forward: out; backward: dx
+    double* part;          // [nblk][C][2]
+    float* dgamma; float* dbeta;
+    float eps; long rows; int C, nblk, relu, accumulate;
+};
+PF_HD void pf_bn_fwd_elem(long idx, const PfBnArgs& a) {              // idx over rows*C
+    const int c = (int)(idx % a.C);
+    const float s = a.gamma[c] * (1.f / sqrtf(a.var[c] + a.eps));
+    const float y = a.x[idx] * s + (a.beta[c] - a.mean[c] * s);
+    a.out[idx] = (a.relu && !(y > 0.f)) ? 0.f : y;
+}
+PF_HD void pf_bn_bwd_partial_elem(long idx, const PfBnArgs& a) {      // idx over nblk*C
+    const int c = (int)(idx % a.C);
+    const long blk = idx / a.C;
+    const long chunk = (a.rows + a.nblk - 1) / a.nblk;
+    const long p0 = blk * chunk, p1 = (p0 + chunk < a.rows) ? p0 + chunk : a.rows;
+    const float rstd = 1.f / sqrtf(a.var[c] + a.eps), mean = a.mean[c];
+    const float s = a.gamma[c] * rstd, t = a.beta[c] - mean * s;
+    double s1 = 0.0, s2 = 0.0;
+    long p = p0;
+    for (; p + 8 <= p1; p += 8) {          // eight rows' loads in flight together; the sums keep their row order
+        float xv[8], gv[8];
+        for (int u = 0; u < 8; ++u) { xv[u] = a.x[(p + u) * a.C + c]; gv[u] = a.dy[(p + u) * a.C + c]; }
+        for (int u = 0; u < 8; ++u) {
+            const float g = (a.relu && !(xv[u] * s + t > 0.f)) ? 0.f : gv[u];
+            s1 += (double)g; s2 += (double)g * (double)((xv[u] - mean) * rstd);
+        }
+    }
+    for (; p < p1; ++p) {
+        const float xv = a.x[p * a.C + c];
+        const float g = (a.relu && !(xv * s + t > 0.f)) ? 0.f : a.dy[p * a.C + c];
+        s1 += (double)g; s2 += (double)g * (double)((xv - mean) * rstd);
+    }
+    a.part[idx * 2] = s1; a.part[idx * 2 + 1] = s2;
+}
+PF_HD void pf_bn_bwd_final_elem(long idx, const PfBnArgs& a) {        // idx over C
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < a.nblk; ++k) {
+        const double* q = a.part + ((long)k * a.C + idx) * 2;
+        s1 += q[0]; s2 += q[1];
+    }
+    if (a.accumulate) { a.dbeta[idx] += (float)s1; a.dgamma[idx] += (float)s2; }
+    else { a.dbeta[idx] = (float)s1; a.dgamma[idx] = (float)s2; }
+}
+PF_HD void pf_bn_bwd_apply_elem(long idx, const PfBnArgs& a) {        // idx over rows*C
+    const int c = (int)(idx % a.C);
+    const float s = a.gamma[c] * (1.f / sqrtf(a.var[c] + a.eps));
+    const float y = a.x[idx] * s + (a.beta[c] - a.mean[c] * s);
+    a.out[idx] = (a.relu && !(y > 0.f)) ? 0.f : s * a.dy[idx];
+}
+
 struct PfLookupBwdArgs {
     const float* coords;                  // planar [B,2,N]
     const float* g_w2c;                   // [2,N]

@@ -553,6 +553,47 @@ int launch_stats_final(const double* part, int B, int Np, int C, int nblk, float
     return (int)hipGetLastError();
 }
 
+// Final stage of the two-stage fp64 reductions of the norm backward passes (pf_norm_bwd, pf_bn_frozen_bwd): the nblk partial
+// (sum g, sum g*xh) pairs of one (group, channel) summed by ONE WAVE -- lane l takes the partials l, l+64, ... in order, then a
+// fixed xor butterfly -- instead of one thread looping over all of them (pf_norm_bwd_final_elem: 37 us per call at nblk ~ 220;
+// 305 us at nblk = 2048).  Same result for every run (fixed order); the elem form stays as the CPU emulation's path.
+//   mode 0: coef[(g*C + c)*2 + {0,1}] = sum / Np            (InstanceNorm backward: means)
+//   mode 1: out0[c] (+)= sum g (d beta), out1[c] (+)= sum g*xhat (d gamma); groups = 1
+__global__ void __launch_bounds__(256) pf_pair_final_wave(const double* __restrict__ part, int groups, int nblk, int C, int mode,
+                                                          double inv_np, float* __restrict__ out0, float* __restrict__ out1,
+                                                          int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (group, channel)
+    if (pair >= (long)groups * C) return;
+    const int c = (int)(pair % C);
+    const long g = pair / C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = lane; k < nblk; k += 64) {
+        const double* q = part + ((g * nblk + k) * C + c) * 2;
+        s1 += q[0]; s2 += q[1];
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+    }
+    if (lane != 0) return;
+    if (mode == 0) {
+        out0[pair * 2] = (float)(s1 * inv_np);
+        out0[pair * 2 + 1] = (float)(s2 * inv_np);
+    } else if (accumulate) {
+        out0[c] += (float)s1; out1[c] += (float)s2;
+    } else {
+        out0[c] = (float)s1; out1[c] = (float)s2;
+    }
+}
+int launch_pair_final(const double* part, int groups, int nblk, int C, int mode, int Np, float* out0, float* out1, int accumulate,
+                      void* stream) {
+    const long pairs = (long)groups * C;
+    hipLaunchKernelGGL(pf_pair_final_wave, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, part, groups, nblk, C,
+                       mode, 1.0 / (double)(Np > 0 ? Np : 1), out0, out1, accumulate);
+    return (int)hipGetLastError();
+}
+
 // ResidualBlock tail, 16-byte accesses (same arithmetic as pf_norm_act_elem)
 __global__ void __launch_bounds__(256) pf_norm_act_vec(const PfNormActArgs a, const long total) {
     const int c4n = a.C / 4;
@@ -908,6 +949,7 @@ static int pf_lookup_dispatch(const PfLookupArgs& a, long total, void* stream) {
 #define PF_NORM_ACT_LAUNCH(a, total, stream) launch_norm_act(a, total, stream)
 #define PF_STATS_LAUNCH launch_stats
 #define PF_STATS_FINAL_LAUNCH launch_stats_final
+#define PF_PAIR_FINAL_LAUNCH launch_pair_final
 #define PF_LAUNCH(name, args, total, stream) \
     pf_launch_elem<decltype(args), pf_##name##_elem>(args, total, stream)
 

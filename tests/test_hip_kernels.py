@@ -774,3 +774,27 @@ def test_unpack_wgrads_adds_packed_gradients_into_parameter_layout(lib):
             assert torch.allclose(gb, ref_b, rtol=2e-7, atol=1e-7)
     with pytest.raises(PfError):
         lib.unpack_wgrads([(jobs[0][0], jobs[0][1], jobs[1][2], jobs[0][3], 64, 3, 49, 32, 0, 1.0)])      # gw of another shape
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_frozen_batchnorm_act_matches_torch_autograd(relu):
+    """autograd.HipFrozenBnAct (pf_bn_frozen_fwd / pf_bn_frozen_bwd: the context encoder's BatchNorm with frozen statistics + ReLU,
+    core/extractor.py:114-115, train_flow.py:107-108) against torch's F.batch_norm(training=False) [+ relu] and its autograd: output,
+    dx, d gamma, d beta to 1e-5 of their scale; channel counts of the three encoder stages, odd row count."""
+    import torch.nn.functional as F
+    from prior_flow_amd.autograd import HipFrozenBnAct
+    gen = torch.Generator().manual_seed(17)
+    for Cc, (Bn, Hh, Ww) in ((64, (2, 9, 21)), (96, (1, 12, 16)), (128, (3, 6, 8))):
+        x = torch.randn(Bn, Cc, Hh, Ww, generator=gen).cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        gamma = (torch.rand(Cc, generator=gen) + 0.5).cuda().requires_grad_()
+        beta = (torch.randn(Cc, generator=gen) * 0.3).cuda().requires_grad_()
+        mean = (torch.randn(Cc, generator=gen) * 0.2).cuda()
+        var = (torch.rand(Cc, generator=gen) + 0.3).cuda()
+        g = torch.randn(Bn, Cc, Hh, Ww, generator=gen).cuda()
+        ref = F.batch_norm(x, mean, var, gamma, beta, False, 0.1, 1e-5)
+        ref = torch.relu(ref) if relu else ref
+        rdx, rdg, rdb = torch.autograd.grad(ref, (x, gamma, beta), g)
+        out = HipFrozenBnAct.apply(x, gamma, beta, mean, var, 1e-5, relu)
+        dx, dg, db = torch.autograd.grad(out, (x, gamma, beta), g)
+        for a, b in ((out, ref), (dx, rdx), (dg, rdg), (db, rdb)):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), (Cc, relu)
