@@ -492,6 +492,15 @@ int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const float* x1,
 int pf_conv2d_wgrad_small(const float* x, int nchw, int ld_in, int off_in, int cin,
                           const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
                           int kh, int kw, int stride, int B, int Hout, int Wout, void* stream);
+/* The same through a caller-provided workspace (pf_conv2d_wgrad_small_ws_floats(...) floats, no initialisation needed; private to
+ * the call until it has finished): every workgroup stores its partial sums there and a second launch adds them with 8 atomics per
+ * weight.  The form above ends with one atomic per weight per workgroup on the same few hundred cache lines, which was most of its
+ * time (414 -> see DESIGN.md section 7 us for the encoder stem at 384x512). */
+long pf_conv2d_wgrad_small_ws_floats(int cin, int cout, int kh, int kw, int B, int Hout, int Wout);
+int pf_conv2d_wgrad_small_ws(const float* x, int nchw, int ld_in, int off_in, int cin,
+                             const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
+                             int kh, int kw, int stride, int B, int Hout, int Wout,
+                             float* workspace, long workspace_floats, void* stream);
 
 /* channel-last slice -> NCHW. */
 int pf_to_nchw(const float* in, int ld_in, int off_in, int c, float* out, int B, int N,

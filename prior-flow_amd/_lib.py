@@ -117,6 +117,8 @@ _SIGNATURES = {
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
     "pf_conv2d_wgrad_small": [_fp, _i, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp],
+    "pf_conv2d_wgrad_small_ws": [_fp, _i, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, C.c_long, _fp],
+    "pf_conv2d_wgrad_small_ws_floats": [_i, _i, _i, _i, _i, _i, _i],
     "pf_to_nchw": [_fp, _i, _i, _i, _fp, _i, _i, _fp],
     "pf_warp_gcorr_bwd": [_fp, _fp, _fp, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow_bwd": [_fp, _fp, _i, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
@@ -183,7 +185,7 @@ class PfLib:
                     continue
                 raise PfError(f"{path} does not export {name}")
             fn.argtypes = args
-            fn.restype = _i
+            fn.restype = C.c_long if name.endswith("_ws_floats") else _i
 
     # ---- helpers -----------------------------------------------------------------------------
     def version(self) -> str:
@@ -460,9 +462,12 @@ class PfLib:
     def conv2d_wgrad_small(self, x, nchw, off_in, cin, dy, off_dy, cout, dw, db, kh, kw, stride, B, Hout, Wout):
         """dw [Cout,Cin,KH,KW] (+= ), db [Cout] (+= or None) of a small-Cin convolution; x NCHW planes or channel-last."""
         self._chk(x, dy, dw, db)
-        self._rc(self._dll.pf_conv2d_wgrad_small(_ptr(x), int(nchw), 0 if nchw else x.shape[-1], off_in, cin,
-                                                 _ptr(dy), dy.shape[-1], off_dy, cout, _ptr(dw), _ptr(db),
-                                                 kh, kw, stride, B, Hout, Wout, self._stream(x)), "pf_conv2d_wgrad_small")
+        n = int(self._dll.pf_conv2d_wgrad_small_ws_floats(cin, cout, kh, kw, B, Hout, Wout))
+        ws = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)      # per call: two streams may run stems side by side
+        self._rc(self._dll.pf_conv2d_wgrad_small_ws(_ptr(x), int(nchw), 0 if nchw else x.shape[-1], off_in, cin,
+                                                    _ptr(dy), dy.shape[-1], off_dy, cout, _ptr(dw), _ptr(db),
+                                                    kh, kw, stride, B, Hout, Wout, _ptr(ws), n, self._stream(x)),
+                 "pf_conv2d_wgrad_small_ws")
 
     def channel_stats(self, y, B, Np, Cch, scale, shift, partials, nblk, eps=1e-5):
         self._chk(y, scale, shift)

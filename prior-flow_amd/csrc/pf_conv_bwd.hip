@@ -267,8 +267,9 @@ struct WgradSmallArgs {
     const float* dy; int ld_dy, off_dy, cout;
     float* dw; float* db;
     int B, Ho, Wo, kh, kw, stride;
+    float* ws;              // optional: per-workgroup partial sums [gridDim.y][gridDim.x][taps*cin + 1][64] (two-stage reduction)
 };
-constexpr int WS_T = 8, WS_MAXTAPS = 13, WS_MAXC = 4;
+constexpr int WS_T = 8, WS_MAXTAPS = 13, WS_MAXC = 4, WS_SLICES = 8;
 
 template <int CIN>
 __global__ void __launch_bounds__(256) pf_wgrad_small_kernel(const WgradSmallArgs a) {
@@ -333,6 +334,20 @@ __global__ void __launch_bounds__(256) pf_wgrad_small_kernel(const WgradSmallArg
                 for (int c = 0; c < CIN; ++c) acc[j][c] = __builtin_fmaf(g, xv[j][c], acc[j][c]);
         }
     }
+    if (a.ws != nullptr) {
+        // two-stage: this workgroup's sums go to its own slice of the workspace (64 consecutive floats per (tap, channel):
+        // coalesced), pf_wgrad_small_reduce adds the slices -- 8 atomics per weight instead of one per workgroup
+        float* const w = a.ws + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (taps * CIN + 1) * 64;
+#pragma unroll
+        for (int j = 0; j < WS_MAXTAPS; ++j) {
+            const int tap = tg + 4 * j;
+            if (tap < taps)
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) w[(tap * CIN + c) * 64 + o] = acc[j][c];
+        }
+        if (tg == 0) w[taps * CIN * 64 + o] = bsum;
+        return;
+    }
     if (o0 + o < a.cout) {
 #pragma unroll
         for (int j = 0; j < WS_MAXTAPS; ++j) {
@@ -345,11 +360,71 @@ __global__ void __launch_bounds__(256) pf_wgrad_small_kernel(const WgradSmallArg
     }
 }
 
+// Second stage of the workspace form: thread (slot, o) of column block y adds the partial sums of one slice of the workgroups
+// (in order) and hands the result to dW / db with one atomic -- WS_SLICES atomics per weight.  The one-stage form ended with one
+// atomic per weight PER WORKGROUP on the same 9 408 addresses (294 cache lines): 414 us per encoder stem, most of it that.
+__global__ void __launch_bounds__(256) pf_wgrad_small_reduce(const float* __restrict__ ws, int nwg, int ny, int taps, int cin,
+                                                             int cout, float* __restrict__ dw, float* __restrict__ db) {
+    const int slots = taps * cin + 1;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)ny * slots * 64) return;
+    const int o = (int)(idx & 63);
+    const int slot = (int)((idx >> 6) % slots);
+    const int y = (int)((idx >> 6) / slots);
+    if (y * 64 + o >= cout) return;
+    const int per = (nwg + WS_SLICES - 1) / WS_SLICES;
+    const int w0 = blockIdx.y * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
+    float sum = 0.f;
+    const float* q = ws + (((long)y * nwg + w0) * slots + slot) * 64 + o;
+    int w = w0;
+    for (; w + 4 <= w1; w += 4) {
+        const float v0 = q[0], v1 = q[(long)slots * 64], v2 = q[(long)slots * 128], v3 = q[(long)slots * 192];
+        sum += v0; sum += v1; sum += v2; sum += v3;
+        q += (long)slots * 256;
+    }
+    for (; w < w1; ++w) { sum += q[0]; q += (long)slots * 64; }
+    if (w1 <= w0) return;
+    if (slot == slots - 1) {
+        if (db) atomicAdd(db + y * 64 + o, sum);
+    } else {
+        const int tap = slot / cin, c = slot % cin;
+        atomicAdd(dw + ((long)(y * 64 + o) * cin + c) * taps + tap, sum);
+    }
+}
+
 }  // namespace
+
+static unsigned wgrad_small_groups(int B, int Hout, int Wout) {
+    const long ntiles = (long)B * ((Hout + WS_T - 1) / WS_T) * ((Wout + WS_T - 1) / WS_T);
+    return (unsigned)(ntiles < 256 ? ntiles : 256);
+}
+
+extern "C" long pf_conv2d_wgrad_small_ws_floats(int cin, int cout, int kh, int kw, int B, int Hout, int Wout) {
+    if (cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || B <= 0 || Hout <= 0 || Wout <= 0) return 0;
+    return (long)wgrad_small_groups(B, Hout, Wout) * ((cout + 63) / 64) * ((long)kh * kw * cin + 1) * 64;
+}
+
+static int wgrad_small_impl(const float* x, int nchw, int ld_in, int off_in, int cin,
+                            const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
+                            int kh, int kw, int stride, int B, int Hout, int Wout, float* ws, void* stream);
 
 extern "C" int pf_conv2d_wgrad_small(const float* x, int nchw, int ld_in, int off_in, int cin,
                                      const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
                                      int kh, int kw, int stride, int B, int Hout, int Wout, void* stream) {
+    return wgrad_small_impl(x, nchw, ld_in, off_in, cin, dy, ld_dy, off_dy, cout, dw, db, kh, kw, stride, B, Hout, Wout, nullptr, stream);
+}
+
+extern "C" int pf_conv2d_wgrad_small_ws(const float* x, int nchw, int ld_in, int off_in, int cin,
+                                        const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
+                                        int kh, int kw, int stride, int B, int Hout, int Wout,
+                                        float* workspace, long workspace_floats, void* stream) {
+    if (!workspace || workspace_floats < pf_conv2d_wgrad_small_ws_floats(cin, cout, kh, kw, B, Hout, Wout)) return PF_ERR_BAD_ARG;
+    return wgrad_small_impl(x, nchw, ld_in, off_in, cin, dy, ld_dy, off_dy, cout, dw, db, kh, kw, stride, B, Hout, Wout, workspace, stream);
+}
+
+static int wgrad_small_impl(const float* x, int nchw, int ld_in, int off_in, int cin,
+                            const float* dy, int ld_dy, int off_dy, int cout, float* dw, float* db,
+                            int kh, int kw, int stride, int B, int Hout, int Wout, float* ws, void* stream) {
     if (!x || !dy || !dw) return PF_ERR_BAD_ARG;
     if (B <= 0 || Hout <= 0 || Wout <= 0 || cin <= 0 || cin > WS_MAXC || cout <= 0) return PF_ERR_BAD_SHAPE;
     if (kh < 1 || kw < 1 || kh * kw > 4 * WS_MAXTAPS || (stride != 1 && stride != 2)) return PF_ERR_BAD_SHAPE;
@@ -358,18 +433,22 @@ extern "C" int pf_conv2d_wgrad_small(const float* x, int nchw, int ld_in, int of
     WgradSmallArgs a;
     a.x = x; a.nchw = nchw; a.ld_in = ld_in; a.off_in = off_in; a.cin = cin;
     a.dy = dy; a.ld_dy = ld_dy; a.off_dy = off_dy; a.cout = cout; a.dw = dw; a.db = db;
-    a.B = B; a.Ho = Hout; a.Wo = Wout; a.kh = kh; a.kw = kw; a.stride = stride;
+    a.B = B; a.Ho = Hout; a.Wo = Wout; a.kh = kh; a.kw = kw; a.stride = stride; a.ws = ws;
     const int PW = (WS_T - 1) * stride + kw, PH = (WS_T - 1) * stride + kh;
     const size_t lds = (size_t)(64 * 64 + PH * PW * cin) * sizeof(float);
-    const long ntiles = (long)B * ((Hout + WS_T - 1) / WS_T) * ((Wout + WS_T - 1) / WS_T);
     // every workgroup ends with one atomic per weight on the SAME Cout*Cin*taps addresses: 1 024 workgroups on the encoder stem
     // (9 408 addresses) spent ~0.8 of its 0.9 ms in that contention -- one workgroup per CU walks more tiles instead
-    dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), (unsigned)((cout + 63) / 64));
+    dim3 grid(wgrad_small_groups(B, Hout, Wout), (unsigned)((cout + 63) / 64));
     switch (cin) {
         case 1: hipLaunchKernelGGL(pf_wgrad_small_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
         case 2: hipLaunchKernelGGL(pf_wgrad_small_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
         case 3: hipLaunchKernelGGL(pf_wgrad_small_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
         default: hipLaunchKernelGGL(pf_wgrad_small_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
+    }
+    if (ws != nullptr) {
+        const long total = (long)grid.y * (kh * kw * cin + 1) * 64;
+        hipLaunchKernelGGL(pf_wgrad_small_reduce, dim3((unsigned)((total + 255) / 256), WS_SLICES), dim3(256), 0, (hipStream_t)stream,
+                           ws, (int)grid.x, (int)grid.y, kh * kw, cin, cout, dw, db);
     }
     return (int)hipGetLastError();
 }

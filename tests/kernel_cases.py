@@ -718,9 +718,71 @@ def case_pack_conv_weights(lib, dev):
             assert float(got_b.abs().max()) == 0.0
 
 
+def case_unpack_wgrads(lib, dev):
+    """pf_unpack_wgrads (training: packed dW / db of many convolutions -> the parameters' .grad tensors, 16 jobs per launch) against
+    the torch expression it replaces (slice, permute, scale, +=): 19 jobs so the second launch is exercised, with a fused two-module
+    job (o_off) and a bias-less one.  One multiply-add per element on both sides: 1 ulp of the result allowed (fma or not)."""
+    from prior_flow_amd._lib import PfError
+    gen = torch.Generator().manual_seed(3)
+    jobs, want = [], []
+    shapes = [(64, 3, 7, 7), (128, 384, 1, 5), (2, 256, 3, 3), (576, 256, 1, 1), (128, 272, 3, 3)] * 4
+    for i, (cout, cin, kh, kw) in enumerate(shapes[:19]):
+        o_off = 128 if i % 5 == 1 else 0
+        op = (o_off + cout + 127) // 128 * 128
+        cin_pad = (cin + 31) // 32 * 32
+        dw = torch.randn(op, kh * kw, cin_pad, generator=gen).to(dev)
+        db = torch.randn(op, generator=gen).to(dev)
+        gw = torch.randn(cout, cin, kh, kw, generator=gen).to(dev)
+        gb = None if i == 3 else torch.randn(cout, generator=gen).to(dev)
+        scale = 0.25 if i % 4 == 0 else 1.0
+        ref_w = gw + scale * dw[o_off:o_off + cout, :, :cin].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
+        ref_b = None if gb is None else gb + scale * db[o_off:o_off + cout]
+        jobs.append((dw, db if gb is not None else None, gw, gb, cout, cin, kh * kw, cin_pad, o_off, scale))
+        want.append((ref_w, ref_b))
+    lib.unpack_wgrads(jobs)
+    for (dw, db, gw, gb, *_), (ref_w, ref_b) in zip(jobs, want):
+        assert torch.allclose(gw, ref_w, rtol=2e-7, atol=1e-7)
+        if gb is not None:
+            assert torch.allclose(gb, ref_b, rtol=2e-7, atol=1e-7)
+    try:
+        lib.unpack_wgrads([(jobs[0][0], jobs[0][1], jobs[1][2], jobs[0][3], 64, 3, 49, 32, 0, 1.0)])      # gw of another shape
+    except PfError:
+        pass
+    else:
+        raise AssertionError("a gradient tensor of the wrong shape was accepted")
+
+
+def case_frozen_batchnorm(lib, dev):
+    """pf_bn_frozen_fwd / pf_bn_frozen_bwd (the context encoder's BatchNorm with frozen statistics [+ ReLU], core/extractor.py:
+    114-115, train_flow.py:107-108) against torch's F.batch_norm(training=False) [+ relu] and its autograd: output, dx, d gamma,
+    d beta to 1e-5 of their scale; the three encoder widths, an odd row count; accumulate on and off."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(17)
+    for relu in (True, False):
+        for Cc, (Bn, Hh, Ww) in ((64, (2, 9, 21)), (96, (1, 12, 16)), (128, (3, 6, 8))):
+            x = torch.randn(Bn, Cc, Hh, Ww, generator=gen).to(dev).requires_grad_()
+            gamma = (torch.rand(Cc, generator=gen) + 0.5).to(dev).requires_grad_()
+            beta = (torch.randn(Cc, generator=gen) * 0.3).to(dev).requires_grad_()
+            mean = (torch.randn(Cc, generator=gen) * 0.2).to(dev)
+            var = (torch.rand(Cc, generator=gen) + 0.3).to(dev)
+            g = torch.randn(Bn, Cc, Hh, Ww, generator=gen).to(dev)
+            ref = F.batch_norm(x, mean, var, gamma, beta, False, 0.1, 1e-5)
+            ref = torch.relu(ref) if relu else ref
+            rdx, rdg, rdb = torch.autograd.grad(ref, (x, gamma, beta), g)
+            rows = lambda t: t.detach().permute(0, 2, 3, 1).reshape(-1, Cc).contiguous()      # noqa: E731
+            xr, gr = rows(x), rows(g)
+            out = lib.bn_frozen_fwd(xr, gamma.detach(), beta.detach(), mean, var, 1e-5, relu, torch.empty_like(xr))
+            dx, dg, db = torch.empty_like(xr), torch.full((Cc,), 2.0, device=dev), torch.full((Cc,), -1.0, device=dev)
+            lib.bn_frozen_bwd(gr, xr, gamma.detach(), beta.detach(), mean, var, 1e-5, relu, dx, dg, db, True)
+            for a, b in ((out, rows(ref)), (dx, rows(rdx)), (dg - 2.0, rdg), (db + 1.0, rdb)):
+                assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), (Cc, relu)
+            lib.bn_frozen_bwd(gr, xr, gamma.detach(), beta.detach(), mean, var, 1e-5, relu, dx, dg, db, False)
+            assert float((dg - rdg).abs().max()) <= 1e-5 * max(1.0, float(rdg.abs().max()))
+
+
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_normalise_images, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_motion_prep, case_conf_stem, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16, case_pack_conv_weights,
                      case_flow_metrics, case_training_pieces, case_dccl_backward, case_upsample_backward,
-                     case_warp_gcorr_backward, case_gru_gate_backward, case_norm_backward,
-                     case_bad_args]
+                     case_warp_gcorr_backward, case_gru_gate_backward, case_norm_backward, case_unpack_wgrads,
+                     case_frozen_batchnorm, case_bad_args]

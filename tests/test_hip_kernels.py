@@ -744,38 +744,6 @@ def test_enc_stem_matches_conv2d(lib, dev, shape):
     assert torch.equal(tw2, tw)
 
 
-def test_unpack_wgrads_adds_packed_gradients_into_parameter_layout(lib):
-    """pf_unpack_wgrads (training: packed dW / db of many convolutions -> the parameters' .grad tensors, 16 jobs per launch) against
-    the torch expression it replaces (slice, permute, scale, +=), 19 jobs so the second launch is exercised, with a fused
-    two-module job (o_off) and a bias-less one.  Bit-exact: one fused multiply-add per element on both sides is not guaranteed, so
-    the comparison allows 1 ulp of the result."""
-    from prior_flow_amd._lib import PfError
-    gen = torch.Generator().manual_seed(3)
-    jobs, want = [], []
-    shapes = [(64, 3, 7, 7), (128, 384, 1, 5), (2, 256, 3, 3), (576, 256, 1, 1), (128, 272, 3, 3)] * 4
-    for i, (cout, cin, kh, kw) in enumerate(shapes[:19]):
-        o_off = 128 if i % 5 == 1 else 0
-        op = (o_off + cout + 127) // 128 * 128
-        cin_pad = (cin + 31) // 32 * 32
-        dw = torch.randn(op, kh * kw, cin_pad, generator=gen).cuda()
-        db = torch.randn(op, generator=gen).cuda()
-        gw = torch.randn(cout, cin, kh, kw, generator=gen).cuda()
-        gb = None if i == 3 else torch.randn(cout, generator=gen).cuda()
-        scale = 0.25 if i % 4 == 0 else 1.0
-        ref_w = gw + scale * dw[o_off:o_off + cout, :, :cin].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
-        ref_b = None if gb is None else gb + scale * db[o_off:o_off + cout]
-        jobs.append((dw, db if gb is not None else None, gw, gb, cout, cin, kh * kw, cin_pad, o_off, scale))
-        want.append((ref_w, ref_b))
-    lib.unpack_wgrads(jobs)
-    torch.cuda.synchronize()
-    for (dw, db, gw, gb, *_), (ref_w, ref_b) in zip(jobs, want):
-        assert torch.allclose(gw, ref_w, rtol=2e-7, atol=1e-7)
-        if gb is not None:
-            assert torch.allclose(gb, ref_b, rtol=2e-7, atol=1e-7)
-    with pytest.raises(PfError):
-        lib.unpack_wgrads([(jobs[0][0], jobs[0][1], jobs[1][2], jobs[0][3], 64, 3, 49, 32, 0, 1.0)])      # gw of another shape
-
-
 @pytest.mark.parametrize("relu", [True, False])
 def test_frozen_batchnorm_act_matches_torch_autograd(relu):
     """autograd.HipFrozenBnAct (pf_bn_frozen_fwd / pf_bn_frozen_bwd: the context encoder's BatchNorm with frozen statistics + ReLU,
@@ -796,5 +764,5 @@ def test_frozen_batchnorm_act_matches_torch_autograd(relu):
         rdx, rdg, rdb = torch.autograd.grad(ref, (x, gamma, beta), g)
         out = HipFrozenBnAct.apply(x, gamma, beta, mean, var, 1e-5, relu)
         dx, dg, db = torch.autograd.grad(out, (x, gamma, beta), g)
-        for a, b in ((out, ref), (dx, rdx), (dg, rdg), (db, rdb)):
+        for a, b in ((out.detach(), ref.detach()), (dx, rdx), (dg, rdg), (db, rdb)):
             assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), (Cc, relu)
