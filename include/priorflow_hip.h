@@ -104,6 +104,12 @@ int pf_unpack_wgrads(const pf_unpack_job* jobs, int n, void* stream);
 int pf_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, const float* b0, const float* b1,
                          int cin, int kh, int kw, int mode, int cin_rot, void* dst_w, float* dst_b,
                          int cout_pad, int cin_pad, void* stream);
+/* Several of them per launch (16 jobs each; the arguments of pf_pack_conv_weights as a struct). */
+typedef struct pf_pack_job {
+    const float* w0; const float* w1; const float* b0; const float* b1; void* dst_w; float* dst_b;
+    int cout0, cout1, cin, kh, kw, mode, cin_rot, cout_pad, cin_pad;
+} pf_pack_job;
+int pf_pack_conv_weights_batch(const pf_pack_job* jobs, int n, void* stream);
 
 /* DCCL.__call__ steps 1-2 (core/corr.py:119-137): own-view 9x9x4 lookup and the raw
  * cross-view lookup through g_w2c.  coords: planar.  own_out/raw_out: channel-last, 324

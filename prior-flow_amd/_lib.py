@@ -41,6 +41,13 @@ class UnpackJob(C.Structure):
                 ("cout", _i), ("cin", _i), ("taps", _i), ("cin_pad", _i), ("o_off", _i), ("scale", C.c_float)]
 
 
+class PackJob(C.Structure):
+    """Mirror of ``pf_pack_job`` (include/priorflow_hip.h)."""
+    _fields_ = [("w0", _fp), ("w1", _fp), ("b0", _fp), ("b1", _fp), ("dst_w", _fp), ("dst_b", _fp),
+                ("cout0", _i), ("cout1", _i), ("cin", _i), ("kh", _i), ("kw", _i), ("mode", _i), ("cin_rot", _i),
+                ("cout_pad", _i), ("cin_pad", _i)]
+
+
 class ConvDesc(C.Structure):
     """Mirror of ``pf_conv_desc`` (include/priorflow_hip.h)."""
     _fields_ = [
@@ -91,6 +98,7 @@ _SIGNATURES = {
     "pf_gru_dx_finish": [_fp, _i, _fp, _i, _fp, _i, _fp, _i, _fp, _i, C.c_long, _i, _i, _fp],
     "pf_pack_conv_weights": [_fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _fp],
     "pf_unpack_wgrads": [C.POINTER(UnpackJob), _i, _fp],
+    "pf_pack_conv_weights_batch": [C.POINTER(PackJob), _i, _fp],
     "pf_bn_frozen_fwd": [_fp, _fp, _fp, _fp, _fp, C.c_float, _i, _fp, C.c_long, _i, _fp],
     "pf_bn_frozen_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, C.c_float, _i, _fp, _i, _fp, _fp, _fp, _i, C.c_long, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
@@ -176,6 +184,7 @@ class PfLib:
         self._dll = C.CDLL(path)
         self._dll.pf_version.restype = C.c_char_p
         self.missing = []
+        self.pack_queue = None
         for name, args in _SIGNATURES.items():
             try:
                 fn = getattr(self._dll, name)
@@ -311,10 +320,36 @@ class PfLib:
         cp = (ic + 31) // 32 * 32
         dst_w = torch.empty(op, kh * kw, cp // 32, 2, 32, dtype=torch.bfloat16, device=w0.device)
         dst_b = torch.empty(op, dtype=torch.float32, device=w0.device)
+        if self.pack_queue is not None:         # inside ``batched_packs()``: launched together when the block ends
+            self.pack_queue.append((w0, w1, b0, b1, dst_w, dst_b, cout0, cout1, cin, kh, kw, mode, cin_rot, op, cp))
+            return dst_w, dst_b
         self._rc(self._dll.pf_pack_conv_weights(_ptr(w0), cout0, _ptr(w1), cout1, _ptr(b0), _ptr(b1), cin, kh, kw, mode, cin_rot,
                                                 C.c_void_p(dst_w.data_ptr()), _ptr(dst_b), op, cp, self._stream(w0)),
                  "pf_pack_conv_weights")
         return dst_w, dst_b
+
+    def batched_packs(self):
+        """Context: every ``pack_conv_weights`` inside returns its (still unwritten) destination tensors at once and the packs run
+        as ceil(n / 16) launches of pf_pack_conv_weights_batch when the block ends -- before anything may read them."""
+        lib = self
+
+        class _Batch:
+            def __enter__(self):
+                self.outer = lib.pack_queue
+                lib.pack_queue = []
+                return self
+
+            def __exit__(self, *exc):
+                jobs, lib.pack_queue = lib.pack_queue, self.outer
+                if exc[0] is None and jobs:
+                    arr = (PackJob * len(jobs))()
+                    for q, (w0, w1, b0, b1, dw, db, c0, c1, cin, kh, kw, mode, rot, op, cp) in zip(arr, jobs):
+                        q.w0, q.w1, q.b0, q.b1 = _ptr(w0), _ptr(w1), _ptr(b0), _ptr(b1)
+                        q.dst_w, q.dst_b = C.c_void_p(dw.data_ptr()), _ptr(db)
+                        q.cout0, q.cout1, q.cin, q.kh, q.kw, q.mode, q.cin_rot, q.cout_pad, q.cin_pad = c0, c1, cin, kh, kw, mode, rot, op, cp
+                    lib._rc(lib._dll.pf_pack_conv_weights_batch(arr, len(jobs), lib._stream(jobs[0][0])), "pf_pack_conv_weights_batch")
+                return False
+        return _Batch()
 
     def unpack_wgrads(self, jobs):
         """jobs: [(dw, db, gw, gb | None, cout, cin, taps, cin_pad, o_off, scale)]: gw += scale * unpacked(dw), gb += scale * db."""

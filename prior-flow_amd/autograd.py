@@ -929,8 +929,20 @@ class _NullCtx:
         return False
 
 
+def _prepack_encoders(lib, *encoders):
+    """Forward and data-gradient operands of every MFMA convolution of the encoders, packed together (ceil(n / 16) launches
+    instead of one per operand in front of its first use); conv2d() / the backward nodes then find them in the pack cache."""
+    with lib.batched_packs():
+        for enc in encoders:
+            for m in enc.modules():
+                if isinstance(m, nn.Conv2d) and m.weight.shape[1] % 4 == 0 and m.bias is not None:
+                    _pack(m.weight, m.bias, "fwd")
+                    _pack(m.weight, None, "dgrad")
+
+
 def _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a_8, iters, init_flow):
     import os
+    _prepack_encoders(lib, model.cnet, model.fnet)
     side = None
     if os.environ.get("PRIORFLOW_TRAIN_FORK", "1") != "0":
         # cnet beside fnet on a side stream (round 4): at the training crop an encoder launch fills a fraction of the chip, and

@@ -955,6 +955,20 @@ PF_HD void pf_pack_conv_weights_elem(long idx, const PfPackWArgs& a) {
     d[32] = pf_bf16_rne(v - pf_bf16_to_f32(hi));
 }
 
+// Several pf_pack_conv_weights problems in one launch (a training step re-packs ~115 operands after every optimizer step):
+// job j owns the indices [start[j], start[j+1]).
+#define PF_PACK_MAX_JOBS 16
+struct PfPackBatchArgs {
+    PfPackWArgs job[PF_PACK_MAX_JOBS];
+    long start[PF_PACK_MAX_JOBS + 1];
+    int n;
+};
+PF_HD void pf_pack_conv_weights_batch_elem(long idx, const PfPackBatchArgs& a) {
+    int j = 0;
+    while (j + 1 < a.n && idx >= a.start[j + 1]) ++j;
+    pf_pack_conv_weights_elem(idx - a.start[j], a.job[j]);
+}
+
 // ----------------------------------------------------------------------------------------------
 // Training: packed weight / bias gradients -> the parameters' own gradient tensors, several convolutions per launch.
 //   gw[o][c][tap] += scale * dw[o_off + o][tap][c]      gb[o] += scale * db[o_off + o]

@@ -118,19 +118,20 @@ class _Packs:
             named[t + ".q1"], named[t + ".q2"] = blk.gru.convq1, blk.gru.convq2
             named[t + ".fh1"], named[t + ".fh2"] = blk.flow_head.conv1, blk.flow_head.conv2
             named[t + ".m0"], named[t + ".m2"] = blk.mask[0], blk.mask[2]
-        for name, m in named.items():
-            self.mods[name] = m
-            self.fwd[name] = _pack(m.weight, m.bias, "fwd")
-            self.dg[name] = _pack(m.weight, None, "dgrad")
-            self.acc[name] = gate_of(m)[1]
-        # fused z|r convolutions: forward pack of the concatenated weights; the data gradient with its OUTPUT channels
-        # reordered [x 256 | h 128] (so that d x and d h land next to each other in the half-step's scratch rows)
-        for t, zr in (("a", zr_a), ("b", zr_b)):
-            for k in "12":
-                _w, _b, src, _tok, acc, (cz, cr) = zr[k]
-                self.fwd[f"{t}.zr{k}"] = _pack(cz.weight, cz.bias, "fwd", src, w1=cr.weight, b1=cr.bias)
-                self.dg[f"{t}.zr{k}"] = _pack(cz.weight, None, "dgrad", src, w1=cr.weight, rot=128)
-                self.acc[f"{t}.zr{k}"] = acc
+        with _lib.load().batched_packs():          # ~54 operands: 4 launches
+            for name, m in named.items():
+                self.mods[name] = m
+                self.fwd[name] = _pack(m.weight, m.bias, "fwd")
+                self.dg[name] = _pack(m.weight, None, "dgrad")
+                self.acc[name] = gate_of(m)[1]
+            # fused z|r convolutions: forward pack of the concatenated weights; the data gradient with its OUTPUT channels
+            # reordered [x 256 | h 128] (so that d x and d h land next to each other in the half-step's scratch rows)
+            for t, zr in (("a", zr_a), ("b", zr_b)):
+                for k in "12":
+                    _w, _b, src, _tok, acc, (cz, cr) = zr[k]
+                    self.fwd[f"{t}.zr{k}"] = _pack(cz.weight, cz.bias, "fwd", src, w1=cr.weight, b1=cr.bias)
+                    self.dg[f"{t}.zr{k}"] = _pack(cz.weight, None, "dgrad", src, w1=cr.weight, rot=128)
+                    self.acc[f"{t}.zr{k}"] = acc
         self.stems = {"a.f1a": ea.convf1_A, "a.f1b": ea.convf1_B, "b.f1": eb.convf1}
         self.stem_w = {n: (m.weight.detach().permute(2, 3, 1, 0).reshape(-1, m.weight.shape[0]).contiguous(),
                            m.bias.detach().contiguous()) for n, m in self.stems.items()}

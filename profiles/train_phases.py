@@ -59,4 +59,15 @@ for k, (name, i) in enumerate(marks):
             cur_e = max(cur_e, e)
     busy += cur_e - cur_s
     ksum = sum(e - s for s, e in iv)
+    by = {}
+    for r in seg:
+        n = r["Kernel_Name"]
+        import re
+        m = re.search(r"pf_\w+?(_elem|_kernel|_wave|_vec\d?|_valu|_strip)?(<[^>]*>)?(?=[\(lR]|$)", n)
+        key = (m.group(0) if m and "at::native" not in n else ("torch:" + (re.search(r"(\w+Functor\w*|direct_copy|copyBuffer|threshold|clamp|reduce_kernel|CatArray|index)", n) or [n[:40]])[0]))
+        d = by.setdefault(key, [0, 0])
+        d[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); d[1] += 1
+    top = sorted(by.items(), key=lambda kv: -kv[1][0])[:7]
     print(f"{name:28s} start {(a - t0) / 1e3:9.1f} us  span {(b - a) / 1e3:9.1f} us  busy {busy / 1e3:9.1f} us  kernel sum {ksum / 1e3:9.1f} us  launches {len(seg):5d}")
+    for k2, (t, c) in top:
+        print(f"        {t / 1e3:9.1f} us  x{c:4d}  {k2[:90]}")
