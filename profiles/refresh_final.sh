@@ -34,7 +34,14 @@ PRIORFLOW_TRAIN_LOOP=0 PRIORFLOW_TRAIN_FORK=0 python profiles/time_train_step.py
 python profiles/time_train_step.py --steps 5 --batch 8 --graph 2>/dev/null | tail -1 > $O/train_step_time_batch8.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/proft -o t -- python3 profiles/time_train_step.py > $O/train_trace.log 2>&1
 cp $(find $O/proft -name "t_kernel_stats.csv" | head -1) $O/train_step_kernel_stats.csv
+python3 profiles/train_sequence.py $(find $O/proft -name "t_kernel_trace.csv" | head -1) > $O/train_sequence.txt     # launches / PyTorch kernels of one eager step
 rm -rf $O/proft
+rocprofv3 --kernel-trace --output-format csv -d $O/proftg -o t -- python3 profiles/time_train_step.py --steps 3 --warmup 1 --graph > /dev/null 2>&1
+python3 profiles/train_phases.py $(find $O/proftg -name "t_kernel_trace.csv" | head -1) > $O/train_phases.txt           # one replayed step by phase
+rm -rf $O/proftg
+for i in 1 2; do for p in 1 0; do
+  PRIORFLOW_GRAD_SINK=$p PRIORFLOW_TRAIN_BN_FUSED=$p python profiles/time_train_step.py --steps 10 --graph 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('graphed step, grad sink + fused BN = $p:', d['ms_per_step'], 'ms')"
+done; done > $O/ab_train_sink.txt
 PRIORFLOW_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_gloo2.json
 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tests/run_train_2rank.py 2>&1 | grep -E "rank|checksums" > $O/train_2rank_check.txt
 # same-box A/Bs, interleaved
@@ -45,4 +52,4 @@ done; done > $O/ab_stem.txt
 for i in 1 2; do for p in 0 1; do
   PRIORFLOW_LOOKUP_WIN=$p python bench.py --batch 32 --no-cpu-baseline --steps 4 --warmup 2 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=32 lookup_win=$p', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"
 done; done > $O/ab_lookup_win_batch32.txt
-cat $O/pytest_gpu.log; cut -c1-300 $O/bench_n1.json; head -3 $O/forward_breakdown.txt | cut -c1-200; cat $O/time_sizes.txt; cut -c1-200 $O/bench_batch32.json; cat $O/ab_stem.txt; cut -c1-250 $O/train_step_time*.json
+cat $O/pytest_gpu.log; cut -c1-300 $O/bench_n1.json; head -3 $O/forward_breakdown.txt | cut -c1-200; cat $O/time_sizes.txt; cut -c1-200 $O/bench_batch32.json; cat $O/ab_stem.txt; cut -c1-250 $O/train_step_time*.json; head -1 $O/train_sequence.txt; cat $O/ab_train_sink.txt
