@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sync-every-step", action="store_true", help="with --graph: read the loss on the host after every step (exposes the host's per-step work)")
     ap.add_argument("--graph", action="store_true", help="the step as one captured HIP graph (train.GraphedTrainStep; single rank)")
     a = ap.parse_args()
     import torch.distributed as dist
@@ -56,12 +57,17 @@ def main():
 
     graphed = tr.GraphedTrainStep(model, opt, sched, crit, iters=a.iters, clip=1.0, warmup=1) if a.graph and world == 1 else None
 
+    ap_sync = a.sync_every_step
+
     def step():
         if graphed is not None:
             loss, m = graphed(i1, i2, gt, valid)
+            # the captured step returns device tensors (overwritten by the next replay): keep a copy, read it after the timed
+            # region -- the host then prepares step k+1 (input copies, three AdamW scalars) while the GPU runs step k
+            losses.append(float(loss) if ap_sync else loss.detach().clone())
         else:
             loss, m = tr.train_step(model, opt, sched, crit, i1, i2, gt, valid, iters=a.iters, clip=1.0)
-        losses.append(float(loss))
+            losses.append(float(loss))
 
     for _ in range(a.warmup + (2 if graphed is not None else 0)):      # graphed: one eager step, the capture, one replay
         step()
@@ -87,7 +93,8 @@ def main():
                           "hip_launches_per_step": ag.STATS["hip"] // a.steps,
                           "torch_conv_launches_per_step": ag.STATS["torch"] // a.steps,
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-                          "losses": [round(x, 3) for x in losses]}))
+                          "loss_read": "every step" if (graphed is None or a.sync_every_step) else "after the timed steps",
+                          "losses": [round(float(x), 3) for x in losses]}))
     if world > 1:
         dist.destroy_process_group()
 
