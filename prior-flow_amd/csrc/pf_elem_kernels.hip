@@ -1,5 +1,6 @@
 // __global__ wrappers + C-ABI launchers of the per-element kernels (gfx950).
 // The math lives in pf_elem.h; see include/priorflow_hip.h for the ABI contract.
+#include "pf_flow_stem.h"
 #include "pf_elem.h"
 #include "pf_split.h"
 
@@ -974,7 +975,25 @@ static int pf_direct_conv_dispatch_n(const PfDirectConvArgs* ds, int n, long tot
         for (int i = n; i < 4; ++i) m.p[i] = m.p[0];
         bool valu = true;
         for (int i = 0; i < n; ++i) valu = valu && stem7x7c2_ok(m.p[i]);
-        if (valu) return launch_stem7x7c2(m, n, stream);
+        if (valu) {
+            // the 2 -> 128 flow stems of the motion encoders: MFMA form (pf_flow_stem.hip, round 4) unless switched off
+            bool mf = true;
+            for (int i = 0; i < n; ++i) mf = mf && m.p[i].Cout == 128 && m.p[i].B == m.p[0].B && m.p[i].H == m.p[0].H && m.p[i].W == m.p[0].W;
+            if (mf) {
+                PfFlowStemMulti fm;
+                for (int i = 0; i < 4; ++i) {
+                    const PfSmallConvArgs& a = m.p[i < n ? i : 0];
+                    PfFlowStemProblem& q = fm.p[i];
+                    q.in = a.in; q.ld_in = a.ld_in; q.c_in_off = a.c_in_off; q.w = a.w; q.bias = a.bias;
+                    q.out = a.out; q.ld_out = a.ld_out; q.c_out_off = a.c_out_off; q.out_split = a.out_split; q.lds_out = a.lds_out;
+                    q.relu = a.relu;
+                }
+                fm.B = m.p[0].B; fm.H = m.p[0].H; fm.W = m.p[0].W;
+                const int rc = pf_flow_stem_launch(fm, n, stream);
+                if (rc != -100) return rc;
+            }
+            return launch_stem7x7c2(m, n, stream);
+        }
         for (int i = 0; i < n; ++i)
             if (m.p[i].out_split || !m.p[i].out) return PF_ERR_BAD_SHAPE;       // the MFMA form writes fp32 rows only
         return launch_small_conv(m, n, stream);

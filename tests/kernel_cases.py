@@ -331,7 +331,10 @@ def case_direct_conv(lib, dev, params):
     x[:, 1:3] = cl(ui["flow_a"]).to(dev)
     out = torch.zeros(N, 130, device=dev)
     lib.conv2d_direct(x, 1, 2, wp.to(dev), b.to(dev), out, 2, 128, 7, 7, True, 1, H8, W8)
-    check(uncl(out[:, 2:].cpu(), 1, H8, W8), want, 2e-5, "direct 7x7")
+    # on the GPU the 2 -> 128 stems run as 3-pass bf16-split MFMAs (pf_flow_stem.hip: 5e-5 on outputs of +-10); the CPU emulation
+    # and the vector-ALU form are exact fp32
+    tol7 = 1e-4 if torch.device(dev).type == "cuda" else 2e-5
+    check(uncl(out[:, 2:].cpu(), 1, H8, W8), want, tol7, "direct 7x7")
     assert float(out[:, :2].abs().max()) == 0.0
     # the same stem for three inputs in ONE launch (pf_conv2d_direct_group): bit-identical to single launches
     x4 = torch.zeros(N, 4, device=dev)
@@ -347,7 +350,7 @@ def case_direct_conv(lib, dev, params):
         single = torch.zeros(N, 128, device=dev)
         lib.conv2d_direct(xi, off, 2, wi, bi, single, 0, 128, 7, 7, True, 1, H8, W8)
         assert torch.equal(single, outs[i]), f"direct group problem {i}"
-    check(uncl(outs[0].cpu(), 1, H8, W8), want, 2e-5, "direct 7x7 group[0]")
+    check(uncl(outs[0].cpu(), 1, H8, W8), want, tol7, "direct 7x7 group[0]")
     import pytest
     from prior_flow_amd._lib import PfError
     with pytest.raises(PfError):                          # overlapping outputs in one group are refused

@@ -429,21 +429,36 @@ def test_small_conv_partial_segments(lib, dev):
         assert float((out[:, 0] - 5.0).abs().max()) == 0.0 and float((out[:, 129] - 5.0).abs().max()) == 0.0
 
 
-def test_flow_stem_valu_kernel_partial_segments(lib, dev):
-    """16-byte aligned outputs take pf_stem7x7c2_valu (64-pixel row segments, lane = pixel): ragged widths, batch 2,
-    an input column offset and a padded input row stride, against torch conv2d (fp32, tolerance 2e-5)."""
+@pytest.mark.parametrize("cout", [128, 64])
+def test_flow_stem_kernels_partial_tiles(lib, dev, cout):
+    """The 7x7 2 -> Cout flow stems with 16-byte aligned outputs: Cout = 128 (the motion encoders' shape, core/update.py:87,173,175)
+    takes pf_flow_stem_kernel (MFMA, 4-row x 32-column tiles, 3-pass bf16 split: 1e-4 on outputs of +-10), any other multiple of 64
+    pf_stem7x7c2_valu (64-pixel row segments, lane = pixel, exact fp32: 2e-5).  Ragged widths and heights, batch 2, an input column
+    offset and a padded input row stride, against torch conv2d; the columns beside the output slice stay untouched; with a split
+    twin as the second output (what the DMA-fed 3x3 behind the stem reads) the twin decodes to the fp32 rows exactly."""
+    from prior_flow_amd.engine import split_twin
     for H8, W8 in ((17, 27), (9, 45), (6, 120), (5, 200), (64, 128)):
         x = gc.uni(f"ragv/x{W8}", (2, 2, H8, W8), -3, 3)
-        w = gc.uni("ragv/w", (128, 2, 7, 7), -0.2, 0.2)
-        b = gc.uni("ragv/b", (128,), -0.1, 0.1)
+        w = gc.uni("ragv/w", (128, 2, 7, 7), -0.2, 0.2)[:cout].contiguous()
+        b = gc.uni("ragv/b", (128,), -0.1, 0.1)[:cout].contiguous()
         want = torch.relu(torch.nn.functional.conv2d(x, w, b, padding=3))
         xin = torch.full((2 * H8 * W8, 4), 7.0, device=dev)
         xin[:, 2:4] = kc.cl(x).to(dev)
-        out = torch.full((2 * H8 * W8, 136), 5.0, device=dev)
-        lib.conv2d_direct(xin, 2, 2, w.permute(2, 3, 1, 0).reshape(49, 2, 128).contiguous().to(dev),
-                          b.to(dev), out, 4, 128, 7, 7, True, 2, H8, W8)
-        kc.check(kc.uncl(out[:, 4:132].cpu(), 2, H8, W8), want, 2e-5, f"7x7 VALU stem W8={W8}")
-        assert float((out[:, :4] - 5.0).abs().max()) == 0.0 and float((out[:, 132:] - 5.0).abs().max()) == 0.0
+        out = torch.full((2 * H8 * W8, cout + 8), 5.0, device=dev)
+        lib.conv2d_direct(xin, 2, 2, w.permute(2, 3, 1, 0).reshape(49, 2, cout).contiguous().to(dev),
+                          b.to(dev), out, 4, cout, 7, 7, True, 2, H8, W8)
+        kc.check(kc.uncl(out[:, 4:4 + cout].cpu(), 2, H8, W8), want, 1e-4 if cout == 128 else 2e-5, f"7x7 stem Cout={cout} W8={W8}")
+        assert float((out[:, :4] - 5.0).abs().max()) == 0.0 and float((out[:, 4 + cout:] - 5.0).abs().max()) == 0.0
+        # rows + twin in one launch: the same rows, and the twin is the bf16 hi | lo split of exactly those values
+        rows2 = torch.empty(2 * H8 * W8, cout, device=dev)
+        twin = split_twin(2 * H8 * W8, cout, dev)
+        wt = w.permute(2, 3, 1, 0).reshape(49, 2, cout).contiguous().to(dev)
+        lib.conv2d_direct_group([(xin, 2, wt, b.to(dev), rows2, 0, twin)], 2, cout, 7, 7, True, 2, H8, W8)
+        assert torch.equal(rows2, out[:, 4:4 + cout])
+        hi = rows2.to(torch.bfloat16)
+        lo = (rows2 - hi.float()).to(torch.bfloat16)
+        ref = torch.stack([hi.view(-1, cout // 32, 32), lo.view(-1, cout // 32, 32)], 2)
+        assert torch.equal(twin.view(torch.int16), ref.contiguous().view(torch.int16))
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
