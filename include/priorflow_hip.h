@@ -431,6 +431,11 @@ int pf_warp_gcorr_bwd(const float* f1, const float* f2, const float* coords, int
 int pf_upsample_flow_bwd(const float* coords1, const float* mask, int ld, const float* g, float* d_mask, int ld_d,
                          float* d_flow, int B, int H8, int W8, void* stream);
 
+/* ResidualBlock tail of the encoders on the training tape (core/extractor.py:47): out = relu(x + y); and the backward of any
+ * ReLU from its forward output: dx = fwd_out > 0 ? g : 0.  n floats, any layout (elementwise). */
+int pf_add_relu(const float* x, const float* y, float* out, long n, void* stream);
+int pf_relu_mask(const float* g, const float* fwd_out, float* dx, long n, void* stream);
+
 /* nn.BatchNorm2d with frozen statistics (freeze_bn, train_flow.py:107-108: the context encoder in every stage but `chairs`),
  * optionally with the ReLU behind it (core/extractor.py:41-42,144-146), on channel-last rows [rows][C], one launch:
  *   out = [relu]( x*s + t ),  s = gamma * rsqrt(var + eps),  t = beta - mean * s. */

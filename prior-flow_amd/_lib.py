@@ -99,6 +99,8 @@ _SIGNATURES = {
     "pf_pack_conv_weights": [_fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _fp],
     "pf_unpack_wgrads": [C.POINTER(UnpackJob), _i, _fp],
     "pf_pack_conv_weights_batch": [C.POINTER(PackJob), _i, _fp],
+    "pf_add_relu": [_fp, _fp, _fp, C.c_long, _fp],
+    "pf_relu_mask": [_fp, _fp, _fp, C.c_long, _fp],
     "pf_bn_frozen_fwd": [_fp, _fp, _fp, _fp, _fp, C.c_float, _i, _fp, C.c_long, _i, _fp],
     "pf_bn_frozen_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, C.c_float, _i, _fp, _i, _fp, _fp, _fp, _i, C.c_long, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
@@ -622,6 +624,22 @@ class PfLib:
         self._rc(self._dll.pf_norm_bwd(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), 0, 1, _ptr(part), nblk, _ptr(coef),
                                        _ptr(scratch), B, Np, Cc, self._stream(dy)), "pf_norm_bwd")
         return coef.view(B, Cc, 2)
+
+    def add_relu(self, x, y, out):
+        """out = relu(x + y), same-shape contiguous fp32 tensors."""
+        self._chk(x, y, out)
+        if x.numel() != y.numel() or x.numel() != out.numel():
+            raise PfError("add_relu: shapes differ")
+        self._rc(self._dll.pf_add_relu(_ptr(x), _ptr(y), _ptr(out), x.numel(), self._stream(x)), "pf_add_relu")
+        return out
+
+    def relu_mask(self, g, fwd_out, dx):
+        """dx = fwd_out > 0 ? g : 0 (the backward of a ReLU from its output)."""
+        self._chk(g, fwd_out, dx)
+        if g.numel() != fwd_out.numel() or g.numel() != dx.numel():
+            raise PfError("relu_mask: shapes differ")
+        self._rc(self._dll.pf_relu_mask(_ptr(g), _ptr(fwd_out), _ptr(dx), g.numel(), self._stream(g)), "pf_relu_mask")
+        return dx
 
     def bn_frozen_fwd(self, x, gamma, beta, mean, var, eps, relu, out):
         """out = [relu](frozen BatchNorm(x)) on channel-last rows [rows, C]."""

@@ -429,6 +429,34 @@ class HipFrozenBnAct(torch.autograd.Function):
         return _nchw(dx, B, H, W), dgamma, dbeta, None, None, None, None
 
 
+class HipAddRelu(torch.autograd.Function):
+    """relu(x + y) of a ResidualBlock (core/extractor.py:47) in one launch (pf_add_relu); backward = one pf_relu_mask, the same
+    gradient for both inputs.  Works on the storage order of its (identically laid out) inputs."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        lib = _lib.load()
+        xr, yr = _rows(x.detach()), _rows(y.detach())
+        out = torch.empty_like(xr)
+        lib.add_relu(xr, yr, out)
+        ctx.save_for_backward(out)
+        ctx.shape = x.shape
+        STATS["hip"] += 1
+        B, Cc, H, W = x.shape
+        return _nchw(out, B, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (out,) = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        dx = torch.empty_like(out)
+        lib.relu_mask(_rows(g), out, dx)
+        STATS["hip"] += 1
+        d = _nchw(dx, B, H, W)
+        return d, d
+
+
 class HipBatchNormTrain(torch.autograd.Function):
     """nn.BatchNorm2d in training mode (batch statistics; the reference's `chairs` stage leaves BatchNorm unfrozen,
     train_flow.py:107-108).  The statistics run over the whole batch, i.e. the channel-last rows [B*H*W][C] are ONE image of
@@ -804,7 +832,7 @@ def encoder_forward(enc, x: torch.Tensor) -> torch.Tensor:
             y = _norm(blk.norm2, conv2d(y, blk.conv2), relu=True)
             if blk.downsample is not None:
                 x = _norm(blk.norm3, conv2d(x, blk.downsample[0]))
-            x = torch.relu(x + y)
+            x = HipAddRelu.apply(x, y)
     x = conv2d(x, enc.conv2)
     if enc.training and enc.dropout is not None:
         x = enc.dropout(x)

@@ -607,6 +607,19 @@ PF_HD void pf_norm_bwd_apply_elem(long idx, const PfNormBwdArgs& a) {       // i
         a.dx[idx] = s * g;
     }
 }
+// ResidualBlock tail on the training tape (core/extractor.py:47): out = relu(x + y), and its backward dx = dy = (out > 0) ? g : 0
+// (one launch each; 4 consecutive floats per call).
+struct PfAddReluArgs { const float* x; const float* y; float* out; long n; };
+PF_HD void pf_add_relu_elem(long idx, const PfAddReluArgs& a) {        // idx over ceil(n / 4)
+    for (long i = idx * 4; i < idx * 4 + 4 && i < a.n; ++i) {
+        const float v = a.x[i] + a.y[i];
+        a.out[i] = v > 0.f ? v : 0.f;
+    }
+}
+PF_HD void pf_relu_mask_elem(long idx, const PfAddReluArgs& a) {       // x = g, y = the forward output, out = masked g
+    for (long i = idx * 4; i < idx * 4 + 4 && i < a.n; ++i) a.out[i] = a.y[i] > 0.f ? a.x[i] : 0.f;
+}
+
 // ----------------------------------------------------------------------------------------------
 // BatchNorm2d with frozen statistics (freeze_bn, train_flow.py:107-108; the context encoder's norm, core/extractor.py:114-115),
 // optionally with the ReLU behind it, on channel-last rows [rows][C]:

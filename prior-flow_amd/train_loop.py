@@ -74,7 +74,7 @@ class LoopBuffers:
             s["dz"] = z(N, 128)
             s["d_corr"] = z(N, 324)
             s["d_raw"] = z(N, 324)
-            s["d_flow"] = z(B, 2, H8, W8)
+            s["d_flow"] = z(iters, B, 2, H8, W8)          # accumulated into by pf_upsample_flow_bwd: one zero fill per backward
             s["own"], s["raw"] = z(N, 324), z(N, 324)
             setattr(self, t, s)
         a, b = self.a, self.b
@@ -262,6 +262,8 @@ class LoopFn(torch.autograd.Function):
         gp = {"a": g_preds[:iters], "b": g_preds[iters:]}
         pg_a, pg_b = pyr_a[2].buffers(pyr_a[0]), pyr_b[2].buffers(pyr_b[0])
         SS = (("a", A), ("b", Bb))
+        for _t, S in SS:
+            S["d_flow"].zero_()
         gh: Dict[str, Optional[torch.Tensor]] = {"a": None, "b": None}        # gradient of the hidden state an iteration hands on
         # The hidden-state chain (heads, GRU) is the only dependency between iterations; the motion encoders' data gradients, the
         # DCCL and warp backwards of iteration i hang off it and run on a side stream beside the chain of iteration i - 1.
@@ -284,9 +286,8 @@ class LoopFn(torch.autograd.Function):
                 if gp[t][i] is None:
                     S["d_mask"][i].zero_(); S["d_mh"][i].zero_(); S["d_delta"][i].zero_(); S["d_fh"][i].zero_()
                     continue
-                S["d_flow"].zero_()
-                lib.upsample_flow_bwd(S["c"][i + 1], S["mask"][i], gp[t][i].contiguous(), S["d_mask"][i], S["d_flow"])
-                lib.to_channel_last(S["d_flow"], 0, 2, S["d_delta"][i], 0)
+                lib.upsample_flow_bwd(S["c"][i + 1], S["mask"][i], gp[t][i].contiguous(), S["d_mask"][i], S["d_flow"][i])
+                lib.to_channel_last(S["d_flow"][i], 0, 2, S["d_delta"][i], 0)
                 n_launch += 3
             if live:
                 # mask = 0.25 * conv (update.py:134,157): the factor rides in the data gradient's epilogue; the weight

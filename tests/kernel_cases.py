@@ -783,9 +783,21 @@ def case_frozen_batchnorm(lib, dev):
             assert float((dg - rdg).abs().max()) <= 1e-5 * max(1.0, float(rdg.abs().max()))
 
 
+def case_add_relu(lib, dev):
+    """pf_add_relu / pf_relu_mask (the ResidualBlock tail relu(x + y) of the training tape, core/extractor.py:47, and the backward
+    of a ReLU from its output): exact against torch, a length that is not a multiple of 4."""
+    gen = torch.Generator().manual_seed(9)
+    for n in (4096, 1027):
+        x, y, g = (torch.randn(n, generator=gen).to(dev) for _ in range(3))
+        out = lib.add_relu(x, y, torch.empty_like(x))
+        assert torch.equal(out, torch.relu(x + y))
+        dx = lib.relu_mask(g, out, torch.empty_like(g))
+        assert torch.equal(dx, torch.where(out > 0, g, torch.zeros_like(g)))
+
+
 ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_normalise_images, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_motion_prep, case_conf_stem, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16, case_pack_conv_weights,
                      case_flow_metrics, case_training_pieces, case_dccl_backward, case_upsample_backward,
                      case_warp_gcorr_backward, case_gru_gate_backward, case_norm_backward, case_unpack_wgrads,
-                     case_frozen_batchnorm, case_bad_args]
+                     case_frozen_batchnorm, case_add_relu, case_bad_args]
