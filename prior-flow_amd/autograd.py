@@ -147,9 +147,15 @@ class GradSink:
 
     def flush(self):
         """Adds every registered packed gradient into its parameters' ``.grad``; ends the step."""
-        if self.active and self.jobs:
-            _lib.load().unpack_wgrads(self.jobs)
-            STATS["hip"] += (len(self.jobs) + 15) // 16
+        try:
+            if self.active and self.jobs:
+                _lib.load().unpack_wgrads(self.jobs)
+                STATS["hip"] += (len(self.jobs) + 15) // 16
+        finally:
+            self.abort()
+
+    def abort(self):
+        """Ends the step without touching the gradients (an exception is on its way out)."""
         self.jobs, self.keep, self.active = [], [], False
 
 

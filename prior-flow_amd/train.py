@@ -247,8 +247,10 @@ def train_step(model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criteri
         seeds += list(criterion.grads)
         # loss.backward(): the criterion has already produced d loss / d prediction for every prediction
         torch.autograd.backward(list(preds_a) + list(preds_b), seeds)
-    finally:
-        sink.flush()
+    except BaseException:
+        sink.abort()            # nothing half-accumulated is added to the gradients; the sink is off for whoever runs next
+        raise
+    sink.flush()
     parallel.all_reduce_sum_(optimizer.grad, group)
     norm = clip_grad_norm_(optimizer, clip)
     optimizer.step()
@@ -312,8 +314,10 @@ class GraphedTrainStep:
             loss_b, m_b = crit(preds_b, gt_b, valid_b, self.gamma, extro_info="B-", lazy=True)
             seeds += list(crit.grads)
             torch.autograd.backward(list(preds_a) + list(preds_b), seeds)
-        finally:
-            sink.flush()
+        except BaseException:
+            sink.abort()
+            raise
+        sink.flush()
         with torch.no_grad():
             opt.lib.sum_squares(opt.grad, opt._norm_part)
             norm = opt._norm_part.sum().sqrt()
