@@ -56,6 +56,19 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_get(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// Global stores of the volume.  Non-temporal by default (round 5): a plain store keeps its line in the XCD's L2, so the
+// 356 MB write stream of a launch evicts the operand rows every workgroup of the XCD re-reads (the role-split kernel:
+// 181 us with plain stores, 109 us with nt stores, same instruction stream; the tile kernel 149 -> 144 us at B = 1 and
+// 1287 -> 1062 us at B = 8).  Only for stores of whole 128-byte lines: the ring kernel's 16- / 32-byte pieces stay plain
+// (nt: 360 us instead of 155).  -DPF_CORR_PLAIN_STORES restores plain stores (profiles/ab_corr_libs.py).
+template <class V>
+__device__ __forceinline__ void vol_store(V* p, const V& v) {
+#ifdef PF_CORR_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
 #ifdef PF_ABLATE_NO_POOL_STORE
 constexpr bool PF_POOL_STORE = false;
 #else
@@ -271,7 +284,7 @@ pf_corr_kernel(const CorrArgs a) {
             for (int k = 0; k < 4; ++k) {
                 const int row = (lane >> 3) + 8 * k, piece = lane & 7;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * S0 + 4 * piece);
-                *reinterpret_cast<f32x4*>(a.lvl[0] + (row0 + row) * N + (long)(ty0 + t) * a.W + tx0 + 4 * piece) = v;
+                vol_store(reinterpret_cast<f32x4*>(a.lvl[0] + (row0 + row) * N + (long)(ty0 + t) * a.W + tx0 + 4 * piece), v);
             }
         }
         // ---- pooled levels: DPP pooling in registers, staged per query row -------------------------
@@ -319,18 +332,18 @@ pf_corr_kernel(const CorrArgs a) {
             for (int k = 0; k < 8; ++k) {          // level 1: 32 rows x (4 x 64 B)
                 const int idx = lane + 64 * k, row = idx >> 4, u = (idx >> 2) & 3, xp = idx & 3;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(st1 + row * S1 + u * 16 + 4 * xp);
-                *reinterpret_cast<f32x4*>(a.lvl[1] + (row0 + row) * N1 + (long)((ty0 >> 1) + u) * W1 + (tx0 >> 1) + 4 * xp) = v;
+                vol_store(reinterpret_cast<f32x4*>(a.lvl[1] + (row0 + row) * N1 + (long)((ty0 >> 1) + u) * W1 + (tx0 >> 1) + 4 * xp), v);
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {          // level 2: 32 rows x (2 x 32 B)
                 const int idx = lane + 64 * k, row = idx >> 2, u = (idx >> 1) & 1, xp = idx & 1;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(st2 + row * S2 + u * 8 + 4 * xp);
-                *reinterpret_cast<f32x4*>(a.lvl[2] + (row0 + row) * N2 + (long)((ty0 >> 2) + u) * W2 + (tx0 >> 2) + 4 * xp) = v;
+                vol_store(reinterpret_cast<f32x4*>(a.lvl[2] + (row0 + row) * N2 + (long)((ty0 >> 2) + u) * W2 + (tx0 >> 2) + 4 * xp), v);
             }
         }
         if (lane < 32) {                           // level 3: 32 rows x 16 B
             const f32x4 v = *reinterpret_cast<const f32x4*>(st3 + lane * S3);
-            *reinterpret_cast<f32x4*>(a.lvl[3] + (row0 + lane) * N3 + (long)(ty0 >> 3) * W3 + (tx0 >> 3)) = v;
+            vol_store(reinterpret_cast<f32x4*>(a.lvl[3] + (row0 + lane) * N3 + (long)(ty0 >> 3) * W3 + (tx0 >> 3)), v);
         }
     };
     if (a.scale_mul != 0.f) epilogue(std::true_type{}); else epilogue(std::false_type{});
@@ -508,7 +521,7 @@ pf_corr_ring_kernel(const CorrArgs a, const int ablate) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = {scaled(acc[t][4 * g]), scaled(acc[t][4 * g + 1]), scaled(acc[t][4 * g + 2]), scaled(acc[t][4 * g + 3])};
-                if (st0) *reinterpret_cast<f32x4*>(l0 + ((long)(t >> 1) * a.W + 32 * (t & 1) + 8 * g) * 4) = v;
+                if (st0) *reinterpret_cast<f32x4*>(l0 + ((long)(t >> 1) * a.W + 32 * (t & 1) + 8 * g) * 4) = v;   // plain: nt stores of 16- / 32-byte pieces take 360 us instead of 155
             }
         // ---- level 1: one whole 128-byte line per query row (register adds; operation order of F.avg_pool2d) -------
         const int ol = opaque_lane(), oli = ol & 31, olh = ol >> 5;
@@ -523,7 +536,7 @@ pf_corr_ring_kernel(const CorrArgs a, const int ablate) {
                 const f32x16& bot = acc[2 + c];
                 p1[c][g].x = pool(scaled(top[4 * g]), scaled(top[4 * g + 1]), scaled(bot[4 * g]), scaled(bot[4 * g + 1]));
                 p1[c][g].y = pool(scaled(top[4 * g + 2]), scaled(top[4 * g + 3]), scaled(bot[4 * g + 2]), scaled(bot[4 * g + 3]));
-                if (stp) *reinterpret_cast<f32x2*>(l1 + (16 * c + 4 * g) * 4) = p1[c][g];
+                if (stp) *reinterpret_cast<f32x2*>(l1 + (16 * c + 4 * g) * 4) = p1[c][g];   // plain: nt stores of 16- / 32-byte pieces take 360 us instead of 155
             }
         if (!(rp & 1)) {                             // upper row pair of a level-2 row: keep tl + tr (the first add of the pooling)
 #pragma unroll
@@ -554,7 +567,7 @@ pf_corr_ring_kernel(const CorrArgs a, const int ablate) {
         for (int k = 0; k < 32 / RPI; ++k) {
             const float* src = img2 + (qr + RPI * k) * RING_IMG2 + 4 * pc;
             const f32x4 v = {src[0], src[1], src[2], src[3]};
-            if (stp) *reinterpret_cast<f32x4*>(l2 + (long)RPI * k * N2 * 4) = v;
+            if (stp) *reinterpret_cast<f32x4*>(l2 + (long)RPI * k * N2 * 4) = v;   // plain: nt stores of 16- / 32-byte pieces take 360 us instead of 155
             // ---- level 3 from the two level-2 rows of the region ------------------------------------------------------
             float* c3 = carry3 + (qr + RPI * k) * 16 + 2 * pc;
             if (rp == 1) {
@@ -564,7 +577,7 @@ pf_corr_ring_kernel(const CorrArgs a, const int ablate) {
                 float q0 = c3[0] + v.x, q1 = c3[1] + v.z;
                 q0 = q0 + v.y; q1 = q1 + v.w;
                 const f32x2 o = {q0 * 0.25f, q1 * 0.25f};
-                if (stp) *reinterpret_cast<f32x2*>(l3 + (long)RPI * k * N3 * 4) = o;
+                if (stp) *reinterpret_cast<f32x2*>(l3 + (long)RPI * k * N3 * 4) = o;   // plain: nt stores of 16- / 32-byte pieces take 360 us instead of 155
             }
         }
     };
@@ -613,6 +626,385 @@ pf_corr_ring_kernel(const CorrArgs a, const int ablate) {
     }
     // the tail DMAs (re-reads) must land before the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ----------------------------------------------------------------------------------------------
+// Role-split kernel (round 5; fused pool, bf16x3, C = 256, W8 % 64 == 0, H8 % 8 == 0): the ring kernel's GEMM with the
+// whole store side moved to waves of their own.
+//
+// What rounds 2-4 measured on the two kernels above (profiles/r2_corr_ablation.txt): GEMM alone 80-97 us, stores alone
+// 110-120 us, together 145-152 us -- the two phases of a wave add, because a wave that stores cannot issue MFMAs, its
+// s_waitcnt vmcnt for the next operand tile also waits for its own stores, and the stores leave in bursts (43-240 per
+// wave, then nothing while the next tile is multiplied).  Here a workgroup is 8 waves with fixed roles:
+//   * waves 0-3 (one per SIMD) are MFMA waves: the ring kernel's stream -- query fragments in registers, target tiles by
+//     LDS-DMA through a 4-slot ring, counted vmcnt in front of one barrier per K-step -- and NOTHING else.  The stream is
+//     software-pipelined by hand: the fragments of a K-step's four 32 x 32 blocks ping-pong between two register sets, the
+//     barrier of K-step k + 1 stands in front of the LAST block of K-step k, so the LDS round trip of the first fragments
+//     and the DMA issue hide behind MFMAs that need nothing from memory.  After a tile's last K-step a wave dumps its 64
+//     raw accumulators into a staging image [32 queries][2 map rows x 64 columns] (16 ds_write_b128, spread over the next
+//     tile's first K-step) and never issues a global store, so its vmcnt counts DMA only;
+//   * waves 4-7 (their SIMD partners) are STORE waves: after the barrier that publishes a staging image they pull it into
+//     registers (the image is free again within one K-step), and over the eight K-steps of the NEXT tile they scale,
+//     pool and store it: per K-step 4 query rows = two level-0 stores of 4 x 256 contiguous bytes and one level-1 store
+//     of 4 whole lines.  The store stream of a CU is therefore even in time (3 stores per wave per K-step) instead of a
+//     burst per tile, every store instruction writes whole 128-byte lines, and no load ever waits behind a store's
+//     completion.  Level 2 goes through the ring kernel's wave-private image and leaves as whole lines, level 3 follows
+//     from two level-2 rows.
+// A work item is 128 query pixels x (RB map rows x 64 NCH columns) of targets, RB = 16 when H8 % 16 == 0 (512x1024:
+// 256 items of 16 tiles, one per CU), else 8.  Same products, same k order, same pooling order as the two kernels above:
+// bit-identical results (tests/test_hip_kernels.py).
+//
+// PF_RS_ABL (compile-time, timing-only diagnosis builds of profiles/; results are garbage): 1 no global stores, 2 no DMA,
+// 4 no MFMA and no fragment reads, 8 no store-wave work, 16 no staging dump, 32 no barriers, 64 MFMA waves leave at once,
+// 256 no pooled-level stores, 512 no level-0 stores, 1024 fragment reads without MFMAs
+// ----------------------------------------------------------------------------------------------
+#ifndef PF_RS_ABL
+#define PF_RS_ABL 0
+#endif
+#ifndef PF_RS_AHEAD
+#define PF_RS_AHEAD 2
+#endif
+#ifndef PF_RS_PRIO
+#define PF_RS_PRIO 0
+#endif
+constexpr int RS_SLOTS = 4;                          // divides the 8 K-steps of a tile: the slot of a K-step is a compile-time constant
+constexpr int RS_AHEAD = PF_RS_AHEAD;                // K-steps in flight (2 or 3)
+constexpr int RS_PITCH = 132;                        // floats per staging row: 2 x 64 targets + 16 bytes (conflict-free ds_write_b128)
+constexpr int RS_STAGE = 32 * RS_PITCH;              // floats per MFMA wave
+constexpr int RS_LDS = RS_SLOTS * RING_TILE + 4 * RS_STAGE * 4 + 4 * RING_STAGE * 4;
+#define RS_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <bool MUL, int NCH>
+__global__ void __launch_bounds__(512)
+pf_corr_rs_kernel(const CorrArgs a, const int RB) {
+    constexpr int ablate = PF_RS_ABL;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int RW = 64 * NCH;                     // region width (map columns)
+    const int NT = (RB >> 1) * NCH;                  // tiles of a work item
+
+    // ---- work mapping: XCD-contiguous ranges of q = ((batch * regions + region) * m_tiles + m) ----------------------
+    int b, m0, ty0, tx0;
+    {
+        const unsigned nwg = gridDim.x, orig = blockIdx.x;
+        const unsigned xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
+        const unsigned q = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+        const unsigned rpb = (unsigned)a.W / RW;                       // regions per band
+        const unsigned regions = (unsigned)(a.H / RB) * rpb;
+        const unsigned bg = q / (unsigned)a.m_tiles;
+        m0 = (int)(q % (unsigned)a.m_tiles) * BM;
+        b = (int)(bg / regions);
+        const unsigned reg = bg % regions;
+        ty0 = (int)(reg / rpb) * RB;
+        tx0 = (int)(reg % rpb) * RW;
+    }
+    auto tile_rp = [](int i) { return 2 * (i / (2 * NCH)) + (i & 1); };
+    auto tile_ch = [](int i) { return (i >> 1) % NCH; };
+    float* const stag_all = reinterpret_cast<float*>(ring + RS_SLOTS * RING_TILE);
+
+    if (wave < 4) {
+        // ================================ MFMA waves ================================================================
+        if (ablate & 64) return;
+#if PF_RS_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        const int li = lane & 31, lh = lane >> 5;
+        const long rowbytes = 4L * a.C;
+        const char* const f1b = reinterpret_cast<const char*>(a.f1) + (long)b * a.N * rowbytes;
+        const char* const f2b = reinterpret_cast<const char*>(a.f2) + (long)b * a.N * rowbytes;
+        bf16x8 fq[RING_NK][4];
+        {
+            const char* qrow = f1b + (long)(m0 + 32 * wave + li) * rowbytes + 32 * lh;
+#pragma unroll
+            for (int ks = 0; ks < RING_NK; ++ks) {
+                fq[ks][0] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128);
+                fq[ks][1] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 16);
+                fq[ks][2] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 64);
+                fq[ks][3] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 80);
+            }
+#pragma unroll
+            for (int ks = 0; ks < RING_NK; ++ks)       // retired before the first DMA (see the ring kernel)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fq[ks][i]));
+        }
+        // ring row 32 w + k of a tile: map row (w >> 1) of the pair, column 32 (w & 1) + k; wave w loads rows 32 w ..: piece j
+        // covers rows 32 w + 8 j + (lane >> 3), the swizzle term (r >> 1) & 7 repeats with period 2 in j
+        unsigned dma_off[4];                             // per-lane byte offsets of the 4 pieces from the wave's tile base
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 32 * wave + 8 * (j & 1) + (lane >> 3);
+            dma_off[j] = (unsigned)((16 * (j >> 1) + 8 * (j & 1) + (lane >> 3)) * (int)rowbytes + (((lane & 7) ^ ((r >> 1) & 7)) * 16));
+        }
+        auto tile_src = [&](int i) -> const char* {       // wave-uniform: first target row of this wave's quarter of tile i
+            const int row = ty0 + 2 * tile_rp(i) + (wave >> 1), col = tx0 + 64 * tile_ch(i) + 32 * (wave & 1);
+            return f2b + ((long)row * a.W + col) * rowbytes;
+        };
+        const char* cur_src = tile_src(0);
+        const char* nxt_src = cur_src;
+        typedef __attribute__((address_space(3))) char lds_char;
+        const unsigned lds_base = (unsigned)(unsigned long)(lds_char*)ring;
+        const unsigned wave_dst = __builtin_amdgcn_readfirstlane(lds_base + 4096u * (unsigned)wave);
+        // One K-step of this wave's quarter tile: 4 pieces of 8 rows x 128 B, source = scalar tile base + per-lane offset +
+        // K-step offset (folded into the scalar base: the instruction's immediate offset would move the LDS address as well).
+        // Inline assembly: the builtin wants a 64-bit per-lane pointer (8 VGPRs for the four pieces and a
+        // 64-bit vector add per piece; the kernel has no registers to spare), the instruction takes a scalar base.
+        auto issue_dma = [&](const char* src, auto KOFF, int slot) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (!(ablate & 2)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned keep;
+                    const unsigned dst = wave_dst + (unsigned)(slot * RING_TILE + j * 1024);
+                    const unsigned off = dma_off[j];
+                    const char* const ksrc = src + decltype(KOFF)::value;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(off), "s"(ksrc), "s"(dst) : "memory");
+                }
+            }
+#else
+            (void)src; (void)slot;
+#endif
+        };
+        // fragment read addresses (LDS byte offsets): ring row 32 t + li, pieces (hi k0-7, hi k8-15, lo k0-7, lo k8-15) of K-half lh.
+        // The reads and their waits are inline assembly: hipcc's own wait insertion drains lgkmcnt to 0 in front of every MFMA
+        // group, which exposes the round trip of the reads issued just before it (2 x ~120 cycles per K-step).
+        unsigned t_addr[4];
+        {
+            const unsigned base = lds_base + (unsigned)li * 128u;
+            const unsigned swz = (unsigned)((li >> 1) & 7), p0 = 2u * lh;
+            t_addr[0] = base + ((p0 + 0) ^ swz) * 16; t_addr[1] = base + ((p0 + 1) ^ swz) * 16;
+            t_addr[2] = base + ((p0 + 4) ^ swz) * 16; t_addr[3] = base + ((p0 + 5) ^ swz) * 16;
+        }
+        float* const stag = stag_all + wave * RS_STAGE + li * RS_PITCH + 4 * lh;
+
+        // acc[2 r + c][4 g + i]: target (map row r of the pair, column 32 c + 8 g + 4 lh + i of the tile), query row li
+        f32x16 acc[4];
+        f32x16 zero16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = zero16;
+        bf16x8 fa[4], fb[4];                             // the two fragment register sets
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { fa[q] = bf16x8{}; fb[q] = bf16x8{}; }
+        auto reads = [&](bf16x8 (&ft)[4], auto OFF) __attribute__((always_inline)) {
+            if (ablate & 4) return;
+            constexpr int off = decltype(OFF)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned ad = t_addr[q];
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ft[q]) : "v"(ad), "n"(off));
+            }
+#endif
+        };
+        // all but the N youngest LDS operations of this wave have returned: the fragments of `ft` may be used
+        auto wait_for = [&](bf16x8 (&ft)[4], auto CNT) __attribute__((always_inline)) {
+            if (ablate & 4) return;
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ft[0]), "+v"(ft[1]), "+v"(ft[2]), "+v"(ft[3]) : "n"(decltype(CNT)::value));
+        };
+        auto mfma3 = [&](bf16x8 (&ft)[4], int t, int ks, int k2, bool fresh) __attribute__((always_inline)) {
+            // per element: (query lo * target hi) + (query hi * target lo) + (hi * hi), as the tile kernel
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][2 + k2], (fresh && k2 == 0) ? zero16 : acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[2 + k2], fq[ks][k2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][k2], acc[t], 0, 0, 0);
+        };
+        auto mfmas = [&](bf16x8 (&ft)[4], int t, int ks, bool fresh) __attribute__((always_inline)) {
+            if (ablate & 4) return;
+            if (ablate & 1024) { asm volatile("" :: "v"(ft[0]), "v"(ft[1]), "v"(ft[2]), "v"(ft[3])); return; }
+            mfma3(ft, t, ks, 0, fresh);
+            mfma3(ft, t, ks, 1, fresh);
+        };
+        auto dump = [&](int t) __attribute__((always_inline)) {      // staging[query li][64 r + 32 c + 8 g + 4 lh ..+3], t = 2 r + c
+            if (ablate & 16) { asm volatile("" :: "v"(acc[t])); return; }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(stag + 64 * (t >> 1) + 32 * (t & 1) + 8 * g) = v;
+            }
+        };
+        using C0 = std::integral_constant<int, 0>;
+        using C4 = std::integral_constant<int, 4>;
+
+        ring_for<0, RS_AHEAD>([&](auto I) __attribute__((always_inline)) {
+            issue_dma(cur_src, std::integral_constant<int, decltype(I)::value * 128>{}, decltype(I)::value);
+        });
+        for (int tile = 0; tile < NT; ++tile) {
+            nxt_src = tile_src(tile + 1 < NT ? tile + 1 : tile);      // past the end the last tile is re-read (uniform vmcnt counts)
+            ring_for<0, RING_NK>([&](auto KS) __attribute__((always_inline)) {
+                constexpr int ks = decltype(KS)::value;
+                constexpr int sbase = (ks % RS_SLOTS) * RING_TILE;
+                constexpr int kd = ks + RS_AHEAD;                      // the K-step whose DMA is issued here
+                // K-step g's pieces were issued RS_AHEAD steps ago; the only younger vector-memory operations of this wave are
+                // the 4 pieces of each of the RS_AHEAD - 1 steps behind it (this wave never stores).  lgkmcnt(0): the last
+                // block's fragments of the previous K-step are in registers (its slot may be overwritten from here on) and a
+                // staging dump has landed before the barrier that hands it to the store wave.
+                if (ablate & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 * (RS_AHEAD - 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(4 * (RS_AHEAD - 1)) : "memory");
+                RS_SB();
+                reads(fa, std::integral_constant<int, sbase>{});
+                RS_SB();
+                // last block of the previous K-step (operands already in registers) with this step's DMA issue between its MFMAs
+                const char* const dsrc = kd >= RING_NK ? nxt_src : cur_src;
+                using DK = std::integral_constant<int, (kd % RING_NK) * 128>;
+                if (ks > 0 || tile > 0) {
+                    wait_for(fb, C4{});
+                    constexpr int pk = (ks + RING_NK - 1) % RING_NK;
+                    if (!(ablate & (4 | 1024))) mfma3(fb, 3, pk, 0, ks == 1);
+                    else mfmas(fb, 3, pk, false);
+                    RS_SB();
+                    issue_dma(dsrc, DK{}, kd % RS_SLOTS);
+                    RS_SB();
+                    if (!(ablate & (4 | 1024))) mfma3(fb, 3, pk, 1, false);
+                } else {
+                    issue_dma(dsrc, DK{}, kd % RS_SLOTS);
+                }
+                RS_SB();
+                reads(fb, std::integral_constant<int, sbase + 4096>{});
+                RS_SB();
+                wait_for(fa, C4{});
+                if (ks == 0 && tile > 0) dump(0);
+                mfmas(fa, 0, ks, ks == 0);
+                RS_SB();
+                reads(fa, std::integral_constant<int, sbase + 2 * 4096>{});
+                RS_SB();
+                wait_for(fb, C4{});
+                if (ks == 0 && tile > 0) dump(1);
+                mfmas(fb, 1, ks, ks == 0);
+                RS_SB();
+                reads(fb, std::integral_constant<int, sbase + 3 * 4096>{});
+                RS_SB();
+                wait_for(fa, C4{});
+                if (ks == 0 && tile > 0) dump(2);
+                mfmas(fa, 2, ks, ks == 0);
+                if (ks == 0 && tile > 0) dump(3);
+                RS_SB();
+            });
+            cur_src = nxt_src;
+        }
+        wait_for(fb, C0{});
+        mfmas(fb, 3, RING_NK - 1, false);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dump(t);
+        // the last dump is handed over; the tail DMAs (re-reads) must land before the workgroup's LDS is released
+        if (ablate & 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+    }
+
+    // ==================================== store waves ===================================================================
+    const int sw = wave - 4;
+#if PF_RS_PRIO == 1
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const int qq = lane >> 4, j = lane & 15;         // pass p: query row 4 p + qq of the wave's 32, target columns 4 j .. 4 j + 3 of both map rows
+    const float* const stag = stag_all + sw * RS_STAGE + qq * RS_PITCH + 4 * j;
+    float* const img2 = stag_all + 4 * RS_STAGE + sw * RING_STAGE;                                       // [32][RING_IMG2]
+    float* const carry3 = img2 + 32 * RING_IMG2;                                                         // [32][16]
+    const long N = a.N;
+    const int W1 = a.W >> 1, W2 = a.W >> 2, W3 = a.W >> 3;
+    const long N1 = N >> 2, N2 = N >> 4, N3 = N >> 6;
+    const long row0 = (long)b * N + m0 + 32 * sw;        // first query row of this wave
+    const unsigned off0 = (unsigned)((qq * N + 4 * j) * 4);
+    const unsigned off1 = (unsigned)((qq * N1 + 2 * j) * 4);
+    auto scaled = [&](float x) { return MUL ? x * a.scale_mul : x / a.inv_scale; };
+    auto pool = [](float tl, float tr, float bl, float br) { float q = tl + tr; q = q + bl; q = q + br; return q * 0.25f; };   // avg_pool2d's order
+    constexpr bool st0 = !(ablate & (1 | 512)), stp = !(ablate & (1 | 256));
+    float hs[8];                                         // level-1 pair sums of an even row pair (level 2's top row), per pass
+    f32x4 raw[8][2];
+
+    auto pass = [&](auto P, const int dt) __attribute__((always_inline)) {       // pass p of data tile dt
+        constexpr int p = decltype(P)::value;
+        const int rp = tile_rp(dt), ch = tile_ch(dt);
+        f32x4 r0 = raw[p][0], r1 = raw[p][1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r0[i] = scaled(r0[i]); r1[i] = scaled(r1[i]); }
+        // ---- level 0: 4 query rows x 256 contiguous bytes per store, both map rows ----------------------------------
+        char* const l0 = reinterpret_cast<char*>(a.lvl[0] + (row0 + 4 * p) * N + (long)(ty0 + 2 * rp) * a.W + tx0 + 64 * ch) + off0;
+        if (st0) {
+            vol_store(reinterpret_cast<f32x4*>(l0), r0);
+            vol_store(reinterpret_cast<f32x4*>(l0 + 4L * a.W), r1);
+        }
+        // ---- level 1: 4 whole lines per store (operation order of F.avg_pool2d) ----------------------------------------
+        f32x2 p1;
+        p1.x = pool(r0[0], r0[1], r1[0], r1[1]);
+        p1.y = pool(r0[2], r0[3], r1[2], r1[3]);
+        char* const l1 = reinterpret_cast<char*>(a.lvl[1] + (row0 + 4 * p) * N1 + (long)((ty0 >> 1) + rp) * W1 + (tx0 >> 1) + 32 * ch) + off1;
+        if (stp) vol_store(reinterpret_cast<f32x2*>(l1), p1);
+        if (!(rp & 1)) {
+            hs[p] = p1.x + p1.y;                     // tl + tr: the first add of the level-2 pooling
+        } else {
+            float q = hs[p] + p1.x;
+            q = q + p1.y;
+            img2[(4 * p + qq) * RING_IMG2 + 16 * ch + j] = q * 0.25f;
+        }
+    };
+    auto finish = [&](const int dt) __attribute__((always_inline)) {
+        // level 2: whole lines out of the wave-private image once both row pairs of all column chunks are in; level 3 from
+        // the two level-2 rows of an 8-row band (the ring kernel's code)
+        const int rp = tile_rp(dt), ch = tile_ch(dt);
+        if (!(rp & 1) || ch != NCH - 1) return;
+        constexpr int C2 = 16 * NCH;                 // level-2 columns of the region
+        constexpr int LPR = C2 / 4;                  // lanes per query row (16 bytes each)
+        constexpr int RPI = 64 / LPR;                // query rows per store instruction
+        const int l2r = rp >> 1;                     // level-2 row inside the item
+        const int qr = lane / LPR, pc = lane % LPR;
+        char* const l2 = reinterpret_cast<char*>(a.lvl[2] + row0 * N2 + (long)((ty0 >> 2) + l2r) * W2 + (tx0 >> 2))
+                         + (unsigned)((qr * N2 + 4 * pc) * 4);
+        char* const l3 = reinterpret_cast<char*>(a.lvl[3] + row0 * N3 + (long)((ty0 >> 3) + (l2r >> 1)) * W3 + (tx0 >> 3))
+                         + (unsigned)((qr * N3 + 2 * pc) * 4);
+#pragma unroll
+        for (int k = 0; k < 32 / RPI; ++k) {
+            const float* src = img2 + (qr + RPI * k) * RING_IMG2 + 4 * pc;
+            const f32x4 v = {src[0], src[1], src[2], src[3]};
+            if (stp) vol_store(reinterpret_cast<f32x4*>(l2 + (long)RPI * k * N2 * 4), v);
+            float* c3 = carry3 + (qr + RPI * k) * 16 + 2 * pc;
+            if (!(l2r & 1)) {
+                c3[0] = v.x + v.y;
+                c3[1] = v.z + v.w;
+            } else {
+                float q0 = c3[0] + v.x, q1 = c3[1] + v.z;
+                q0 = q0 + v.y; q1 = q1 + v.w;
+                const f32x2 o = {q0 * 0.25f, q1 * 0.25f};
+                if (stp) vol_store(reinterpret_cast<f32x2*>(l3 + (long)RPI * k * N3 * 4), o);
+            }
+        }
+    };
+    auto pull = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            raw[p][0] = *reinterpret_cast<const f32x4*>(stag + 4 * p * RS_PITCH);
+            raw[p][1] = *reinterpret_cast<const f32x4*>(stag + 4 * p * RS_PITCH + 64);
+        }
+    };
+
+    // The staging image of tile i is complete behind the barrier of K-step (i + 1, 1).  Interval (tile, ks): pass (ks - 1) & 7 of
+    // data tile (ks >= 1 ? tile - 1 : tile - 2).
+    for (int tile = 0; tile < NT; ++tile) {
+        ring_for<0, RING_NK>([&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
+            // lgkmcnt(0): the staging reads of this wave have returned before the barrier behind which the image is rewritten
+            if (ablate & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (ablate & 8) return;
+            const int dt = ks >= 1 ? tile - 1 : tile - 2;
+            if (dt < 0) return;
+            if (ks == 1) pull();
+            pass(std::integral_constant<int, (ks + 7) & 7>{}, dt);
+            if (ks == 0) finish(dt);
+        });
+    }
+    if (!(ablate & 8) && NT >= 2) {
+        pass(std::integral_constant<int, 7>{}, NT - 2);
+        finish(NT - 2);
+    }
+    if (ablate & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ablate & 8) return;
+    pull();
+    ring_for<0, 8>([&](auto P) __attribute__((always_inline)) { pass(P, NT - 1); });
+    finish(NT - 1);
 }
 
 // 2x2 mean of one level into the next (generic path only)
@@ -664,7 +1056,32 @@ static int corr_launch(const float* f1, const float* f2, float* lvl0, float* lvl
         // 152 vs 145 us at B = 1 (both sit on the ~110 us their scattered store stream needs), 4-5 % faster from B = 8 on.
         // PRIORFLOW_CORR_RING = 0 / 1 forces one of them (tests, A/B comparisons).
         const char* env = getenv("PRIORFLOW_CORR_RING");
-        const bool ring = env ? env[0] == '1' : B >= 4;
+        const char* ab = getenv("PRIORFLOW_CORR_ABLATE");            // timing-only diagnosis (profiles/ab_corr.py)
+        const int ablate = ab ? atoi(ab) : 0;
+        // 2: the role-split kernel (round 5), 1: the ring kernel, 0: the tile kernel
+        const int form = env ? (env[0] - '0') : 2;
+        if (split && C == 32 * RING_NK && (W8 % 64) == 0 && form == 2) {
+            const int nch = (W8 % 128) == 0 ? 2 : 1;                 // work items of RB x 128 (or RB x 64) target pixels
+            const int RB = (H8 % 16) == 0 ? 16 : 8;
+            dim3 grid((unsigned)((long)B * a.m_tiles * (H8 / RB) * (W8 / (64 * nch))));
+            const bool mul = a.scale_mul != 0.f;
+            static const hipError_t attr = [] {
+                const void* k[4] = {reinterpret_cast<const void*>(&pf_corr_rs_kernel<true, 2>), reinterpret_cast<const void*>(&pf_corr_rs_kernel<true, 1>),
+                                    reinterpret_cast<const void*>(&pf_corr_rs_kernel<false, 2>), reinterpret_cast<const void*>(&pf_corr_rs_kernel<false, 1>)};
+                for (int i = 0; i < 4; ++i) {
+                    const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
+                    if (e != hipSuccess) return e;
+                }
+                return hipSuccess;
+            }();
+            if (attr != hipSuccess) return (int)attr;
+            if (mul && nch == 2) hipLaunchKernelGGL((pf_corr_rs_kernel<true, 2>), grid, dim3(512), RS_LDS, s, a, RB);
+            else if (mul) hipLaunchKernelGGL((pf_corr_rs_kernel<true, 1>), grid, dim3(512), RS_LDS, s, a, RB);
+            else if (nch == 2) hipLaunchKernelGGL((pf_corr_rs_kernel<false, 2>), grid, dim3(512), RS_LDS, s, a, RB);
+            else hipLaunchKernelGGL((pf_corr_rs_kernel<false, 1>), grid, dim3(512), RS_LDS, s, a, RB);
+            return (int)hipGetLastError();
+        }
+        const bool ring = form == 1;
         if (split && C == 32 * RING_NK && (W8 % 64) == 0 && ring) {
             const int nch = (W8 % 128) == 0 ? 2 : 1;                 // regions of 8 x 128 (or 8 x 64) target pixels
             dim3 grid((unsigned)((long)B * a.m_tiles * (H8 / 8) * (W8 / (64 * nch))));
@@ -679,8 +1096,6 @@ static int corr_launch(const float* f1, const float* f2, float* lvl0, float* lvl
                 return hipSuccess;
             }();
             if (attr != hipSuccess) return (int)attr;
-            const char* ab = getenv("PRIORFLOW_CORR_ABLATE");        // timing-only diagnosis (profiles/ab_corr.py)
-            const int ablate = ab ? atoi(ab) : 0;
             if (mul && nch == 2) hipLaunchKernelGGL((pf_corr_ring_kernel<true, 2>), grid, dim3(256), RING_LDS, s, a, ablate);
             else if (mul) hipLaunchKernelGGL((pf_corr_ring_kernel<true, 1>), grid, dim3(256), RING_LDS, s, a, ablate);
             else if (nch == 2) hipLaunchKernelGGL((pf_corr_ring_kernel<false, 2>), grid, dim3(256), RING_LDS, s, a, ablate);

@@ -253,19 +253,23 @@ def test_corr_pyramid(lib, dev, shape, prec):
         kc.check(lv[i].cpu(), pyr[i].reshape(B * n, -1), 3e-5 if prec == "fp32" else 2e-4, f"level {i}")
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 128), (2, 24, 128), (1, 48, 64), (3, 16, 64)], ids=lambda s: "B%dx%dx%d" % s)
-def test_corr_ring_kernel_matches_tile_kernel_bitwise(lib, dev, shape, monkeypatch):
+@pytest.mark.parametrize("shape", [(1, 64, 128), (2, 24, 128), (1, 48, 64), (3, 16, 64), (1, 32, 256), (2, 40, 64)],
+                         ids=lambda s: "B%dx%dx%d" % s)
+@pytest.mark.parametrize("form", ["1", "2"], ids=["ring", "role_split"])
+def test_corr_ring_kernel_matches_tile_kernel_bitwise(lib, dev, shape, form, monkeypatch):
     """The ring kernel (transposed GEMM, query fragments in registers, target tiles of 2 map rows x 64 columns streamed
     by LDS-DMA, regions of 8 x 128 -- or 8 x 64 when W/8 is not a multiple of 128 -- per workgroup) performs the tile
     kernel's arithmetic in the tile kernel's order: all four levels must be bit-identical, and nothing outside them may
-    be written.  (Maps whose width is not a multiple of 64, e.g. 640x1280, stay on the tile kernel.)"""
+    be written.  (Maps whose width is not a multiple of 64, e.g. 640x1280, stay on the tile kernel.)  The same holds for
+    the role-split kernel (round 5: the ring kernel's GEMM on four MFMA waves, scaling / pooling / every global store on
+    four store waves fed through an LDS staging image; items of 16 or 8 map rows)."""
     B, h, w = shape
     n = h * w
     gen = torch.Generator().manual_seed(h * w + B)
     f = [(torch.rand(B * n, 256, generator=gen) * 3.4 - 1.7).to(dev) for _ in range(2)]
     sp = [lib.split_bf16(x, torch.empty(B * n, 8, 2, 32, dtype=torch.bfloat16, device=dev)) for x in f]
     out = {}
-    for rep, mode in enumerate(("0", "1", "1", "1", "1", "1")):      # the ring kernel repeatedly: a stale ring tile (a missed
+    for rep, mode in enumerate(("0",) + (form,) * 5):      # the ring kernel repeatedly: a stale ring tile (a missed
         monkeypatch.setenv("PRIORFLOW_CORR_RING", mode)              # DMA wait) would show up as a rare 128 x 32 patch
         # one guard row of NaNs behind every level: must stay untouched
         lv = [torch.full((B * n + 1, (h >> i) * (w >> i)), float("nan"), device=dev) for i in range(4)]
@@ -273,14 +277,14 @@ def test_corr_ring_kernel_matches_tile_kernel_bitwise(lib, dev, shape, monkeypat
         torch.cuda.synchronize()
         if rep >= 2:
             for i in range(4):
-                assert torch.equal(out["1"][i], lv[i]) or i < 0 or bool(torch.isnan(lv[i][B * n]).all()) and \
-                    torch.equal(out["1"][i][:B * n], lv[i][:B * n]), f"level {i}: ring kernel run {rep} differs from its first run"
+                assert torch.equal(out[form][i], lv[i]) or i < 0 or bool(torch.isnan(lv[i][B * n]).all()) and \
+                    torch.equal(out[form][i][:B * n], lv[i][:B * n]), f"level {i}: ring kernel run {rep} differs from its first run"
         else:
             out[mode] = lv
     for i in range(4):
-        assert torch.isnan(out["1"][i][B * n]).all(), f"level {i}: wrote past the end"
-        assert torch.isfinite(out["1"][i][:B * n]).all(), f"level {i}: unwritten elements"
-        d = (out["0"][i][:B * n] - out["1"][i][:B * n]).abs()
+        assert torch.isnan(out[form][i][B * n]).all(), f"level {i}: wrote past the end"
+        assert torch.isfinite(out[form][i][:B * n]).all(), f"level {i}: unwritten elements"
+        d = (out["0"][i][:B * n] - out[form][i][:B * n]).abs()
         bad = (d > 0).nonzero()
         assert bad.numel() == 0, (f"level {i}: {bad.shape[0]} elements differ between the two kernels, max {float(d.max()):.3e}, "
                                   f"first at (row, col) {bad[0].tolist()}, last {bad[-1].tolist()}")
