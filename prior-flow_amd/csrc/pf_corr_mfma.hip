@@ -22,6 +22,7 @@
 // 1..3 then come from a small pooling kernel (odd sizes drop the last row / column like
 // F.avg_pool2d(2, stride=2), core/corr.py:108).
 #include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 #include "pf_common.h"
 #include "../../include/priorflow_hip.h"
@@ -667,6 +668,10 @@ pf_corr_ring_kernel(const CorrArgs a, const int ablate) {
 #ifndef PF_RS_PRIO
 #define PF_RS_PRIO 0
 #endif
+#ifdef PF_RS_STAMP               // diagnosis build: cycles per wave spent in barriers / behind waits / issuing stores
+__device__ unsigned long long pf_rs_dbg[2048 * 8 * 4];
+#define RS_T() __builtin_amdgcn_s_memtime()
+#endif
 constexpr int RS_SLOTS = 4;                          // divides the 8 K-steps of a tile: the slot of a K-step is a compile-time constant
 constexpr int RS_AHEAD = PF_RS_AHEAD;                // K-steps in flight (2 or 3)
 constexpr int RS_PITCH = 132;                        // floats per staging row: 2 x 64 targets + 16 bytes (conflict-free ds_write_b128)
@@ -749,21 +754,18 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
         // K-step offset (folded into the scalar base: the instruction's immediate offset would move the LDS address as well).
         // Inline assembly: the builtin wants a 64-bit per-lane pointer (8 VGPRs for the four pieces and a
         // 64-bit vector add per piece; the kernel has no registers to spare), the instruction takes a scalar base.
-        auto issue_dma = [&](const char* src, auto KOFF, int slot) __attribute__((always_inline)) {
+        auto dma_piece = [&](const char* src, auto KOFF, int slot, int j) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
             if (!(ablate & 2)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned keep;
-                    const unsigned dst = wave_dst + (unsigned)(slot * RING_TILE + j * 1024);
-                    const unsigned off = dma_off[j];
-                    const char* const ksrc = src + decltype(KOFF)::value;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(off), "s"(ksrc), "s"(dst) : "memory");
-                }
+                unsigned keep;
+                const unsigned dst = wave_dst + (unsigned)(slot * RING_TILE + j * 1024);
+                const unsigned off = dma_off[j];
+                const char* const ksrc = src + decltype(KOFF)::value;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(off), "s"(ksrc), "s"(dst) : "memory");
             }
 #else
-            (void)src; (void)slot;
+            (void)src; (void)slot; (void)j;
 #endif
         };
         // fragment read addresses (LDS byte offsets): ring row 32 t + li, pieces (hi k0-7, hi k8-15, lo k0-7, lo k8-15) of K-half lh.
@@ -804,32 +806,42 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
             if (ablate & 4) return;
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ft[0]), "+v"(ft[1]), "+v"(ft[2]), "+v"(ft[3]) : "n"(decltype(CNT)::value));
         };
-        auto mfma3 = [&](bf16x8 (&ft)[4], int t, int ks, int k2, bool fresh) __attribute__((always_inline)) {
-            // per element: (query lo * target hi) + (query hi * target lo) + (hi * hi), as the tile kernel
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][2 + k2], (fresh && k2 == 0) ? zero16 : acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[2 + k2], fq[ks][k2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][k2], acc[t], 0, 0, 0);
+        // One 32 x 32 block of a K-step: 6 MFMAs -- per element (query lo * target hi) + (query hi * target lo) + (hi * hi) for
+        // both 16-channel halves, the tile kernel's order -- with gap(i) issued behind MFMA i.  What goes into the gaps is
+        // everything else this wave does: one DMA piece, or one ds_write_b128 of the staging dump (the LDS takes wide
+        // stores at ~80 B/clk per CU: the four waves' 64 KB of accumulators in one burst held the matrix pipe for ~800
+        // cycles per tile; one store per gap hides behind the 32 cycles of the MFMA in front of it).
+        auto block = [&](bf16x8 (&ft)[4], int t, int ks, bool fresh, auto&& gap) __attribute__((always_inline)) {
+            ring_for<0, 6>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value, k2 = i / 3, m = i % 3;
+                if (!(ablate & (4 | 1024))) {
+                    if (m == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][2 + k2], (fresh && i == 0) ? zero16 : acc[t], 0, 0, 0);
+                    else if (m == 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[2 + k2], fq[ks][k2], acc[t], 0, 0, 0);
+                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][k2], acc[t], 0, 0, 0);
+                } else if ((ablate & 1024) && i == 0) asm volatile("" :: "v"(ft[0]), "v"(ft[1]), "v"(ft[2]), "v"(ft[3]));
+                RS_SB();
+                gap(I);
+                RS_SB();
+            });
         };
-        auto mfmas = [&](bf16x8 (&ft)[4], int t, int ks, bool fresh) __attribute__((always_inline)) {
-            if (ablate & 4) return;
-            if (ablate & 1024) { asm volatile("" :: "v"(ft[0]), "v"(ft[1]), "v"(ft[2]), "v"(ft[3])); return; }
-            mfma3(ft, t, ks, 0, fresh);
-            mfma3(ft, t, ks, 1, fresh);
-        };
-        auto dump = [&](int t) __attribute__((always_inline)) {      // staging[query li][64 r + 32 c + 8 g + 4 lh ..+3], t = 2 r + c
+        auto no_gap = [](auto) {};
+        auto dump_piece = [&](int t, int g) __attribute__((always_inline)) {   // staging[query li][64 r + 32 c + 8 g + 4 lh ..+3], t = 2 r + c
             if (ablate & 16) { asm volatile("" :: "v"(acc[t])); return; }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(stag + 64 * (t >> 1) + 32 * (t & 1) + 8 * g) = v;
-            }
+            const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(stag + 64 * (t >> 1) + 32 * (t & 1) + 8 * g) = v;
         };
         using C0 = std::integral_constant<int, 0>;
         using C4 = std::integral_constant<int, 4>;
 
         ring_for<0, RS_AHEAD>([&](auto I) __attribute__((always_inline)) {
-            issue_dma(cur_src, std::integral_constant<int, decltype(I)::value * 128>{}, decltype(I)::value);
+            ring_for<0, 4>([&](auto J) __attribute__((always_inline)) {
+                dma_piece(cur_src, std::integral_constant<int, decltype(I)::value * 128>{}, decltype(I)::value, decltype(J)::value);
+            });
         });
+#ifdef PF_RS_STAMP
+        unsigned long long st_wait = 0, st_bar = 0;
+        const unsigned long long st_begin = RS_T();
+#endif
         for (int tile = 0; tile < NT; ++tile) {
             nxt_src = tile_src(tile + 1 < NT ? tile + 1 : tile);      // past the end the last tile is re-read (uniform vmcnt counts)
             ring_for<0, RING_NK>([&](auto KS) __attribute__((always_inline)) {
@@ -840,56 +852,80 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
                 // the 4 pieces of each of the RS_AHEAD - 1 steps behind it (this wave never stores).  lgkmcnt(0): the last
                 // block's fragments of the previous K-step are in registers (its slot may be overwritten from here on) and a
                 // staging dump has landed before the barrier that hands it to the store wave.
+#ifdef PF_RS_STAMP
+                {
+                    const unsigned long long t0 = RS_T();
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 * (RS_AHEAD - 1)) : "memory");
+                    const unsigned long long t1 = RS_T();
+                    asm volatile("s_barrier" ::: "memory");
+                    const unsigned long long t2 = RS_T();
+                    st_wait += t1 - t0; st_bar += t2 - t1;
+                }
+#else
                 if (ablate & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 * (RS_AHEAD - 1)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(4 * (RS_AHEAD - 1)) : "memory");
+#endif
                 RS_SB();
                 reads(fa, std::integral_constant<int, sbase>{});
                 RS_SB();
-                // last block of the previous K-step (operands already in registers) with this step's DMA issue between its MFMAs
+                // last block of the previous K-step (operands already in registers) with this step's DMA pieces in its gaps
                 const char* const dsrc = kd >= RING_NK ? nxt_src : cur_src;
                 using DK = std::integral_constant<int, (kd % RING_NK) * 128>;
+                auto dma_gap = [&](auto I) __attribute__((always_inline)) {
+                    if constexpr (decltype(I)::value < 4) dma_piece(dsrc, DK{}, kd % RS_SLOTS, decltype(I)::value);
+                };
                 if (ks > 0 || tile > 0) {
                     wait_for(fb, C4{});
-                    constexpr int pk = (ks + RING_NK - 1) % RING_NK;
-                    if (!(ablate & (4 | 1024))) mfma3(fb, 3, pk, 0, ks == 1);
-                    else mfmas(fb, 3, pk, false);
-                    RS_SB();
-                    issue_dma(dsrc, DK{}, kd % RS_SLOTS);
-                    RS_SB();
-                    if (!(ablate & (4 | 1024))) mfma3(fb, 3, pk, 1, false);
+                    block(fb, 3, (ks + RING_NK - 1) % RING_NK, ks == 1, dma_gap);
                 } else {
-                    issue_dma(dsrc, DK{}, kd % RS_SLOTS);
+                    ring_for<0, 4>(dma_gap);
                 }
+                // The staging dump of a tile rides in the gaps of blocks that do not touch the accumulator being dumped:
+                // acc[0] / acc[1] (final after blocks 0 / 1 of the tile's last K-step) behind blocks 1 / 2 of that K-step,
+                // acc[2] / acc[3] (final after block 2 / the block above) behind blocks 0 / 1 of the next tile's first K-step.
+                auto dump_gap = [&](int t, bool on) {
+                    return [&, t, on](auto I) __attribute__((always_inline)) {
+                        if constexpr (decltype(I)::value < 4) { if (on) dump_piece(t, decltype(I)::value); }
+                    };
+                };
                 RS_SB();
                 reads(fb, std::integral_constant<int, sbase + 4096>{});
                 RS_SB();
                 wait_for(fa, C4{});
-                if (ks == 0 && tile > 0) dump(0);
-                mfmas(fa, 0, ks, ks == 0);
+                if (ks == 0) block(fa, 0, ks, true, dump_gap(2, tile > 0));
+                else block(fa, 0, ks, false, no_gap);
                 RS_SB();
                 reads(fa, std::integral_constant<int, sbase + 2 * 4096>{});
                 RS_SB();
                 wait_for(fb, C4{});
-                if (ks == 0 && tile > 0) dump(1);
-                mfmas(fb, 1, ks, ks == 0);
+                if (ks == 0) block(fb, 1, ks, true, dump_gap(3, tile > 0));
+                else if (ks == RING_NK - 1) block(fb, 1, ks, false, dump_gap(0, true));
+                else block(fb, 1, ks, false, no_gap);
                 RS_SB();
                 reads(fb, std::integral_constant<int, sbase + 3 * 4096>{});
                 RS_SB();
                 wait_for(fa, C4{});
-                if (ks == 0 && tile > 0) dump(2);
-                mfmas(fa, 2, ks, ks == 0);
-                if (ks == 0 && tile > 0) dump(3);
+                if (ks == RING_NK - 1) block(fa, 2, ks, false, dump_gap(1, true));
+                else block(fa, 2, ks, ks == 0, no_gap);
                 RS_SB();
             });
             cur_src = nxt_src;
         }
         wait_for(fb, C0{});
-        mfmas(fb, 3, RING_NK - 1, false);
+        block(fb, 3, RING_NK - 1, false, no_gap);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dump(t);
+        for (int g = 0; g < 4; ++g) dump_piece(2, g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dump_piece(3, g);
         // the last dump is handed over; the tail DMAs (re-reads) must land before the workgroup's LDS is released
         if (ablate & 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef PF_RS_STAMP
+        if (lane == 0 && blockIdx.x < 2048) {
+            unsigned long long* d = pf_rs_dbg + (blockIdx.x * 8 + wave) * 4;
+            d[0] = RS_T() - st_begin; d[1] = st_wait; d[2] = st_bar; d[3] = 0;
+        }
+#endif
         return;
     }
 
@@ -979,14 +1015,29 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
         }
     };
 
+#ifdef PF_RS_STAMP
+    unsigned long long st_bar = 0, st_work = 0, st_last = 0;
+    const unsigned long long st_begin = RS_T();
+#endif
     // The staging image of tile i is complete behind the barrier of K-step (i + 1, 1).  Interval (tile, ks): pass (ks - 1) & 7 of
     // data tile (ks >= 1 ? tile - 1 : tile - 2).
     for (int tile = 0; tile < NT; ++tile) {
         ring_for<0, RING_NK>([&](auto KS) __attribute__((always_inline)) {
             constexpr int ks = decltype(KS)::value;
             // lgkmcnt(0): the staging reads of this wave have returned before the barrier behind which the image is rewritten
+#ifdef PF_RS_STAMP
+            {
+                const unsigned long long t0 = RS_T();
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const unsigned long long t1 = RS_T();
+                st_bar += t1 - t0;
+                if (st_last) st_work += t0 - st_last;
+                st_last = t1;
+            }
+#else
             if (ablate & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             if (ablate & 8) return;
             const int dt = ks >= 1 ? tile - 1 : tile - 2;
             if (dt < 0) return;
@@ -995,6 +1046,12 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
             if (ks == 0) finish(dt);
         });
     }
+#ifdef PF_RS_STAMP
+    if (lane == 0 && blockIdx.x < 2048) {
+        unsigned long long* d = pf_rs_dbg + (blockIdx.x * 8 + wave) * 4;
+        d[0] = RS_T() - st_begin; d[1] = st_work; d[2] = st_bar; d[3] = 1;
+    }
+#endif
     if (!(ablate & 8) && NT >= 2) {
         pass(std::integral_constant<int, 7>{}, NT - 2);
         finish(NT - 2);
@@ -1079,6 +1136,20 @@ static int corr_launch(const float* f1, const float* f2, float* lvl0, float* lvl
             else if (mul) hipLaunchKernelGGL((pf_corr_rs_kernel<true, 1>), grid, dim3(512), RS_LDS, s, a, RB);
             else if (nch == 2) hipLaunchKernelGGL((pf_corr_rs_kernel<false, 2>), grid, dim3(512), RS_LDS, s, a, RB);
             else hipLaunchKernelGGL((pf_corr_rs_kernel<false, 1>), grid, dim3(512), RS_LDS, s, a, RB);
+#ifdef PF_RS_STAMP
+            if (getenv("PRIORFLOW_CORR_STAMP")) {
+                hipDeviceSynchronize();
+                static unsigned long long h[2048 * 8 * 4];
+                hipMemcpyFromSymbol(h, HIP_SYMBOL(pf_rs_dbg), sizeof(h));
+                const int nb = grid.x < 2048 ? (int)grid.x : 2048;
+                double m[3] = {0, 0, 0}, st[3] = {0, 0, 0};
+                for (int bI = 0; bI < nb; ++bI)
+                    for (int w = 0; w < 8; ++w)
+                        for (int k = 0; k < 3; ++k) (w < 4 ? m : st)[k] += (double)h[(bI * 8 + w) * 4 + k] / (4.0 * nb);
+                fprintf(stderr, "[rs stamp] MFMA waves: loop %.0f cyc, vmcnt/lgkm wait %.0f, in barrier %.0f | store waves: loop %.0f, between barriers (work) %.0f, in barrier %.0f   (s_memtime ticks, mean over %d workgroups)\n",
+                        m[0], m[1], m[2], st[0], st[1], st[2], nb);
+            }
+#endif
             return (int)hipGetLastError();
         }
         const bool ring = form == 1;
