@@ -25,6 +25,9 @@ Extra objects on the JSON line:
   cpu_baseline  the CPU oracle (oracle/priorflow_oracle.py, the checker -- never the product)
                 timed on the host cores on the same pair, rank 0 at N=1 only, plus the EPE of
                 the GPU flow against it (`parity`);
+  batch32       BASELINE.json configs[2]: 32 resident pairs, a few timed steps, pair 0 against the oracle;
+  train_step    BASELINE.json configs[3] per GPU: the product training step at 384x512, iters=12, one pair, captured as a HIP
+                graph (train.GraphedTrainStep): ms/step, training pairs/s, launches of an eager step, loss trajectory;
   fp32_exact    the same forward in exact-fp32 MFMA arithmetic (the strict reference point beside the
                 bf16x3 headline): pairs/s and EPE vs the oracle, rank 0 at N=1 only.
 """
@@ -94,6 +97,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-batch32", action="store_true", help="skip the bounded configs[2] leg of the N=1 line")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the bounded training-step leg (configs[3] per GPU) of the N=1 line")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
                     help="update-block conv arithmetic (default: PRIORFLOW_PRECISION or bf16x3)")
     return ap.parse_args()
@@ -442,6 +446,53 @@ def batch32_point(params, device, ref_cpu, steps=4, warmup=2, batch=32):
     return out
 
 
+def train_step_point(device, steps=10, size=(384, 512), iters=ITERS):
+    """BASELINE.json configs[3] per GPU on the driver's own line: the product training step (zero_grad, GT rotation, forward of
+    both branches, sequence loss, backward, clip, fused AdamW -- train_flow.py:120-141) at the reference's training crop
+    (train_flow.py:217: 384x512, iters=12), one pair per GPU, as train.GraphedTrainStep: one eager step, the capture, one replay,
+    then `steps` timed replays on fresh data each (the loss is read after the timed region).  Also one eager step's launch count."""
+    from prior_flow_amd import autograd as ag
+    from prior_flow_amd import det_state_dict, synthetic_pair
+    from prior_flow_amd import train as tr
+    from prior_flow_amd.modules import state_dict_shapes
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    Ht, Wt = size
+    model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    model.load_state_dict(det_state_dict(state_dict_shapes()), strict=True)
+    model = model.to(device).train()
+    model.freeze_bn()                                                            # train_flow.py:107-108
+    opt, sched = tr.fetch_optimizer(argparse.Namespace(lr=2e-5, wdecay=5e-5, epsilon=1e-8, num_steps=100000), model)
+    i1, i2 = (t.to(device) for t in synthetic_pair(1, Ht, Wt, seed=1234))
+    gen = torch.Generator().manual_seed(99)
+    gt = (torch.rand(1, 2, Ht, Wt, generator=gen) * 8 - 4).to(device)
+    valid = torch.ones(1, Ht, Wt, device=device)
+    crit = tr.uniform_loss(Ht, Wt, device=device)
+    stepper = tr.GraphedTrainStep(model, opt, sched, crit, iters=iters, clip=1.0, warmup=1)
+    torch.cuda.reset_peak_memory_stats(device)
+    ag.STATS["hip"] = ag.STATS["torch"] = 0
+    losses = [stepper(i1, i2, gt, valid)[0]]                                     # eager step
+    torch.cuda.synchronize()
+    launches = {"hip_library": int(ag.STATS["hip"]), "torch_conv_or_gemm": int(ag.STATS["torch"])}
+    for _ in range(2):                                                           # capture + first replay, one more replay
+        losses.append(stepper(i1, i2, gt, valid)[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        losses.append(stepper((i1 + float(k % 3)).clamp(0, 255), i2, gt, valid)[0])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": f"training step {Ht}x{Wt}, iters={iters}, 1 pair per GPU (BASELINE.json configs[3] per GPU): forward + backward + "
+                       "clip + AdamW on the HIP library, captured as one HIP graph (train.GraphedTrainStep)",
+           "value": round(steps / dt, 3), "unit": "training frame-pairs/s", "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "graphs": len(stepper.graphs), "eager_step_launches": launches,
+           "loss_trajectory": [round(float(x), 4) for x in losses],
+           "grad_parity": "tests/test_hip_train_step.py (reference step golden, oracle autograd, loop node vs tape at this crop)",
+           "peak_mem_GB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
+    del stepper, model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def visible_gpus() -> int:
     """GPUs this process would see, WITHOUT touching the HIP runtime (on this pool a process that has initialised the GPU must
     not fork + exec children): the visibility masks first, else the KFD topology (a node with simd_count > 0 is a GPU)."""
@@ -625,6 +676,14 @@ def main():
                     result["batch32"] = batch32_point(params, device, ref_cpu)
                 except Exception as exc:
                     result["batch32"] = {"error": repr(exc)}
+            if args.batch == 1 and not args.no_train_step:
+                try:
+                    log("training-step leg (configs[3] per GPU)")
+                    del model, flow
+                    torch.cuda.empty_cache()
+                    result["train_step"] = train_step_point(device)
+                except Exception as exc:
+                    result["train_step"] = {"error": repr(exc)}
         print(json.dumps(result), flush=True)
     if dist is not None:
         rank_barrier()

@@ -272,35 +272,49 @@ def _grad_sink(optimizer):
 
 
 class GraphedTrainStep:
-    """The whole optimisation step -- zero_grad, GT rotation, forward of both branches, sequence loss, backward, clip, fused
-    AdamW (train_flow.py:120-141) -- captured ONCE into a HIP graph and replayed: at the reference's training crop the step is
-    ~2 300 launches of 5-80 us each, and the host (autograd's Python nodes, ctypes calls) is as slow as the GPU; a replay costs
-    the host nothing.  What changes from step to step lives in device memory: the four inputs (static buffers copied into),
-    the step-dependent AdamW scalars and the clip coefficient (``pf_adamw_step_dev``: hyper = {1 - lr * wd, lr / bc1, sqrt(bc2),
-    clip coefficient}; the first three are written by the host before a replay, the last by the graph itself from
-    ``pf_sum_squares``).  Single process only: with more than one rank the gradient all-reduce sits between backward and clip, and
-    ``train_step`` (eager) is the path; ``add_noise`` (host-side numpy draw, train_flow.py:127-130) likewise.
+    """The whole optimisation step -- zero_grad, GT rotation, forward of both branches, sequence loss, backward, [gradient
+    all-reduce], clip, fused AdamW (train_flow.py:120-141) -- captured ONCE into HIP graphs and replayed: at the reference's
+    training crop the step is ~1 400 launches of 5-80 us each, and the host (autograd's Python nodes, ctypes calls) is as slow as
+    the GPU; a replay costs the host nothing.  What changes from step to step lives in device memory: the four inputs (static
+    buffers copied into), the step-dependent AdamW scalars and the clip coefficient (``pf_adamw_step_dev``: hyper = {1 - lr * wd,
+    lr / bc1, sqrt(bc2), clip coefficient}; the first three are uploaded by the host before a replay -- from a ring of pinned
+    slots, each guarded by an event, so a host that runs several replays ahead of the GPU never rewrites a slot whose copy is
+    still pending --, the last by the graph itself from ``pf_sum_squares``).
+
+    One rank: ONE graph.  More ranks (``torch.distributed`` initialised, or ``group=``): graph A = zero_grad ... backward + sink
+    flush, then the ONE eager collective of training -- ``parallel.all_reduce_sum_`` of the flat gradient buffer (RCCL over xGMI,
+    replacing DataParallel's reduce_add, train_flow.py:96) --, then graph B = gradient norm, clip coefficient, AdamW; the replica
+    checksum comparison of ``train_step`` runs every ``SYNC_CHECK_EVERY`` steps.  ``add_noise`` (a host-side numpy draw,
+    train_flow.py:127-130) stays with the eager ``train_step``.
 
         step = GraphedTrainStep(model, optimizer, scheduler, criterion, iters=12)
         loss, metrics = step(image1, image2, flow_gt, valid)        # 0-dim device tensors; float(...) them when needed
 
-    The first ``warmup`` calls run the eager ``train_step`` (lazy initialisations, allocator warm-up); the next call captures
-    (recording executes nothing) and replays."""
+    The returned tensors are views of ONE fresh copy of the step's outputs (a later replay does not overwrite them).  The first
+    ``warmup`` calls run the eager ``train_step`` (lazy initialisations, allocator warm-up); the next call captures (recording
+    executes nothing) and replays.  If the capture fails nothing is kept: the next call captures again."""
+
+    HYPER_SLOTS = 8
 
     def __init__(self, model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criterion: uniform_loss, iters: int = 12,
-                 gamma: float = 0.8, clip: float = 1.0, warmup: int = 2):
+                 gamma: float = 0.8, clip: float = 1.0, warmup: int = 2, group=None):
         self.model, self.opt, self.sched, self.crit = model, optimizer, scheduler, criterion
-        self.iters, self.gamma, self.clip, self.warmup = iters, gamma, clip, warmup
+        self.iters, self.gamma, self.clip, self.warmup = iters, gamma, clip, max(1, int(warmup))   # >= 1: first-use allocations cannot be captured
+        self.group = group
+        self.world = parallel._world(group)
         self.calls = 0
-        self.graph = None
+        self.graphs = None               # (graph,) or (graph A, graph B)
         self.static = None
-        self.out = None
+        self.out_vec = None              # [loss, metrics..., grad_norm] of the last replay (static, device)
+        self.out_keys = None
         dev = optimizer.flat.device
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self._hyper_host = torch.zeros(self.HYPER_SLOTS, 3, dtype=torch.float32).pin_memory()
+        self._hyper_ev = [None] * self.HYPER_SLOTS
+        self._hyper_n = 0
 
-    def _body(self):
-        """One step on the static inputs; every value that leaves it is a device tensor."""
+    def _body_a(self):
+        """zero_grad ... backward + sink flush on the static inputs; every value that leaves it is a device tensor."""
         net = getattr(self.model, "module", self.model)
         opt, crit = self.opt, self.crit
         i1, i2, gt, valid = self.static
@@ -318,6 +332,11 @@ class GraphedTrainStep:
             sink.abort()
             raise
         sink.flush()
+        return loss_a + loss_b, {**m_a, **m_b}
+
+    def _body_b(self, loss, metrics):
+        """Gradient norm, clip coefficient, AdamW on the (all-reduced) flat gradient; packs the step's outputs."""
+        opt = self.opt
         with torch.no_grad():
             opt.lib.sum_squares(opt.grad, opt._norm_part)
             norm = opt._norm_part.sum().sqrt()
@@ -325,38 +344,77 @@ class GraphedTrainStep:
             self.hyper[3:4].copy_((self.clip / (norm + 1e-6)).clamp(max=1.0).float().reshape(1))
             g = opt.param_groups[0]
             opt.lib.adamw_step_dev(opt.flat, opt.grad, opt.exp_avg, opt.exp_avg_sq, g["betas"][0], g["betas"][1], g["eps"], self.hyper)
-        return loss_a + loss_b, {**m_a, **m_b, "grad_norm": norm.float()}
+            keys = list(metrics) + ["grad_norm"]
+            vec = torch.stack([loss.float()] + [metrics[k].float() for k in metrics] + [norm.float()])
+        return vec, keys
 
     def _set_hyper(self):
         g = self.opt.param_groups[0]
         lr, wd, (b1, b2) = float(g["lr"]), float(g["weight_decay"]), g["betas"]
         t = self.opt.step_count + 1
-        self._hyper_host[0] = 1.0 - lr * wd
-        self._hyper_host[1] = lr / (1.0 - b1 ** t)
-        self._hyper_host[2] = math.sqrt(1.0 - b2 ** t)
-        self.hyper[:3].copy_(self._hyper_host, non_blocking=True)
+        k = self._hyper_n % self.HYPER_SLOTS
+        self._hyper_n += 1
+        if self._hyper_ev[k] is not None:
+            self._hyper_ev[k].synchronize()          # the copy that last read this slot has run (HYPER_SLOTS steps ago)
+        h = self._hyper_host[k]
+        h[0] = 1.0 - lr * wd
+        h[1] = lr / (1.0 - b1 ** t)
+        h[2] = math.sqrt(1.0 - b2 ** t)
+        self.hyper[:3].copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_ev[k] = ev
+
+    def _capture(self):
+        graphs = []
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._body_b(*self._body_a())
+            graphs.append(g)
+        else:
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                la = self._body_a()
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                out = self._body_b(*la)
+            graphs += [ga, gb]
+        return tuple(graphs), out
 
     def __call__(self, image1, image2, flow_gt, valid):
+        if parallel._world(self.group) != self.world:
+            raise _lib.PfError("GraphedTrainStep: the process group changed after construction "
+                               f"({self.world} -> {parallel._world(self.group)} ranks); build the stepper after init_process_group")
         self.calls += 1
         if self.calls <= self.warmup:
             loss, m = train_step(self.model, self.opt, self.sched, self.crit, image1, image2, flow_gt, valid, iters=self.iters,
-                                 gamma=self.gamma, clip=self.clip)
+                                 gamma=self.gamma, clip=self.clip, group=self.group)
             return loss, m
         self.opt._check_aliases()
-        if self.graph is None:
+        if self.graphs is None:
             self.static = tuple(t.detach().float().contiguous().clone() for t in (image1, image2, flow_gt, valid))
             self._set_hyper()
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = self._body()
+            try:
+                graphs, (vec, keys) = self._capture()
+            except BaseException:
+                self.static = None                   # nothing half-captured is kept (the sink was aborted by _body_a)
+                raise
+            self.graphs, self.out_vec, self.out_keys = graphs, vec, keys
         else:
             for dst, src in zip(self.static, (image1, image2, flow_gt, valid)):
                 dst.copy_(src)
             self._set_hyper()
-        self.graph.replay()
+        self.graphs[0].replay()
+        if self.world > 1:
+            parallel.all_reduce_sum_(self.opt.grad, self.group)
+            self.graphs[1].replay()
         self.opt.step_count += 1
         self.opt.grad_scale = 1.0
         _lib.bump_weights_epoch()       # the graph wrote the parameters through raw pointers: drop packed copies
         self.sched.step()
-        return self.out
+        if self.world > 1 and self.opt.step_count % SYNC_CHECK_EVERY == 1:
+            self.opt.assert_in_sync(self.group)
+        out = self.out_vec.clone()
+        return out[0], {k: out[i + 1] for i, k in enumerate(self.out_keys)}
