@@ -129,20 +129,6 @@ int pf_dccl_lookup_il(const float* coords,
                       const float* g_w2c, const float* g_w2c_il, float* own_out, float* raw_out,
                       int B, int H8, int W8, int ld, void* stream);
 
-/* Both branches' lookups of one iteration (core/prior_raft.py:185-188: corr_fn_A(coords1_A), corr_fn_B(coords1_B)) as ONE
- * launch: descs[0] and descs[1] are two pf_dccl_lookup_il problems of the same shape.  Alone a lookup moves 95 MB at
- * half the HBM rate; as two concurrent launches on two queues the pair took as long as back to back and cost a
- * cross-queue join (~10 us) on the critical chain -- one grid over both has neither. */
-typedef struct pf_lookup_desc {
-    const float* coords;        /* planar [B,2,H8,W8] */
-    const float* own[4];        /* this view's pyramid, level i: [B*N][(H8>>i)*(W8>>i)] */
-    const float* other[4];      /* the other view's pyramid */
-    const float* g_w2c;         /* [2,H8,W8] */
-    const float* g_w2c_il;      /* optional interleaved copy [N][2], or NULL */
-    float* own_out;             /* [B*N][ld] */
-    float* raw_out;             /* [B*N][ld] */
-} pf_lookup_desc;
-int pf_dccl_lookup_pair(const pf_lookup_desc* descs, int B, int H8, int W8, int ld, void* stream);
 
 /* DCCL.__call__ step 3 + the caller's add (core/corr.py:138, core/prior_raft.py:187-188):
  * out = own + img_rotate(raw, g_back), channel-last. */
@@ -299,6 +285,11 @@ int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, int H8, int W
 int pf_enc_stem(const float* img, const void* weight, const float* bias, float* out, void* out_split, int relu,
                 double* stats_out, int Bn, int H, int W, void* stream);
 
+/* Test support (tests/test_hip_kernels.py): fills the whole 160 KB LDS of every CU with `pattern` (e.g. 0x7fc00000, a NaN), so
+ * that a kernel which reads LDS it never wrote -- padding floats multiplied by zero weights -- shows up as NaNs in its output.
+ * No counterpart in the reference. */
+int pf_debug_dirty_lds(unsigned pattern, void* stream);
+
 /* Tiny-Cin direct convolution (7x7 2->128, 3x3 8->32, 3x3 32->16; core/update.py:171-178,87).
  * Weights packed [KH*KW][Cin][Cout]. */
 int pf_conv2d_direct(const float* in, int ld_in, int off_in, int cin,
@@ -352,11 +343,6 @@ int pf_norm_act(const float* y, const float* s, const float* t, const float* res
 int pf_flow_head_out(const float* x, int ld, int C, const float* weight, const float* bias,
                      float* coords1, float* delta, int ld_delta, int B, int H8, int W8, void* stream);
 
-/* The same for the two branches of an iteration (same shapes, two weight sets, two coords1 / delta destinations) as ONE
- * launch: branch B's FlowHead tail then needs no cross-queue dependency of its own (core/prior_raft.py:193-196, 206-209). */
-int pf_flow_head_out_pair(const float* x_a, const float* weight_a, const float* bias_a, float* coords1_a, float* delta_a,
-                          const float* x_b, const float* weight_b, const float* bias_b, float* coords1_b, float* delta_b,
-                          int ld, int C, int ld_delta, int B, int H8, int W8, void* stream);
 
 /* coords1 += delta (core/prior_raft.py:193,196).  delta: channel-last, 2 channels at column 0. */
 int pf_coords_add(float* coords1, const float* delta, int ld, int B, int H8, int W8, void* stream);

@@ -29,12 +29,6 @@ def _norm_bwd_blocks(Np: int) -> int:
     return max(1, min(Np // 16, 1024))
 
 
-class LookupDesc(C.Structure):
-    """Mirror of ``pf_lookup_desc`` (include/priorflow_hip.h)."""
-    _fields_ = [("coords", C.c_void_p), ("own", C.c_void_p * 4), ("other", C.c_void_p * 4), ("g_w2c", C.c_void_p),
-                ("g_w2c_il", C.c_void_p), ("own_out", C.c_void_p), ("raw_out", C.c_void_p)]
-
-
 class UnpackJob(C.Structure):
     """Mirror of ``pf_unpack_job`` (include/priorflow_hip.h)."""
     _fields_ = [("dw", _fp), ("db", _fp), ("gw", _fp), ("gb", _fp),
@@ -95,6 +89,7 @@ _SIGNATURES = {
     "pf_corr_pyramid_bf16x3": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_split_bf16": [_fp, _fp, C.c_long, _i, _fp],
     "pf_enc_stem": [_fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
+    "pf_debug_dirty_lds": [C.c_uint, _fp],
     "pf_gru_dx_finish": [_fp, _i, _fp, _i, _fp, _i, _fp, _i, _fp, _i, C.c_long, _i, _i, _fp],
     "pf_pack_conv_weights": [_fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _fp],
     "pf_unpack_wgrads": [C.POINTER(UnpackJob), _i, _fp],
@@ -105,7 +100,6 @@ _SIGNATURES = {
     "pf_bn_frozen_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, C.c_float, _i, _fp, _i, _fp, _fp, _fp, _i, C.c_long, _i, _fp],
     "pf_dccl_lookup": [_fp] * 12 + [_i, _i, _i, _i, _fp],
     "pf_dccl_lookup_il": [_fp] * 13 + [_i, _i, _i, _i, _fp],
-    "pf_dccl_lookup_pair": [C.c_void_p, _i, _i, _i, _i, _fp],
     "pf_dccl_combine": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_warp_gcorr": [_fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _fp],
     "pf_conf_stem": [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _fp],
@@ -121,7 +115,6 @@ _SIGNATURES = {
     "pf_channel_stats_final": [_fp, _i, _i, _i, _i, C.c_float, _fp, _fp, _fp],
     "pf_norm_act": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_flow_head_out": [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
-    "pf_flow_head_out_pair": [_fp] * 10 + [_i] * 6 + [_fp],
     "pf_coords_add": [_fp, _fp, _i, _i, _i, _i, _fp],
     "pf_upsample_flow": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
@@ -383,27 +376,6 @@ class PfLib:
             _ptr(g_w2c), _ptr(g_il), _ptr(own_out), _ptr(raw_out), B, H, W, own_out.shape[-1],
             self._stream(coords)), "pf_dccl_lookup_il")
 
-    def dccl_lookup_pair(self, items):
-        """items: two tuples (coords, pyr_own, pyr_other, g_w2c, own_out, raw_out, g_il) -- both branches' lookups, one launch."""
-        if len(items) != 2:
-            raise PfError("dccl_lookup_pair takes exactly two problems")
-        arr = (LookupDesc * 2)()
-        for d, (coords, pyr_own, pyr_other, g_w2c, own_out, raw_out, g_il) in zip(arr, items):
-            self._chk(coords, g_w2c, own_out, raw_out, g_il, *pyr_own, *pyr_other)
-            if coords.shape != items[0][0].shape or own_out.shape != items[0][4].shape:
-                raise PfError("dccl_lookup_pair: the two problems must have the same shape")
-            d.coords = coords.data_ptr()
-            for l in range(4):
-                d.own[l] = pyr_own[l].data_ptr()
-                d.other[l] = pyr_other[l].data_ptr()
-            d.g_w2c = g_w2c.data_ptr()
-            d.g_w2c_il = g_il.data_ptr() if g_il is not None else None
-            d.own_out, d.raw_out = own_out.data_ptr(), raw_out.data_ptr()
-        coords, own_out = items[0][0], items[0][4]
-        B, _, H, W = coords.shape
-        self._rc(self._dll.pf_dccl_lookup_pair(C.cast(arr, C.c_void_p), B, H, W, own_out.shape[-1], self._stream(coords)),
-                 "pf_dccl_lookup_pair")
-
     def dccl_combine(self, own, raw, g_back, out, B, H8, W8):
         self._chk(own, raw, g_back, out)
         self._rc(self._dll.pf_dccl_combine(_ptr(own), _ptr(raw), _ptr(g_back), _ptr(out), B, H8, W8,
@@ -496,6 +468,11 @@ class PfLib:
                                        None if stats is None else C.c_void_p(stats.data_ptr()), Bn, H, W, self._stream(images)),
                  "pf_enc_stem")
 
+    def debug_dirty_lds(self, pattern: int = 0x7fc00000, like=None):
+        """Test support: every CU's whole LDS is filled with `pattern` (default: a NaN) on the current stream (pf_debug_dirty_lds)."""
+        stream = self._stream(like) if like is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._rc(self._dll.pf_debug_dirty_lds(C.c_uint(pattern & 0xffffffff), stream), "pf_debug_dirty_lds")
+
     def conv2d_wgrad_small(self, x, nchw, off_in, cin, dy, off_dy, cout, dw, db, kh, kw, stride, B, Hout, Wout):
         """dw [Cout,Cin,KH,KW] (+= ), db [Cout] (+= or None) of a small-Cin convolution; x NCHW planes or channel-last."""
         self._chk(x, dy, dw, db)
@@ -534,17 +511,6 @@ class PfLib:
         self._rc(self._dll.pf_flow_head_out(_ptr(x), x.shape[-1], Cch, _ptr(weight), _ptr(bias), _ptr(coords1),
                                             _ptr(delta), 0 if delta is None else delta.shape[-1], B, H, W,
                                             self._stream(x)), "pf_flow_head_out")
-
-    def flow_head_out_pair(self, xa, wa, ba, c1a, da, xb, wb, bb, c1b, db, Cch):
-        """FlowHead.conv2 + coords1 += delta of both branches in one launch."""
-        self._chk(xa, wa, ba, c1a, da, xb, wb, bb, c1b, db)
-        B, _, H, W = c1a.shape
-        if xa.shape[-1] != xb.shape[-1] or (da is None) != (db is None) or (da is not None and da.shape[-1] != db.shape[-1]):
-            raise PfError("flow_head_out_pair: the two branches' buffers differ in shape")
-        self._rc(self._dll.pf_flow_head_out_pair(_ptr(xa), _ptr(wa), _ptr(ba), _ptr(c1a), _ptr(da),
-                                                 _ptr(xb), _ptr(wb), _ptr(bb), _ptr(c1b), _ptr(db),
-                                                 xa.shape[-1], Cch, 0 if da is None else da.shape[-1], B, H, W,
-                                                 self._stream(xa)), "pf_flow_head_out_pair")
 
     def coords_add(self, coords1, delta):
         self._chk(coords1, delta)

@@ -113,12 +113,13 @@ class GradSink:
         self.used = 0
         self.want = 0
         self.jobs: list = []
+        self.slow: list = []                      # convolutions with a frozen weight or bias (torch ops at flush)
         self.keep: list = []
 
     def begin(self, params) -> bool:
         """Starts a step; False (and stays off) unless every parameter carries a contiguous fp32 ``.grad`` already."""
         self.active = all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in params)
-        self.jobs, self.keep, self.used = [], [], 0
+        self.jobs, self.slow, self.keep, self.used = [], [], [], 0
         if not self.active:
             return False
         dev = params[0].device
@@ -142,8 +143,18 @@ class GradSink:
         return both[:op * taps * cin_pad].view(op, taps, cin_pad), both[op * taps * cin_pad:]
 
     def add(self, dw, db, w, b, o_off: int = 0, scale: float = 1.0):
+        """Registers the packed gradient of one convolution.  A frozen parameter (requires_grad=False: not in the optimizer, no
+        ``.grad`` -- e.g. frozen encoders under a trainable update block) is skipped, as autograd drops a gradient nobody asked
+        for; a convolution of which only the weight or only the bias is trainable takes the slow path of ``flush``."""
         cout, cin, kh, kw = w.shape
-        self.jobs.append((dw, db, w.grad, None if b is None else b.grad, cout, cin, kh * kw, dw.shape[2], o_off, float(scale)))
+        wg = w.grad if w.requires_grad else None
+        bg = b.grad if (b is not None and b.requires_grad) else None
+        if wg is None and bg is None:
+            return
+        if wg is None or (b is not None and bg is None):
+            self.slow.append((dw, db, wg, bg, cout, cin, kh, kw, o_off, float(scale)))
+            return
+        self.jobs.append((dw, db, wg, bg, cout, cin, kh * kw, dw.shape[2], o_off, float(scale)))
 
     def flush(self):
         """Adds every registered packed gradient into its parameters' ``.grad``; ends the step."""
@@ -151,15 +162,44 @@ class GradSink:
             if self.active and self.jobs:
                 _lib.load().unpack_wgrads(self.jobs)
                 STATS["hip"] += (len(self.jobs) + 15) // 16
+            if self.active:
+                for dw, db, wg, bg, cout, cin, kh, kw, o, scale in self.slow:
+                    if wg is not None:
+                        wg.add_(Conv.unpack_wgrad(dw[o:o + cout], cout, cin, kh, kw), alpha=scale)
+                    if bg is not None:
+                        bg.add_(db[o:o + cout], alpha=scale)
         finally:
             self.abort()
 
     def abort(self):
         """Ends the step without touching the gradients (an exception is on its way out)."""
-        self.jobs, self.keep, self.active = [], [], False
+        self.jobs, self.slow, self.keep, self.active = [], [], [], False
 
 
-SINK = GradSink()
+class _SinkByDevice:
+    """``autograd.SINK``: one GradSink per device, selected by the CURRENT device (the reference's caller is
+    ``nn.DataParallel`` -- worker threads, one device each --, so the training path may hold no state that two replicas share;
+    autograd runs a backward node with its forward's device current, so the autograd Functions, ``train_step`` and
+    ``GraphedTrainStep`` of one replica all see the same sink and another replica's step never touches it)."""
+
+    def __init__(self):
+        object.__setattr__(self, "_by_device", {})
+
+    def for_device(self, index=None) -> GradSink:
+        idx = torch.cuda.current_device() if index is None else int(index)
+        sinks = self._by_device
+        if idx not in sinks:
+            sinks[idx] = GradSink()
+        return sinks[idx]
+
+    def __getattr__(self, name):
+        return getattr(self.for_device(), name)
+
+    def __setattr__(self, name, value):
+        setattr(self.for_device(), name, value)
+
+
+SINK = _SinkByDevice()
 
 
 class WeightGrad:
@@ -358,8 +398,10 @@ class HipSmallConv(torch.autograd.Function):
         (xin,) = ctx.saved_tensors
         B, C, Ho, Wo, cout, kh, kw, stride = ctx.shape
         STATS["hip"] += 1
-        if SINK.active:                          # the kernel accumulates in the parameter layout: straight into .grad
-            w, b = ctx.wb
+        w, b = ctx.wb
+        if SINK.active and w.requires_grad and b.requires_grad and w.grad is not None and b.grad is not None:
+            # the kernel accumulates in the parameter layout: straight into .grad (a frozen stem takes the path below and
+            # autograd drops what was not asked for)
             lib.conv2d_wgrad_small(xin, True, 0, C, _rows(gy), 0, cout, w.grad, b.grad, kh, kw, stride, B, Ho, Wo)
             return None, None, None, None
         dw = torch.zeros(cout, C, kh, kw, device=gy.device)

@@ -353,11 +353,6 @@ struct PfLookupArgs {
     float* raw_out;                 // channel-last [B*N][ld]
     int B, H, W, ld;
 };
-// Both branches' lookups of an iteration as ONE grid (pf_dccl_lookup_pair): element idx < per belongs to p[0], the rest to p[1].
-struct PfLookupPairArgs {
-    PfLookupArgs p[2];
-    long per;                       // elements of one problem (a multiple of the block size for wave-uniform dispatch)
-};
 // One call = PF_LOOKUP_TPT consecutive taps (same level, same slow index a): their gather chains
 // (coords -> grid taps -> other-volume taps) are independent, so the loads of all of them are in
 // flight together.  Timing-only ablations (round 1; profiles/microbench_lookup.py is the harness) showed the kernel bound by the
@@ -439,11 +434,6 @@ PF_HD void pf_lookup_elem(long idx, const PfLookupArgs& a) {  // idx over B*N*(3
         a.raw_out[row * a.ld + k0 + j] = pf_apply_v(t, oth);
 #endif
     }
-}
-
-PF_HD void pf_lookup_pair_elem(long idx, const PfLookupPairArgs& a) {
-    if (idx < a.per) pf_lookup_elem(idx, a.p[0]);
-    else pf_lookup_elem(idx - a.per, a.p[1]);
 }
 
 // K4(c): rotate the raw cross-view lookup back and add the own-view lookup

@@ -726,21 +726,6 @@ int launch_flow_out(const PfFlowOutArgs& a, long total, void* stream) {
     }
     return pf_launch_elem<PfFlowOutArgs, pf_flow_out_elem>(a, total, stream);
 }
-// two problems of one shape (C, ld multiples of 4: the strip kernel); else two launches
-int launch_flow_out2(const PfFlowOutArgs& a, const PfFlowOutArgs& b, long total, void* stream) {
-    if (a.C % 4 == 0 && a.ld % 4 == 0 && b.C == a.C && b.ld % 4 == 0) {
-        const int spr = (a.W + 3) / 4;
-        const long strips = (long)a.B * a.H * spr;
-        long blocks = (2 * strips + 3) / 4;
-        if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-        PfFlowOutN pn; pn.p[0] = a; pn.p[1] = b;
-        hipLaunchKernelGGL(pf_flow_out_strip<2>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, pn, strips, spr);
-        return (int)hipGetLastError();
-    }
-    const int rc = launch_flow_out(a, total, stream);
-    return rc != 0 ? rc : launch_flow_out(b, total, stream);
-}
-
 // Region sums: one block per (pixel chunk k, image b); per-thread fp64 accumulators for up to 8
 // regions, wave shuffle reduction, then LDS across the 4 waves.  Deterministic (no atomics): the
 // host adds the nblk partials.
@@ -946,7 +931,6 @@ static int pf_lookup_dispatch(const PfLookupArgs& a, long total, void* stream) {
 #define PF_SEQ_LOSS_LAUNCH(a, stream) launch_seq_loss(a, stream)
 #define PF_SUMSQ_LAUNCH(a, stream) launch_sumsq(a, stream)
 #define PF_FLOW_OUT_LAUNCH(a, total, stream) launch_flow_out(a, total, stream)
-#define PF_FLOW_OUT2_LAUNCH(a, b, total, stream) launch_flow_out2(a, b, total, stream)
 #define PF_NORM_ACT_LAUNCH(a, total, stream) launch_norm_act(a, total, stream)
 #define PF_STATS_LAUNCH launch_stats
 #define PF_STATS_FINAL_LAUNCH launch_stats_final

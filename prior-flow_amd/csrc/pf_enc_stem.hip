@@ -29,7 +29,8 @@ constexpr int ST_WROW = ST_PIECES * 32;   // 704 bytes per channel in memory: pe
 constexpr int ST_WLDS = ST_WROW + 16;     // 720-byte LDS row stride: conflict-free ds_read_b128 over 32 channel rows
 constexpr int ST_PROWS = 21;              // input rows of a tile's patch: 2 * 8 + 5
 constexpr int ST_PW = 208;                // floats per patch row: 69 pixels x 3 channels = 207, padded
-constexpr int ST_LDS = 64 * ST_WLDS + ST_PROWS * ST_PW * 4;
+// + 16 bytes: the last fragment piece of patch row 20 reads floats 202 .. 209 of the row, two floats past it (x zero weights)
+constexpr int ST_LDS = 64 * ST_WLDS + ST_PROWS * ST_PW * 4 + 16;
 
 struct StemArgs {
     const float* img; const char* w; const float* bias;
@@ -103,6 +104,11 @@ pf_enc_stem_kernel(const StemArgs a) {
 #pragma unroll
         for (int u = 0; u < ST_PER; ++u)
             if (p_dst[u] >= 0) patch[p_dst[u]] = pv[u];
+        // the padding float of every row and the four floats behind the last row are read too (x zero weights): they must hold
+        // finite values -- LDS keeps what an earlier kernel left there, and NaN x 0 = NaN would end in column x0 + 31 of the tile
+        // and in the fused InstanceNorm statistics.  Every tile: the statistics buffer below aliases rows 0 .. 4.
+        if (tid < ST_PROWS) patch[tid * ST_PW + 207] = 0.f;
+        else if (tid < ST_PROWS + 4) patch[ST_PROWS * ST_PW + tid - ST_PROWS] = 0.f;
         __syncthreads();
 #ifndef PF_STEM_ABL_NO_STAGE
         if (tile + gridDim.x < a.ntiles) load_patch(tile + gridDim.x);      // in flight during this tile's MFMAs
@@ -201,6 +207,24 @@ pf_enc_stem_kernel(const StemArgs a) {
 }
 
 }  // namespace
+
+namespace {
+__global__ void __launch_bounds__(256) pf_dirty_lds_kernel(unsigned pattern, unsigned* sink) {
+    extern __shared__ unsigned lds_words[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) lds_words[i] = pattern;
+    __syncthreads();
+    if (lds_words[(threadIdx.x * 97) % (160 * 1024 / 4)] != pattern && sink) sink[0] = 1;      // keeps the stores alive
+}
+}  // namespace
+
+extern "C" int pf_debug_dirty_lds(unsigned pattern, void* stream) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_dirty_lds_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return (int)attr;
+    // one 160 KB workgroup per CU at a time, a few rounds so that every CU gets one
+    hipLaunchKernelGGL(pf_dirty_lds_kernel, dim3(1024), dim3(256), 160 * 1024, (hipStream_t)stream, pattern, (unsigned*)nullptr);
+    return (int)hipGetLastError();
+}
 
 extern "C" int pf_enc_stem(const float* img, const void* weight, const float* bias, float* out, void* out_split, int relu,
                            double* stats_out, int Bn, int H, int W, void* stream) {

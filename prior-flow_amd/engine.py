@@ -850,7 +850,8 @@ class EncoderPlan:
         self.norm1 = enc.norm1
         self.final = Conv.of(enc.conv2, precision)             # 1x1 128 -> 256
         self._bn_cache: Dict[int, tuple] = {}
-        self._bufs = None
+        self._bufs = None                           # the buffers of the shape being run
+        self._bufs_by_key: Dict[tuple, dict] = {}   # every resident shape's (captured HIP graphs hold pointers into them)
         # cnet in bf16x3 mode: every BatchNorm (eval) is folded into the convolution in front of it, ReLU and the residual add
         # move into the conv epilogues (PF_EPI_RELU / PF_EPI_RELU_RES), and the stride-1 3x3 convs read split twins through the
         # all-DMA kernel -- no normalisation pass, no statistics kernel, no input affine.  PRIORFLOW_FOLD_BN=0: the unfolded plan.
@@ -914,7 +915,7 @@ class EncoderPlan:
 
     def _alloc(self, Bn, H, W):
         key = (Bn, H, W)
-        if self._bufs is not None and self._bufs["key"] == key:
+        if self._select(key):
             return
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.dev)  # noqa: E731
         b = {"key": key}
@@ -925,7 +926,23 @@ class EncoderPlan:
         b["sc"] = [z(Bn * 128) for _ in range(3)]
         b["sh"] = [z(Bn * 128) for _ in range(3)]
         b["part"] = z(Bn * 1024 * 128 * 2, dt=torch.float64)       # [image][<= 1024 tiles or 128 chunks][C][2]
-        self._bufs = b
+        self._bufs = self._bufs_by_key[key] = b
+
+    def _select(self, key) -> bool:
+        """Makes the buffers of `key` current when they exist.  One set per resident shape: PriOr_RAFT keeps several workspaces
+        and the graphs captured on them, and a graph holds pointers into these buffers too (round 5: with a single cached set a
+        batch-32 forward freed the buffers the B = 1 graph replays into)."""
+        b = self._bufs_by_key.get(key)
+        if b is not None:
+            self._bufs = b
+        return b is not None
+
+    def release(self, H: int, W: int, batches) -> None:
+        """Drops the buffers of the shapes (Bn in `batches`, H, W): their workspace (and its graphs) left the model's cache."""
+        for key in [k for k in self._bufs_by_key if k[-2:] == (H, W) and k[-3] in batches]:
+            if self._bufs is self._bufs_by_key[key]:
+                self._bufs = None
+            del self._bufs_by_key[key]
 
     def run(self, images: torch.Tensor, out: torch.Tensor, epilogue: int, aux: Optional[torch.Tensor] = None,
             outs: Optional[torch.Tensor] = None, auxs: Optional[torch.Tensor] = None):
@@ -1003,7 +1020,7 @@ class EncoderPlan:
     # ---- cnet with folded BatchNorm (bf16x3) ---------------------------------------------------------------------------
     def _alloc_folded(self, Bn, H, W):
         key = ("fold", Bn, H, W)
-        if self._bufs is not None and self._bufs["key"] == key:
+        if self._select(key):
             return
         z = lambda *s_: torch.zeros(*s_, dtype=torch.float32, device=self.dev)  # noqa: E731
         b = {"key": key, "s2d": z(Bn * (H // 2) * (W // 2), 12)}
@@ -1015,7 +1032,7 @@ class EncoderPlan:
             b[f"xs{lvl}"] = [split_twin(rows, c, self.dev), split_twin(rows, c, self.dev)]
             b[f"y{lvl}"] = split_twin(rows, c, self.dev)
             b[f"r{lvl}"] = z(rows, c)
-        self._bufs = b
+        self._bufs = self._bufs_by_key[key] = b
 
     def _run_folded(self, images, out, epilogue, aux, outs, auxs):
         lib = self.lib

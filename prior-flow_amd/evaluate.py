@@ -197,3 +197,56 @@ def validate_FlowScape_regions(model, iters=12, scene="sunny", dataset=None):
     if dataset is None:
         raise FileNotFoundError("FlowScape is not available in this build: pass dataset=<iterable of samples>")
     return validate_regions(model, dataset, iters=iters, scene=scene)
+
+
+@torch.no_grad()
+def validate(model, dataset: Iterable, iters: int = 12, name: str = "synthetic", verbose: bool = True) -> Dict[str, float]:
+    """The body of the reference's plain validation loops (evaluate.py:337-366 ``validate_MPF``, :369-397 ``validate_FlowScape`` --
+    what ``train_flow.py:187-194`` calls every VAL_FREQ steps): ``model.eval()``, per sample pad, ``model(..., test_mode=True)``,
+    unpad; EPE = mean of sqrt(du^2 + dv^2) over the pixels of ALL samples, SEPE = mean over samples of the per-sample mean
+    great-circle distance.  The per-pixel maps come from ``pf_flow_metrics`` (one launch per sample), the sums stay on the device
+    in fp64 until the end.  Returns ``{name + "-epe", name + "-SEPE"}`` and prints the reference's line."""
+    lib = _lib.load()
+    was_training = getattr(model, "training", False)
+    model.eval()
+    epe_sum = None
+    pixels, sd_means = 0, []
+    for sample in dataset:
+        image1, image2, flow_gt = sample[0], sample[1], sample[2]
+        image1 = image1[None].cuda()
+        image2 = image2[None].cuda()
+        padder = InputPadder(image1.shape)
+        image1, image2 = padder.pad(image1, image2)
+        flow_pr = model(image1.contiguous(), image2.contiguous(), iters=iters, test_mode=True)
+        flow = padder.unpad(flow_pr[0])[None].float().contiguous()
+        gt = flow_gt[None].to(flow.device).float().contiguous()
+        epe = torch.empty(1, flow.shape[-2], flow.shape[-1], device=flow.device)
+        sd = torch.empty_like(epe)
+        lib.flow_metrics(flow, gt, epe, sd)
+        e = epe.double().sum()
+        epe_sum = e if epe_sum is None else epe_sum + e
+        pixels += epe.numel()
+        sd_means.append(sd.double().mean())
+    if epe_sum is None:
+        raise ValueError("validate: empty dataset")
+    if was_training:
+        model.train()           # (the reference's callers do this themselves, train_flow.py:196-198)
+    epe_v = float(epe_sum / pixels)
+    sd_v = float(torch.stack(sd_means).mean())
+    if verbose:
+        print("Validation (%s) EPE: %f, SEPE: %f" % (name, epe_v, sd_v))
+    return {f"{name}-epe": epe_v, f"{name}-SEPE": sd_v}
+
+
+def validate_MPF(model, iters=12, scene="EFT", dataset=None):
+    """evaluate.py:337-366.  The MPFDataset files are not available offline: pass ``dataset``."""
+    if dataset is None:
+        raise FileNotFoundError("MPFDataset is not available in this build: pass dataset=<iterable of samples>")
+    return validate(model, dataset, iters=iters, name=scene)
+
+
+def validate_FlowScape(model, iters=12, scene="sunny", dataset=None):
+    """evaluate.py:369-397."""
+    if dataset is None:
+        raise FileNotFoundError("FlowScape is not available in this build: pass dataset=<iterable of samples>")
+    return validate(model, dataset, iters=iters, name=f"FlowScape-{scene}")

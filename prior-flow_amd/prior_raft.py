@@ -88,13 +88,29 @@ class PriOr_RAFT(nn.Module):
             self._graphs.clear()
         return self._packed
 
+    WS_KEEP = 3                 # shapes kept resident (least recently used goes first); PRIORFLOW_WS_KEEP overrides
+    WS_BYTES = 128 << 30        # ... as long as their buffers stay under this many bytes (B = 32 at 512x1024 is ~27 GB)
+
     def _workspace(self, B, H, W, device) -> Workspace:
+        """The buffers of one (B, H, W) problem.  A few shapes stay resident, least recently used first out, together with the
+        HIP graphs captured on them: an evaluation loop over mixed sizes (or B = 1 / B = 32 in turn) re-uses its workspaces and
+        graphs instead of re-allocating ~1 GB and re-capturing 258 kernels per switch."""
         key = (B, H, W, str(device))
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is None:
             ws = Workspace(self._lib(), B, H, W, device)
-            self._ws = {key: ws}          # keep one shape resident (288 GB HBM, but be polite)
-            self._graphs.clear()
+            ws.nbytes = sum(t.numel() * t.element_size() for t in vars(ws).values() if isinstance(t, torch.Tensor)) + \
+                sum(t.numel() * t.element_size() for v in vars(ws).values() if isinstance(v, (list, tuple))
+                    for t in v if isinstance(t, torch.Tensor))
+        self._ws[key] = ws          # most recently used last
+        keep = max(1, int(os.environ.get("PRIORFLOW_WS_KEEP", self.WS_KEEP)))
+        while len(self._ws) > 1 and (len(self._ws) > keep or sum(w.nbytes for w in self._ws.values()) > self.WS_BYTES):
+            old = next(iter(self._ws))
+            del self._ws[old]
+            for gk in [gk for gk in self._graphs if (gk[0], gk[1], gk[2], gk[4]) == old]:
+                del self._graphs[gk]      # a graph holds pointers into its workspace
+            for plan in (self._enc_plans or ()):
+                plan.release(old[1], old[2], (2 * old[0], 4 * old[0]))      # ... and into the encoders' activation buffers
         return ws
 
     def _encoder_plans(self):

@@ -264,11 +264,13 @@ def _grad_sink(optimizer):
     """Starts autograd.GradSink for one step (the convolutions' weight gradients go straight into the ``.grad`` views of the flat
     buffer; PRIORFLOW_GRAD_SINK=0: through autograd's own accumulation as in round 3).  Call ``.flush()`` after backward."""
     from .autograd import SINK
+    dev = optimizer.flat.device
+    sink = SINK.for_device(dev.index if dev.index is not None else torch.cuda.current_device())     # this replica's own
     if os.environ.get("PRIORFLOW_GRAD_SINK", "1") != "0":
-        SINK.begin(optimizer.params)
+        sink.begin(optimizer.params)
     else:
-        SINK.active = False
-    return SINK
+        sink.active = False
+    return sink
 
 
 class GraphedTrainStep:

@@ -288,7 +288,7 @@ class LoopFn(torch.autograd.Function):
                     continue
                 lib.upsample_flow_bwd(S["c"][i + 1], S["mask"][i], gp[t][i].contiguous(), S["d_mask"][i], S["d_flow"][i])
                 lib.to_channel_last(S["d_flow"][i], 0, 2, S["d_delta"][i], 0)
-                n_launch += 3
+                n_launch += 2
             if live:
                 # mask = 0.25 * conv (update.py:134,157): the factor rides in the data gradient's epilogue; the weight
                 # gradient of that conv is scaled once, after the deferred launch
@@ -373,7 +373,8 @@ class LoopFn(torch.autograd.Function):
         stem_grads = []
         for name, x, off, dy in (("a.f1a", A["flow4"], 0, A["d_t_a"]), ("a.f1b", A["flow4"], 2, A["d_t_ba"]), ("b.f1", Bb["flow2"], 0, Bb["d_t"])):
             m = P.stems[name]
-            if SINK.active:     # accumulated in the parameter layout: straight into .grad
+            if SINK.active and m.weight.grad is not None and m.bias.grad is not None and m.weight.requires_grad and m.bias.requires_grad:
+                # accumulated in the parameter layout: straight into .grad (a frozen stem: autograd drops the returned gradient)
                 lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, m.weight.grad, m.bias.grad, 7, 7, 1, Bi, H8, W8)
                 stem_grads += [None, None]
                 continue

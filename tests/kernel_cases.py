@@ -187,19 +187,6 @@ def case_dccl(lib, dev):
     o_own, o_cross = po.dccl_lookup(co.cpu(), po.build_pyramid(vb), po.build_pyramid(va),
                                     g["b2aT_16x32"].cpu(), g["a2b_16x32"].cpu())
     check(corr_n, o_own + o_cross, 1e-3, "corr_b vs oracle (all pixels)")
-    # both directions as ONE launch (pf_dccl_lookup_pair): bit-identical to the two single launches
-    own_a, raw_a = torch.empty(N, LD, device=dev), torch.empty(N, LD, device=dev)
-    lib.dccl_lookup(co, pa_d, pb_d, gw, own_a, raw_a, g_il)
-    co_b = co.flip(-1).contiguous()                      # different coordinates for the second problem
-    own_b1, raw_b1 = torch.empty(N, LD, device=dev), torch.empty(N, LD, device=dev)
-    lib.dccl_lookup(co_b, pb_d, pa_d, g["b2aT_16x32"], own_b1, raw_b1)
-    pa2, pb2 = (torch.full((N, LD), 3.0, device=dev) for _ in range(2)), (torch.full((N, LD), 3.0, device=dev) for _ in range(2))
-    own_pa, raw_pa = pa2
-    own_pb, raw_pb = pb2
-    lib.dccl_lookup_pair([(co, pa_d, pb_d, gw, own_pa, raw_pa, g_il),
-                          (co_b, pb_d, pa_d, g["b2aT_16x32"], own_pb, raw_pb, None)])
-    assert torch.equal(own_pa, own_a) and torch.equal(raw_pa, raw_a), "pair launch, problem 0"
-    assert torch.equal(own_pb, own_b1) and torch.equal(raw_pb, raw_b1), "pair launch, problem 1"
     # padded row stride
     own2 = torch.full((N, 336), 7.0, device=dev)
     raw2 = torch.full((N, 336), 7.0, device=dev)
@@ -468,20 +455,6 @@ def case_flow_head_out(lib, dev):
     lib.flow_head_out(cl(x).to(dev), 256, w.permute(0, 2, 3, 1).reshape(2, 9, 256).contiguous().to(dev),
                       b.to(dev), c2, None)
     check(c2, c1, 0.0, "delta buffer is optional")
-    # both branches of an iteration in one launch (pf_flow_head_out_pair): the bits of two single launches
-    x2 = gc.uni("fho/x2", (2, 256, H8, W8), -1, 1)
-    w2 = gc.uni("fho/w2", (2, 256, 3, 3), -0.05, 0.05)
-    b2 = gc.uni("fho/b2", (2,), -0.1, 0.1)
-    pk = lambda t: t.permute(0, 2, 3, 1).reshape(2, 9, 256).contiguous().to(dev)      # noqa: E731
-    ca, cb = co.clone().to(dev), co.flip(0).clone().to(dev)
-    da, db = torch.zeros(2 * N, 4, device=dev), torch.zeros(2 * N, 4, device=dev)
-    lib.flow_head_out(cl(x).to(dev), 256, pk(w), b.to(dev), ca, da)
-    lib.flow_head_out(cl(x2).to(dev), 256, pk(w2), b2.to(dev), cb, db)
-    pa, pb = co.clone().to(dev), co.flip(0).clone().to(dev)
-    qa, qb = torch.zeros(2 * N, 4, device=dev), torch.zeros(2 * N, 4, device=dev)
-    lib.flow_head_out_pair(cl(x).to(dev), pk(w), b.to(dev), pa, qa, cl(x2).to(dev), pk(w2), b2.to(dev), pb, qb, 256)
-    assert torch.equal(pa, ca) and torch.equal(pb, cb) and torch.equal(qa, da) and torch.equal(qb, db), "pair launch != two launches"
-    assert float((da - db).abs().max()) > 1e-3
 
 
 def case_split_bf16(lib, dev):

@@ -85,3 +85,39 @@ def test_validate_regions_with_the_model(capsys):
             assert abs(res[name][key] - want[name][key]) <= 1e-5 * abs(want[name][key]) + 1e-7, (name, key)
     with pytest.raises(FileNotFoundError):
         ev.validate_MPF_regions(model)
+
+
+def test_plain_validate_loops_equal_the_references_arithmetic(capsys):
+    """validate_MPF / validate_FlowScape (evaluate.py:337-397: the in-training validation call of train_flow.py:187-194): EPE over
+    all pixels of all samples and SEPE as the mean of per-sample means, on the model's own flows, against the reference's
+    arithmetic spelled out in torch (sqrt of the summed squares; the golden-pinned great-circle distance); the model comes back in
+    the mode it was given in."""
+    from prior_flow_amd import evaluate as ev
+    from prior_flow_amd.modules import state_dict_shapes
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    model.load_state_dict(gc.det_state_dict(state_dict_shapes()), strict=True)
+    model = model.cuda().train()
+    data = []
+    for i in range(3):
+        i1, i2 = gc.synthetic_pair(1, 128, 256, seed=177 + i)
+        gt = torch.stack([gc.uni(f"val2/u{i}", (126, 250), -6, 6), gc.uni(f"val2/v{i}", (126, 250), -3, 3)])
+        data.append((i1[0, :, 1:127, 3:253].contiguous(), i2[0, :, 1:127, 3:253].contiguous(), gt, None))
+    res = ev.validate_MPF(model, iters=2, scene="EFT", dataset=data)
+    assert model.training
+    assert "Validation (EFT) EPE:" in capsys.readouterr().out
+    model.eval()
+    epes, sds = [], []
+    with torch.no_grad():
+        for i1, i2, gt, _ in data:
+            pad = ev.InputPadder(i1[None].shape)
+            a, b = pad.pad(i1[None].cuda(), i2[None].cuda())
+            flow = pad.unpad(model(a.contiguous(), b.contiguous(), iters=2, test_mode=True)[0]).cpu()
+            epes.append(torch.sum((flow - gt) ** 2, dim=0).sqrt().view(-1).numpy())
+            sds.append(float(ev.calculate_great_circle_distance(flow[None].cuda(), gt[None].cuda())[0].mean()))
+    want_epe, want_sd = float(np.mean(np.concatenate(epes))), float(np.mean(np.array(sds)))
+    assert abs(res["EFT-epe"] - want_epe) <= 1e-5 * want_epe and abs(res["EFT-SEPE"] - want_sd) <= 1e-5 * want_sd, (res, want_epe, want_sd)
+    res2 = ev.validate_FlowScape(model, iters=2, scene="sunny", dataset=data[:1])
+    assert set(res2) == {"FlowScape-sunny-epe", "FlowScape-sunny-SEPE"}
+    with pytest.raises(FileNotFoundError):
+        ev.validate_MPF(model)

@@ -395,3 +395,34 @@ def test_folded_stem_normalisation_is_bitwise_the_materialised_one(params, monke
     a, b = run("0"), run("1")
     assert float(a.abs().mean()) > 0.1
     assert torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_workspaces_and_graphs_of_several_shapes_stay_resident(params):
+    """an evaluation loop over mixed sizes (or B = 1 / B = 2 in turn) must not re-allocate its workspace and re-capture
+    its graph on every switch: the model keeps a few shapes resident (least recently used first out) together with the graphs
+    captured on them, and the results of a shape do not change when it comes back."""
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+    model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+    model.load_state_dict(params, strict=True)
+    model = model.cuda().eval()
+    shapes = [(1, 128, 256), (2, 128, 256), (1, 136, 216)]
+    pairs = {s: tuple(t.cuda() for t in gc.synthetic_pair(s[0], s[1], s[2], seed=5)) for s in shapes}
+    first, ws_ids, graph_ids = {}, {}, {}
+    with torch.no_grad():
+        for rnd in range(3):
+            for s in shapes:
+                out = model(*pairs[s], iters=2, test_mode=True)
+                key = (s[0], s[1], s[2], str(out.device))
+                if rnd == 0:
+                    first[s] = out.clone()
+                    ws_ids[s] = id(model._ws[key])
+                    graph_ids[s] = id(model._graphs[(s[0], s[1], s[2], 2, str(out.device))][0])
+                else:
+                    assert torch.equal(out, first[s])
+                    assert id(model._ws[key]) == ws_ids[s], "the workspace was re-allocated"
+                    assert id(model._graphs[(s[0], s[1], s[2], 2, str(out.device))][0]) == graph_ids[s], "the graph was re-captured"
+        assert len(model._ws) == 3
+        # a fourth shape pushes the least recently used one (and its graph) out
+        model(*(t.cuda() for t in gc.synthetic_pair(1, 128, 384, seed=5)), iters=2, test_mode=True)
+        assert len(model._ws) == 3 and (1, 128, 256, str(out.device)) not in model._ws
+        assert all((k[0], k[1], k[2]) != (1, 128, 256) for k in model._graphs)
