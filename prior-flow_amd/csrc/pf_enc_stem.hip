@@ -96,6 +96,8 @@ pf_enc_stem_kernel(const StemArgs a) {
         }
     };
     if ((long)blockIdx.x < a.ntiles) load_patch(blockIdx.x);
+    // (Round 5: starting the second workgroup of a CU half a tile late, so that one's stores run under the other's MFMAs, only
+    // added the delay -- 72 -> 77 / 79 / 86 us at 2 / 4 / 8 sleep rounds, profiles/r5_encoder_ablation.txt: a workgroup has 4 tiles.)
     for (long tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx = (int)(tile % a.tiles_x), ty = (int)((tile / a.tiles_x) % a.tiles_y);
         const long im = tile / per_img;
