@@ -668,6 +668,9 @@ pf_corr_ring_kernel(const CorrArgs a, const int ablate) {
 #ifndef PF_RS_PRIO
 #define PF_RS_PRIO 0
 #endif
+#ifndef PF_RS_SYNC               // 0: one s_barrier per K-step for all 8 waves (shipped); 1: counters in LDS (see "Synchronisation" below)
+#define PF_RS_SYNC 0
+#endif
 #ifdef PF_RS_STAMP               // diagnosis build: cycles per wave spent in barriers / behind waits / issuing stores
 __device__ unsigned long long pf_rs_dbg[2048 * 8 * 4];
 #define RS_T() __builtin_amdgcn_s_memtime()
@@ -676,7 +679,9 @@ constexpr int RS_SLOTS = 4;                          // divides the 8 K-steps of
 constexpr int RS_AHEAD = PF_RS_AHEAD;                // K-steps in flight (2 or 3)
 constexpr int RS_PITCH = 132;                        // floats per staging row: 2 x 64 targets + 16 bytes (conflict-free ds_write_b128)
 constexpr int RS_STAGE = 32 * RS_PITCH;              // floats per MFMA wave
-constexpr int RS_LDS = RS_SLOTS * RING_TILE + 4 * RS_STAGE * 4 + 4 * RING_STAGE * 4;
+constexpr int RS_CNT_OFF = RS_SLOTS * RING_TILE + 4 * RS_STAGE * 4 + 4 * RING_STAGE * 4;   // 16 counters (unsigned) behind the images
+constexpr int RS_LDS = RS_CNT_OFF + 64;
+constexpr unsigned RS_SPIN_CAP = 1u << 22;           // a poll loop gives up after this many rounds (a hang must not outlive the kernel)
 #define RS_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <bool MUL, int NCH>
@@ -707,6 +712,35 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
     auto tile_rp = [](int i) { return 2 * (i / (2 * NCH)) + (i & 1); };
     auto tile_ch = [](int i) { return (i >> 1) % NCH; };
     float* const stag_all = reinterpret_cast<float*>(ring + RS_SLOTS * RING_TILE);
+    constexpr bool FLAGSYNC = PF_RS_SYNC != 0;
+    // Synchronisation, experimental form (PF_RS_SYNC = 1; measured and NOT shipped: 111 us against 97 us per launch at 512x1024, 872
+    // against 834 us at batch 8, profiles/r5_corr_rs_flagsync.txt -- the LDS atomic + poll per K-step cost the four MFMA waves more
+    // (their side alone: 93 against 80 us) than the barrier waits it removes).  With one s_barrier per K-step for all eight waves a store wave that is held up in a
+    // global store (the CU accepts one 1-KB store per ~46 cycles; twelve are issued behind every barrier) arrives late and the
+    // four MFMA waves wait for it: 23 K of 167 K cycles per item in the barrier, 6 K without the stores (profiles/r5_corr_rs_stamps.txt).
+    // So nobody executes s_barrier in the loop.  Monotonic counters in LDS instead:
+    //   cnt[0]      K-step arrivals of the MFMA waves: a wave adds 1 once ITS pieces of K-step g have landed (counted vmcnt); the
+    //               fragments of K-step g may be read, and the slot of K-step g - 2 overwritten, once cnt[0] >= 4 (g + 1).  The
+    //               add is posted a block early and the poll read rides under three MFMAs that need nothing from memory;
+    //   cnt[4 + w]  staging images of MFMA wave w handed over (added behind the last ds_write of a tile's dump: LDS executes a
+    //               wave's instructions in order), polled by store wave w before it pulls an image;
+    //   cnt[8 + w]  images pulled by store wave w (added once its reads have returned), polled by MFMA wave w before a dump.
+    // A store wave may therefore lag a whole tile (eight K-steps) behind without holding anybody up.
+    unsigned* const cnt = reinterpret_cast<unsigned*>(ring + RS_CNT_OFF);
+    if (FLAGSYNC) {
+        if (tid < 16) cnt[tid] = 0u;
+        __syncthreads();
+    }
+    auto post = [&](unsigned* c) __attribute__((always_inline)) {             // one LDS atomic per wave
+        if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto spin_until = [&](const unsigned* c, unsigned target, bool sleepy) __attribute__((always_inline)) {
+        unsigned v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile unsigned*>(c));
+        for (unsigned n = 0; v < target && n < RS_SPIN_CAP; ++n) {
+            if (sleepy) __builtin_amdgcn_s_sleep(8);
+            v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile unsigned*>(c));
+        }
+    };
 
     if (wave < 4) {
         // ================================ MFMA waves ================================================================
@@ -824,6 +858,26 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
                 RS_SB();
             });
         };
+        // the two halves of a block on their own (PF_RS_SYNC = 1: the K-step synchronisation sits between them)
+        auto block_half = [&](bf16x8 (&ft)[4], int t, int ks, int k2, bool fresh) __attribute__((always_inline)) {
+            if (ablate & (4 | 1024)) return;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][2 + k2], (fresh && k2 == 0) ? zero16 : acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[2 + k2], fq[ks][k2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][k2], acc[t], 0, 0, 0);
+        };
+        auto block_half_gaps = [&](bf16x8 (&ft)[4], int t, int ks, auto&& gap) __attribute__((always_inline)) {   // second half, gap(i) behind MFMA i
+            ring_for<0, 3>([&](auto I) __attribute__((always_inline)) {
+                constexpr int m = decltype(I)::value;
+                if (!(ablate & (4 | 1024))) {
+                    if (m == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[1], fq[ks][3], acc[t], 0, 0, 0);
+                    else if (m == 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[3], fq[ks][1], acc[t], 0, 0, 0);
+                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[1], fq[ks][1], acc[t], 0, 0, 0);
+                }
+                RS_SB();
+                gap(I);
+                RS_SB();
+            });
+        };
         auto no_gap = [](auto) {};
         auto dump_piece = [&](int t, int g) __attribute__((always_inline)) {   // staging[query li][64 r + 32 c + 8 g + 4 lh ..+3], t = 2 r + c
             if (ablate & 16) { asm volatile("" :: "v"(acc[t])); return; }
@@ -842,6 +896,95 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
         unsigned long long st_wait = 0, st_bar = 0;
         const unsigned long long st_begin = RS_T();
 #endif
+        if (FLAGSYNC) {
+            using C1 = std::integral_constant<int, 1>;
+            // arrival for K-step 0 (its pieces are the oldest RS_AHEAD - 1 groups behind)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RS_AHEAD - 1)) : "memory");
+            post(cnt);
+            unsigned gstep = 0;                                        // global K-step
+            for (int tile = 0; tile < NT; ++tile) {
+                nxt_src = tile_src(tile + 1 < NT ? tile + 1 : tile);
+                ring_for<0, RING_NK>([&](auto KS) __attribute__((always_inline)) {
+                    constexpr int ks = decltype(KS)::value;
+                    constexpr int sbase = (ks % RS_SLOTS) * RING_TILE;
+                    constexpr int kd = ks + RS_AHEAD;
+                    const char* const dsrc = kd >= RING_NK ? nxt_src : cur_src;
+                    using DK = std::integral_constant<int, (kd % RING_NK) * 128>;
+                    const unsigned target = 4u * (gstep + 1u);
+                    // the poll read of this K-step's arrival count, in flight under the first half of the previous K-step's last block
+                    unsigned seen;
+                    {
+                        const unsigned ca = lds_base + RS_CNT_OFF;
+                        asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(ca) : "memory");
+                    }
+                    RS_SB();
+                    if (ks > 0 || tile > 0) {
+                        wait_for(fb, C1{});                            // everything but the poll read
+                        constexpr int pk = (ks + RING_NK - 1) % RING_NK;
+                        block_half(fb, 3, pk, 0, ks == 1);
+                    }
+                    RS_SB();
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(seen));
+                    if (__builtin_amdgcn_readfirstlane(seen) < target) spin_until(cnt, target, false);
+                    RS_SB();
+                    reads(fa, std::integral_constant<int, sbase>{});
+                    RS_SB();
+                    // second half of that block with this K-step's DMA pieces (slot of K-step g - 2: every wave is past it) in the gaps
+                    if (ks > 0 || tile > 0) {
+                        constexpr int pk = (ks + RING_NK - 1) % RING_NK;
+                        block_half_gaps(fb, 3, pk, [&](auto I) __attribute__((always_inline)) {
+                            dma_piece(dsrc, DK{}, kd % RS_SLOTS, decltype(I)::value);
+                        });
+                        dma_piece(dsrc, DK{}, kd % RS_SLOTS, 3);
+                    } else {
+                        ring_for<0, 4>([&](auto I) __attribute__((always_inline)) { dma_piece(dsrc, DK{}, kd % RS_SLOTS, decltype(I)::value); });
+                    }
+                    auto dump_gap = [&](int t, bool on) {
+                        return [&, t, on](auto I) __attribute__((always_inline)) {
+                            if constexpr (decltype(I)::value < 4) { if (on) dump_piece(t, decltype(I)::value); }
+                        };
+                    };
+                    RS_SB();
+                    reads(fb, std::integral_constant<int, sbase + 4096>{});
+                    RS_SB();
+                    wait_for(fa, C4{});
+                    if (ks == 0) block(fa, 0, ks, true, dump_gap(2, tile > 0));
+                    else block(fa, 0, ks, false, no_gap);
+                    RS_SB();
+                    reads(fa, std::integral_constant<int, sbase + 2 * 4096>{});
+                    RS_SB();
+                    wait_for(fb, C4{});
+                    if (ks == RING_NK - 1) spin_until(cnt + 8 + wave, (unsigned)tile, false);      // the store wave has pulled the previous image
+                    if (ks == 0) {
+                        block(fb, 1, ks, true, dump_gap(3, tile > 0));
+                        if (tile > 0) post(cnt + 4 + wave);                                        // image of tile - 1 complete (behind its last ds_write)
+                    } else if (ks == RING_NK - 1) block(fb, 1, ks, false, dump_gap(0, true));
+                    else block(fb, 1, ks, false, no_gap);
+                    RS_SB();
+                    // arrival for the next K-step: its pieces went out RS_AHEAD - 1 K-steps ago
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RS_AHEAD - 1)) : "memory");
+                    post(cnt);
+                    RS_SB();
+                    reads(fb, std::integral_constant<int, sbase + 3 * 4096>{});
+                    RS_SB();
+                    wait_for(fa, C4{});                                // the four youngest LDS operations are the reads above
+                    if (ks == RING_NK - 1) block(fa, 2, ks, false, dump_gap(1, true));
+                    else block(fa, 2, ks, ks == 0, no_gap);
+                    RS_SB();
+                    ++gstep;
+                });
+                cur_src = nxt_src;
+            }
+            wait_for(fb, C0{});
+            block(fb, 3, RING_NK - 1, false, no_gap);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dump_piece(2, g);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dump_piece(3, g);
+            post(cnt + 4 + wave);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the tail DMAs (re-reads) land before this wave leaves
+            return;
+        }
         for (int tile = 0; tile < NT; ++tile) {
             nxt_src = tile_src(tile + 1 < NT ? tile + 1 : tile);      // past the end the last tile is re-read (uniform vmcnt counts)
             ring_for<0, RING_NK>([&](auto KS) __attribute__((always_inline)) {
@@ -1019,6 +1162,18 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
     unsigned long long st_bar = 0, st_work = 0, st_last = 0;
     const unsigned long long st_begin = RS_T();
 #endif
+    if (FLAGSYNC) {
+        for (int tile = 0; tile < NT; ++tile) {
+            spin_until(cnt + 4 + sw, (unsigned)tile + 1u, true);       // image of this tile handed over
+            if (!(ablate & 8)) pull();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            post(cnt + 8 + sw);                                        // ... and free again
+            if (ablate & 8) continue;
+            ring_for<0, 8>([&](auto P) __attribute__((always_inline)) { pass(P, tile); });
+            finish(tile);
+        }
+        return;
+    }
     // The staging image of tile i is complete behind the barrier of K-step (i + 1, 1).  Interval (tile, ks): pass (ks - 1) & 7 of
     // data tile (ks >= 1 ? tile - 1 : tile - 2).
     for (int tile = 0; tile < NT; ++tile) {
