@@ -120,7 +120,7 @@ __device__ __forceinline__ void tile_epilogue_t(const pf_conv_desc& d, const f32
             float* o = base + p0 * ld + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (live(r)) o[(long)roff(r) * ld] = v[r];
+                if (live(r)) o[(long)roff(r) * ld] = v[r];      // (nt stores here: no effect, profiles/r5_ab_epilogue_nt.txt)
         }
         if (sbase != nullptr) {
             char* sp = reinterpret_cast<char*>(sbase) + ((p0 * lds + (col >> 5)) * 128 + 2 * (col & 31));

@@ -299,11 +299,13 @@ class GraphedTrainStep:
     HYPER_SLOTS = 8
 
     def __init__(self, model, optimizer: FlatAdamW, scheduler: OneCycleLinearLR, criterion: uniform_loss, iters: int = 12,
-                 gamma: float = 0.8, clip: float = 1.0, warmup: int = 2, group=None):
+                 gamma: float = 0.8, clip: float = 1.0, warmup: int = 2, group=None, split: bool = None):
         self.model, self.opt, self.sched, self.crit = model, optimizer, scheduler, criterion
         self.iters, self.gamma, self.clip, self.warmup = iters, gamma, clip, max(1, int(warmup))   # >= 1: first-use allocations cannot be captured
         self.group = group
         self.world = parallel._world(group)
+        # two graphs with the all-reduce between them; a single rank can ask for the split too (what it costs: profiles/)
+        self.split = (self.world > 1 or os.environ.get("PRIORFLOW_TRAIN_SPLIT_GRAPH", "0") == "1") if split is None else bool(split) or self.world > 1
         self.calls = 0
         self.graphs = None               # (graph,) or (graph A, graph B)
         self.static = None
@@ -369,7 +371,7 @@ class GraphedTrainStep:
 
     def _capture(self):
         graphs = []
-        if self.world == 1:
+        if not self.split:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self._body_b(*self._body_a())
@@ -409,8 +411,8 @@ class GraphedTrainStep:
                 dst.copy_(src)
             self._set_hyper()
         self.graphs[0].replay()
-        if self.world > 1:
-            parallel.all_reduce_sum_(self.opt.grad, self.group)
+        if self.split:
+            parallel.all_reduce_sum_(self.opt.grad, self.group)      # no-op with one rank
             self.graphs[1].replay()
         self.opt.step_count += 1
         self.opt.grad_scale = 1.0

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sync-every-step", action="store_true", help="with --graph: read the loss on the host after every step (exposes the host's per-step work)")
-    ap.add_argument("--graph", action="store_true", help="the step as one captured HIP graph (train.GraphedTrainStep; single rank)")
+    ap.add_argument("--graph", action="store_true", help="the step as captured HIP graph(s) (train.GraphedTrainStep; any number of ranks)")
     a = ap.parse_args()
     import torch.distributed as dist
     from prior_flow_amd import autograd as ag
@@ -37,10 +37,14 @@ def main():
     from prior_flow_amd.prior_raft import PriOr_RAFT
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    own_gpu = torch.cuda.device_count() >= world          # rehearsal on one card: every rank on cuda:0 over gloo (RCCL refuses that)
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if own_gpu else 0)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if own_gpu:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     H, W = a.size
     model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
     model.load_state_dict(det_state_dict(state_dict_shapes()), strict=True)
@@ -55,7 +59,8 @@ def main():
     crit = tr.uniform_loss(H, W, device=dev)
     losses = []
 
-    graphed = tr.GraphedTrainStep(model, opt, sched, crit, iters=a.iters, clip=1.0, warmup=1) if a.graph and world == 1 else None
+    # one rank: one graph; more ranks: graph A, the eager all-reduce of the flat gradient buffer, graph B (train.GraphedTrainStep)
+    graphed = tr.GraphedTrainStep(model, opt, sched, crit, iters=a.iters, clip=1.0, warmup=1) if a.graph else None
 
     ap_sync = a.sync_every_step
 
@@ -89,7 +94,8 @@ def main():
         print(json.dumps({"metric": "training pairs/sec (forward+backward+AdamW)", "value": round(world * a.batch / (ms / 1e3), 3),
                           "unit": "pairs/s", "n_gpus": world, "ms_per_step": round(ms, 2), "steps": a.steps,
                           "config": {"workload": f"train_step {H}x{W} iters={a.iters} batch/GPU={a.batch}",
-                                     "hip_graph": graphed is not None},
+                                     "hip_graph": graphed is not None, "graphs": len(graphed.graphs) if graphed is not None else 0,
+                                     "backend": dist.get_backend() if world > 1 else None, "ranks_share_one_gpu": not own_gpu},
                           "hip_launches_per_step": ag.STATS["hip"] // a.steps,
                           "torch_conv_launches_per_step": ag.STATS["torch"] // a.steps,
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
