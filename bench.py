@@ -51,7 +51,7 @@ H, W, ITERS = 512, 1024, 12
 # `stats` = --kernel-trace --stats of the graph replay, `pmc` = the FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_traffic.py).
 # `in_replay_us` and `traffic` are attached only when an entry matches the run's workload; otherwise they are null with a note.
 PROFILE_INDEX = "profile_index.json"
-PROFILE = {"stats": None, "pmc": None, "note": "no workload selected yet"}      # set by select_profile()
+PROFILE = {"stats": None, "pmc": None, "round": None, "note": "no workload selected yet"}      # set by select_profile()
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 # what a loop of v_mfma_f32_32x32x16_bf16 and nothing else sustains on all 256 CUs with operands that toggle like real data
@@ -124,7 +124,8 @@ def select_profile(batch, gpus):
         entries = []
     for e in entries:
         if all(e.get(k) == v for k, v in want.items()):
-            PROFILE.update(stats=e.get("stats"), pmc=e.get("pmc"), note="profiles/%s entry for %s" % (PROFILE_INDEX, want))
+            PROFILE.update(stats=e.get("stats"), pmc=e.get("pmc"), round=e.get("round"),
+                           note="profiles/%s entry for %s" % (PROFILE_INDEX, want))
             return
     PROFILE.update(stats=None, pmc=None, note="profiles/%s has no entry for %s: in_replay_us / traffic not reported "
                                               "(the committed profiles are of other workloads)" % (PROFILE_INDEX, want))
@@ -254,7 +255,12 @@ def profile_kernels(model, i1, i2):
         ("conv2d", "conv", lambda d, Bc, H8, W8, like: conv_name(d, Bc, H8, W8),
              lambda d, Bc, H8, W8, like: sum(2.0 * Bc * H8 * W8 * x.cout * x.kh * x.kw * (x.c0 + x.c1) for x in d)),
         ("corr_pyramid", "corr", lambda *a: "pf_corr_kernel", lambda f1, f2, lv, Bc, H8, W8: corr_bytes(Bc, H8, W8, f1.shape[-1])),
-        ("corr_pyramid_bf16x3", "corr", lambda *a: "pf_corr_kernel", lambda f1, f2, lv, Bc, H8, W8, c: corr_bytes(Bc, H8, W8, c)),
+        # bf16x3: the role-split kernel (round 5) on maps with W/8 % 64 == 0 and H/8 % 8 == 0 unless PRIORFLOW_CORR_RING says otherwise
+        ("corr_pyramid_bf16x3", "corr",
+             lambda f1, f2, lv, Bc, H8, W8, c: ("pf_corr_rs_kernel" if W8 % 64 == 0 and H8 % 8 == 0 and c == 256
+                                                and os.environ.get("PRIORFLOW_CORR_RING", "2") == "2" else
+                                                "pf_corr_ring_kernel" if os.environ.get("PRIORFLOW_CORR_RING") == "1" else "pf_corr_kernel"),
+             lambda f1, f2, lv, Bc, H8, W8, c: corr_bytes(Bc, H8, W8, c)),
         # SURVEY.md 8(d), one branch: own 10x10 patch x 4 B x 4 levels read + 324 x 4 B written; cross <= 81 x 4 taps x 4 B x 4
         # levels read + 324 x 4 B written = 9 376 B per pixel (76.8 MB at 64x128)
         ("dccl_lookup", "lookup", lambda *a, **k: "pf_lookup", lambda coords, *a, **k: px(coords) * (1600.0 + 1296.0 + 5184.0 + 1296.0)),
@@ -309,7 +315,8 @@ def profile_kernels(model, i1, i2):
     peak_mfma = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     how = "avg_launch_us: the kernel alone on the chip (single-stream eager pass, HIP events, dispatch gap subtracted); " \
           "in_replay_us: its rocprofv3 average inside the captured multi-stream forward (%s)" % (
-              ("profiles/" + PROFILE["stats"]) if PROFILE["stats"] else PROFILE["note"])
+              ("profiles/%s: the committed round-%s profile, taken on ANOTHER box than the one being timed -- boxes differ by up "
+               "to +-4 %%" % (PROFILE["stats"], PROFILE.get("round"))) if PROFILE["stats"] else PROFILE["note"])
 
     def obj(kind, name):
         work, ms, n = by[(kind, name)]

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Per-forward kernel breakdown from a rocprofv3 --kernel-trace CSV of `bench.py`.
 usage: summarize_trace.py <kernel_trace.csv> [forward_index]
-The window runs from one pf_corr_kernel launch pair to the next (one steady-state forward)."""
+The window runs from one corr-build (pf_corr_kernel / pf_corr_rs_kernel) launch pair to the next (one steady-state forward)."""
 import collections
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "pf_corr_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "pf_corr_kernel" in r["Kernel_Name"] or "pf_corr_rs_kernel" in r["Kernel_Name"] or "pf_corr_ring_kernel" in r["Kernel_Name"]]
 starts = idx[0::2]
 if len(sys.argv) > 2:
     k = int(sys.argv[2])
