@@ -115,11 +115,13 @@ class GradSink:
         self.jobs: list = []
         self.slow: list = []                      # convolutions with a frozen weight or bias (torch ops at flush)
         self.keep: list = []
+        self.join_streams: list = []              # streams that still write packed gradients (train_loop's deferred launches)
 
     def begin(self, params) -> bool:
         """Starts a step; False (and stays off) unless every parameter carries a contiguous fp32 ``.grad`` already."""
         self.active = all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in params)
         self.jobs, self.slow, self.keep, self.used = [], [], [], 0
+        self.join_streams = []
         if not self.active:
             return False
         dev = params[0].device
@@ -159,6 +161,8 @@ class GradSink:
     def flush(self):
         """Adds every registered packed gradient into its parameters' ``.grad``; ends the step."""
         try:
+            for st in self.join_streams:
+                torch.cuda.current_stream().wait_stream(st)
             if self.active and self.jobs:
                 _lib.load().unpack_wgrads(self.jobs)
                 STATS["hip"] += (len(self.jobs) + 15) // 16
@@ -173,7 +177,9 @@ class GradSink:
 
     def abort(self):
         """Ends the step without touching the gradients (an exception is on its way out)."""
-        self.jobs, self.slow, self.keep, self.active = [], [], [], False
+        for st in self.join_streams:          # (also on the way out of a failed step: later work must not overtake the side stream)
+            torch.cuda.current_stream().wait_stream(st)
+        self.jobs, self.slow, self.keep, self.join_streams, self.active = [], [], [], [], False
 
 
 class _SinkByDevice:

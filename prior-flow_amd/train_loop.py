@@ -21,6 +21,7 @@ Reference lines: core/update.py:81-99 (BasicMotionEncoder), :117-136 (BasicUpdat
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -344,43 +345,58 @@ class LoopFn(torch.autograd.Function):
             lib.conv2d_wgrad(_flat(x0), off0, c0, _flat(dy), off_dy, cout, dw, db, m.kh, m.kw, Bi, H8, W8,
                              x1=None if x1 is None else _flat(x1), off1=off1, c1=c1)
 
-        # (the chain's convolutions first: their output gradients were produced on this stream; the side stream is joined in
-        # front of the motion encoders' weight gradients)
-        for t, S in (("a", A), ("b", Bb)):
-            hs = S["h"]
-            wg(t + ".m2", S["mh"], 0, 256, S["d_mask"], 0, 576)
-            wg(t + ".m0", hs[1:], 0, 128, S["d_mh"], 0, 256)
-            wg(t + ".fh2", S["fh"], 0, 256, S["d_delta"], 0, 4)
-            wg(t + ".fh1", hs[1:], 0, 128, S["d_fh"], 0, 256)
-            wg(t + ".q2", S["rhr2"], 0, 128, S["d_q2"], 0, 128, x1=S["x"], off1=0, c1=256)
-            wg(t + ".zr2", S["h1"], 0, 128, S["d_zr2"], 0, 256, x1=S["x"], off1=0, c1=256)
-            wg(t + ".q1", S["rhr1"], 0, 128, S["d_q1"], 0, 128, x1=S["x"], off1=0, c1=256)
-            wg(t + ".zr1", hs[:iters], 0, 128, S["d_zr1"], 0, 256, x1=S["x"], off1=0, c1=256)
-        wg("a.out", A["cat"], 0, 272, A["d_out"], 0, 124)
-        wg("b.out", Bb["cat"], 0, 256, Bb["d_out"], 0, 128)
-        main.wait_stream(side)
-        for t, S in (("a", A), ("b", Bb)):
-            wg(t + ".c1", S["corr"], 0, 324, S["d_c1"], 0, 256)
-        wg("a.c2", A["c1"], 0, 256, A["d_cat"], 0, 128)
-        wg("b.c2", Bb["c1"], 0, 256, Bb["d_cat"], 0, 192)
-        wg("a.f2a", A["t_a"], 0, 128, A["d_cat"], 128, 64)
-        wg("a.f2b", A["t_ba"], 0, 128, A["d_cat"], 192, 64)
-        wg("b.f2", Bb["t"], 0, 128, Bb["d_cat"], 192, 64)
-        wg("a.cf2", A["cf1"], 0, 32, A["d_cat"], 256, 16)
-        wg("a.cf1", A["conf_in"], 0, 8, A["d_cf1"], 0, 32)
-        for t in "ab":          # mask = 0.25 * conv: the output gradient stored for m2 is the un-scaled one
-            P.acc[t + ".m2"].scale = 0.25
-        stem_grads = []
-        for name, x, off, dy in (("a.f1a", A["flow4"], 0, A["d_t_a"]), ("a.f1b", A["flow4"], 2, A["d_t_ba"]), ("b.f1", Bb["flow2"], 0, Bb["d_t"])):
-            m = P.stems[name]
-            if SINK.active and m.weight.grad is not None and m.bias.grad is not None and m.weight.requires_grad and m.bias.requires_grad:
-                # accumulated in the parameter layout: straight into .grad (a frozen stem: autograd drops the returned gradient)
-                lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, m.weight.grad, m.bias.grad, 7, 7, 1, Bi, H8, W8)
-                stem_grads += [None, None]
-                continue
-            dw, db = torch.zeros_like(m.weight), torch.zeros_like(m.bias)
-            lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, dw, db, 7, 7, 1, Bi, H8, W8)
-            stem_grads += [dw, db]
+        # Round 5: with the gradient sink on, nothing on this stream reads a weight gradient before the sink's flush (the autograd
+        # nodes only register their packed buffers), so the deferred launches -- 3.5 ms of chip-filling kernels -- go to the side
+        # stream and run beside the correlation pyramids' and the encoders' backward (6 ms of mostly small kernels); the sink joins
+        # the stream before it unpacks.  Without the sink the gradients are handed to autograd right away: same stream, as before.
+        defer_side = bool(SINK.active) and os.environ.get("PRIORFLOW_TRAIN_WGRAD_SIDE", "1") != "0"
+        wg_stream = side if defer_side else main
+        if defer_side:
+            ev_iter = torch.cuda.Event()
+            ev_iter.record(side)                   # the iterations' side chains (d f1 / d f2, pyramid and motion-encoder gradients) ...
+            main.wait_event(ev_iter)               # ... are what this node returns: the calling stream waits for them, not for the launches below
+            side.wait_stream(main)                 # every output gradient of the chain has been produced
+        with torch.cuda.stream(wg_stream):
+            # (the chain's convolutions first: their output gradients were produced on this stream; the side stream is joined in
+            # front of the motion encoders' weight gradients)
+            for t, S in (("a", A), ("b", Bb)):
+                hs = S["h"]
+                wg(t + ".m2", S["mh"], 0, 256, S["d_mask"], 0, 576)
+                wg(t + ".m0", hs[1:], 0, 128, S["d_mh"], 0, 256)
+                wg(t + ".fh2", S["fh"], 0, 256, S["d_delta"], 0, 4)
+                wg(t + ".fh1", hs[1:], 0, 128, S["d_fh"], 0, 256)
+                wg(t + ".q2", S["rhr2"], 0, 128, S["d_q2"], 0, 128, x1=S["x"], off1=0, c1=256)
+                wg(t + ".zr2", S["h1"], 0, 128, S["d_zr2"], 0, 256, x1=S["x"], off1=0, c1=256)
+                wg(t + ".q1", S["rhr1"], 0, 128, S["d_q1"], 0, 128, x1=S["x"], off1=0, c1=256)
+                wg(t + ".zr1", hs[:iters], 0, 128, S["d_zr1"], 0, 256, x1=S["x"], off1=0, c1=256)
+            wg("a.out", A["cat"], 0, 272, A["d_out"], 0, 124)
+            wg("b.out", Bb["cat"], 0, 256, Bb["d_out"], 0, 128)
+            if not defer_side:
+                main.wait_stream(side)
+            for t, S in (("a", A), ("b", Bb)):
+                wg(t + ".c1", S["corr"], 0, 324, S["d_c1"], 0, 256)
+            wg("a.c2", A["c1"], 0, 256, A["d_cat"], 0, 128)
+            wg("b.c2", Bb["c1"], 0, 256, Bb["d_cat"], 0, 192)
+            wg("a.f2a", A["t_a"], 0, 128, A["d_cat"], 128, 64)
+            wg("a.f2b", A["t_ba"], 0, 128, A["d_cat"], 192, 64)
+            wg("b.f2", Bb["t"], 0, 128, Bb["d_cat"], 192, 64)
+            wg("a.cf2", A["cf1"], 0, 32, A["d_cat"], 256, 16)
+            wg("a.cf1", A["conf_in"], 0, 8, A["d_cf1"], 0, 32)
+            for t in "ab":          # mask = 0.25 * conv: the output gradient stored for m2 is the un-scaled one
+                P.acc[t + ".m2"].scale = 0.25
+            stem_grads = []
+            for name, x, off, dy in (("a.f1a", A["flow4"], 0, A["d_t_a"]), ("a.f1b", A["flow4"], 2, A["d_t_ba"]), ("b.f1", Bb["flow2"], 0, Bb["d_t"])):
+                m = P.stems[name]
+                if SINK.active and m.weight.grad is not None and m.bias.grad is not None and m.weight.requires_grad and m.bias.requires_grad:
+                    # accumulated in the parameter layout: straight into .grad (a frozen stem: autograd drops the returned gradient)
+                    lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, m.weight.grad, m.bias.grad, 7, 7, 1, Bi, H8, W8)
+                    stem_grads += [None, None]
+                    continue
+                dw, db = torch.zeros_like(m.weight), torch.zeros_like(m.bias)
+                lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, dw, db, 7, 7, 1, Bi, H8, W8)
+                stem_grads += [dw, db]
+        if defer_side:
+            SINK.join_streams.append(side)
         n_launch += 29 + 3
         STATS["hip"] += n_launch
         d_net_a, d_net_b = _nchw(gh["a"].contiguous(), B, H8, W8), _nchw(gh["b"].contiguous(), B, H8, W8)
