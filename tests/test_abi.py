@@ -122,3 +122,16 @@ def test_no_unsafe_packed_fp32_instructions(built_lib):
     assert len(bundles) >= 4 and sum(a.count("v_mfma") for a in bundles) > 100, "device code not found"
     bad = [line for asm in bundles for line in scan.unsafe_packed(asm)]
     assert not bad, bad[:5]
+
+
+def test_design_numbers_are_the_committed_profiles():
+    """DESIGN.md section 6 must quote the files it cites.  The figures block of DESIGN.md is the verbatim output of
+    profiles/design_numbers.py over the committed profiles/r5_final_* files; regenerate with `python profiles/design_numbers.py --write`."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("design_numbers", os.path.join(root, "profiles", "design_numbers.py"))
+    dn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dn)
+    text = open(os.path.join(root, "DESIGN.md")).read()
+    a, e = text.index(dn.BEGIN) + len(dn.BEGIN), text.index(dn.END)
+    assert text[a:e].strip() == dn.build().strip(), "DESIGN.md's generated block is stale: python profiles/design_numbers.py --write"
