@@ -88,8 +88,8 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision
         const long tiles4 = B * ((g.H + 3) / 4) * ((g.W + 31) / 32), tiles8 = B * ((g.H + 7) / 8) * ((g.W + 31) / 32);
         const long wgs128 = tiles4 * ngroups * ((max_cout + 127) / 128);
         static const int force8 = [] { const char* e = getenv("PRIORFLOW_CONV_TH8"); return e ? atoi(e) : 0; }();   // A/B knob
-        if (force8 && g.kh == g.kw && g.kh > 1) return 5;
-        if (max_cout <= 64 && g.kh == g.kw && g.kh > 1 && tiles8 * ngroups >= 512) return 5;
+        if (force8 > 0 && g.kh == g.kw && g.kh > 1) return 5;
+        if (force8 >= 0 && max_cout <= 64 && g.kh == g.kw && g.kh > 1 && tiles8 * ngroups >= 512) return 5;     // -1: never (A/B)
         return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
     }
     const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;

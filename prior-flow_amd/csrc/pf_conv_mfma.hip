@@ -862,6 +862,7 @@ int conv_ws_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g, int ma
         if (grp.d[i].stats_out != nullptr || grp.d[i].in_scale != nullptr) return 0;
     const long wgs256 = (long)(g.M / g.N) * ((g.H + 7) / 8) * ((g.W + 31) / 32) * ngroups * ((max_cout + 63) / 64);
     // (measured: the 256-px tile wins for the 3x3 convs, -2 % at B=1; for 1x5 / 5x1 its taller halo costs more than the weights save)
+    if (ws >= 3 && g.kh == 3 && wgs256 >= 256) return 2;       // A/B: the 256 px x 64 channel roles kernel for Cout <= 64 as well
     return (ws >= 2 && g.kh == 3 && max_cout > 64 && wgs256 >= 256) ? 2 : 1;
 }
 
