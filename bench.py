@@ -221,6 +221,8 @@ def profile_kernels(model, i1, i2):
     def conv_name(descs, Bc, H8, W8):
         tile = lib.conv2d_tile(descs, Bc, H8, W8)
         d0 = descs[0]
+        if tile == 6:      # the weights-stationary kernel of the encoders' 3x3 64 -> 64 convolutions (round 5)
+            return "pf_enc_conv64_kernel"
         roles = lib.conv2d_roles(descs, Bc, H8, W8) if tile in (3, 4, 5) else 0
         if roles >= 16:    # pre-split operands: the all-DMA kernel, <NT, KH, KW, WN> exactly as rocprof names it
             r = roles - 16

@@ -122,7 +122,11 @@ static int conv_dma_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g
 extern "C" int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
     ConvGroups grp; ConvGeom g; int max_cout;
     const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
-    return rc != PF_OK ? rc : conv_tile(g, ngroups, max_cout, descs[0].precision);
+    if (rc != PF_OK) return rc;
+    const int tile = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    // 6: the weights-stationary kernel of the encoders' 3x3 64 -> 64 convolutions (pf_enc_conv.hip): statistics partials per
+    // (row, 32-column strip) instead of per 8-row tile
+    return ((tile == 5 || tile == 3) && pf_enc_conv64_applies(grp, ngroups, g, max_cout)) ? 6 : tile;
 }
 
 extern "C" int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
@@ -152,6 +156,8 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
         if (!descs[i].in0 || (descs[i].c1 > 0 && !descs[i].in1)) return PF_ERR_BAD_ARG;   // fp32 operands needed from here on
         if (descs[i].pre) return PF_ERR_BAD_SHAPE;                                          // accumulator start values: all-DMA kernel only
     }
+    // tile 5 (Cout <= 64 on a big map) with 64 input channels: the weights-stationary kernel, bit-identical to the halo kernel
+    if ((tile_id == 5 || tile_id == 3) && pf_enc_conv64_applies(grp, ngroups, g, max_cout)) return pf_enc_conv64_launch(grp, g, s);
     switch (tile_id) {
         case 0: case 1: case 2: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
         case 3: return pf_conv_part1_launch(grp, ngroups, g, max_cout, s);

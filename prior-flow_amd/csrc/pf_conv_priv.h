@@ -349,6 +349,10 @@ int pf_conv_part3_launch(const pfconv::ConvGroups& grp, int ngroups, const pfcon
 int pf_conv_ws256_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t stream);
 int pf_conv_ws_choice(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout);
 
+// pf_enc_conv.hip: the weights-stationary kernel of the encoders' 3x3 64 -> 64 convolutions (round 5)
+bool pf_enc_conv64_applies(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout);
+int pf_enc_conv64_launch(const pfconv::ConvGroups& grp, const pfconv::ConvGeom& g, hipStream_t stream);
+
 // pf_conv_dma.hip: launcher of the all-DMA kernel.  `roles` as in pf_conv2d_roles (1: 128-px tile, 2: 256 px x 64 channels).
 int pf_conv_dma_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, int nt, int roles,
                        hipStream_t stream);

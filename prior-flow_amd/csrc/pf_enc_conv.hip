@@ -1,0 +1,337 @@
+// pf_enc_conv64: the encoders' 3x3 convolutions with 64 input and 64 output channels at 1/2 resolution (core/extractor.py:16-17,
+// ResidualBlock conv1 / conv2 of layer1; fnet: 4B images of 256 x 512 at 512x1024), PF_PREC_BF16X3 arithmetic, with the WEIGHTS
+// STATIONARY (round 5).
+//
+// The halo kernel (pf_conv_halo_kernel<2,3,3,.,8>) re-stages the layer's 147 KB of split weights for every 256-pixel tile -- more
+// bytes than the tile's input halo (87 KB) and output (64 KB) together -- and its staging and matrix phases do not overlap
+// (profiles/r5_encoder_ablation.txt: loop 108 us = data path alone 57 + matrix alone 51, of 155 us).  Here a workgroup keeps the
+// weights for its whole life:
+//   * W_hi, the bf16 high halves, of the wave's 32 output channels x all K = 576 in REGISTERS (36 fragments = 144 VGPRs: the
+//     MFMA's B operand);
+//   * W_lo, the low halves of all 64 output channels, in LDS (73.7 KB, one ds_read_b128 per K-step);
+// and walks DOWN a strip of 32 columns in steps of 4 rows: the input lives in a 10-row ring in LDS (the 6 rows a step reads + the
+// 4 new rows of the next step, staged -- affine + ReLU of the previous layer's norm, bf16 hi|lo split -- while the step multiplies),
+// so a pixel is fetched once per strip (+ 2 halo columns), not once per tile and chunk.  8 waves = 2 channel tiles x 4 rows, one
+// 32 x 32 accumulator each; one barrier per step.  K order, pass order and the statistics' summation order are the halo kernel's:
+// outputs and fused InstanceNorm partials are BIT-IDENTICAL to it (tests/test_hip_kernels.py).
+// LDS: 73 728 + 10 x 34 x 256 = 160 768 B of the 163 840.
+#include <stdlib.h>
+#include "pf_conv_priv.h"
+
+namespace {
+using namespace pfconv;
+
+constexpr int EC_ROWB = 34 * 256;                    // bytes of a ring row: 34 pixels x 2 chunks x {hi[32], lo[32]} bf16
+constexpr int EC_RING = 10;
+constexpr int EC_KSTEPS = 36;                        // 2 chunks x 9 taps x 2 K-steps of 16 channels
+constexpr int EC_WLO = EC_KSTEPS * 2048;             // [k-step][channel tile][k half][32 channels][16 B]
+constexpr int EC_AFF = EC_WLO + EC_RING * EC_ROWB;   // input affine of the image: scale[64], shift[64] fp32
+constexpr int EC_LDS = EC_AFF + 512;
+constexpr int EC_WROW = 9 * 64 * 4;                  // bytes of one output channel's packed weights: [tap][64 ch as 2 x {hi[32], lo[32]}]
+#ifndef PF_EC_ABL                                    // timing-only diagnosis builds: 1 no staging, 2 no epilogue, 4 no K loop
+#define PF_EC_ABL 0
+#endif
+#ifndef PF_EC_DEFER                                  // 1: a step's outputs are written at the start of the wave's NEXT half-step (A/B)
+#define PF_EC_DEFER 0
+#endif
+
+struct EcArgs {
+    const float* in; int ld_in;                      // input rows (channel offset folded in)
+    const char* w; const float* bias;
+    float* out; int ld_out;                          // output rows (channel offset folded in)
+    const float* in_scale; const float* in_shift; int in_relu;
+    double* stats;                                   // [image][H * strips][64][2] or NULL: one partial per (row, strip)
+    float scale; int relu;
+    int Bn, H, W, seg, nseg, strips;                 // seg: rows per work item (a multiple of 4); nseg = H / seg; strips = W / 32
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void ec_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ec_for<I + 1, N>(f);
+    }
+}
+
+__global__ void __launch_bounds__(512)
+pf_enc_conv64_kernel(const EcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int abl = PF_EC_ABL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int nt = wave >> 2, mr = wave & 3;         // channel tile, row of the step
+    // work item: (image, segment of rows, strip of 32 columns); consecutive workgroups = neighbouring strips of one segment
+    const int sx = blockIdx.x % a.strips;
+    const int sg = (blockIdx.x / a.strips) % a.nseg;
+    const int im = blockIdx.x / (a.strips * a.nseg);
+    const int x0 = 32 * sx, yseg = sg * a.seg;
+    const int nsteps = a.seg >> 2;
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds_base = (unsigned)(unsigned long)(lds_char*)lds;
+    const unsigned ring_base = lds_base + EC_WLO;
+
+    // K order = the halo kernel's (bit-identical sums): chunk c of 32 channels, tap, K-step h of that chunk; inside an MFMA the
+    // lane half kh multiplies channels 16 kh + 8 h .. + 7 of the chunk (the staging kernels' K permutation)
+    // ---- weights: W_lo -> LDS, W_hi -> registers -------------------------------------------------------------------
+    for (int e = tid; e < EC_KSTEPS * 128; e += 512) {
+        const int s = e >> 7, r = e & 127, tnt = r >> 6, kh = (r >> 5) & 1, n = r & 31;
+        const int c = s / 18, tap = (s >> 1) % 9, h = s & 1;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.w + (long)(32 * tnt + n) * EC_WROW + (tap * 64 + c * 32) * 4 + 64 + (kh * 16 + h * 8) * 2);
+        *reinterpret_cast<f32x4*>(lds + s * 2048 + tnt * 1024 + kh * 512 + n * 16) = v;
+    }
+    if (tid < 128) {
+        float v = tid < 64 ? 1.f : 0.f;
+        if (a.in_scale != nullptr) v = tid < 64 ? a.in_scale[(long)im * 64 + tid] : a.in_shift[(long)im * 64 + tid - 64];
+        reinterpret_cast<float*>(lds + EC_AFF)[tid] = v;
+    }
+    bf16x8 whi[EC_KSTEPS];
+    {
+        const char* wrow = a.w + (long)(32 * nt + li) * EC_WROW + lh * 32;
+#pragma unroll
+        for (int s = 0; s < EC_KSTEPS; ++s) {
+            const int c = s / 18, tap = (s >> 1) % 9, h = s & 1;
+            whi[s] = *reinterpret_cast<const bf16x8*>(wrow + (tap * 64 + c * 32) * 4 + h * 16);
+        }
+    }
+    __syncthreads();                                     // the affine is in LDS
+
+    // ---- staging of input rows.  Thread -> 4 channels f4 of column cg (and, for the first 64 threads, of a halo column):
+    // a half of a step's new rows (2 rows) is 3 items per thread, all addresses by shifts
+    const int f4 = tid & 15, cg = tid >> 4;              // cg 0..31
+    const bool affine = a.in_scale != nullptr, in_relu = a.in_relu != 0;
+    const float* const in_img = a.in + (long)im * a.H * a.W * a.ld_in + 4 * f4;
+    // LDS byte offset of this thread's hi half inside a pixel: chunk (f4 >> 3), 16-byte piece ((f4 & 7) >> 1), half piece (f4 & 1)
+    const unsigned st_piece = (unsigned)((f4 >> 3) * 8 + ((f4 & 7) >> 1)), st_in = (unsigned)((f4 & 1) * 8);
+    auto item_rc = [&](int u, int& r, int& col) -> bool {   // item u of a half: (row r in 0..1, column 0..33); false: no such item
+        if (u < 2) { r = u; col = cg + 1; return true; }     // columns 1..32: the strip itself
+        r = cg >> 1; col = (cg & 1) * 33;                    // columns 0 and 33 (the halo), rows 0..1: threads with cg < 4
+        return cg < 4;
+    };
+    auto item_src = [&](int rr, int col, bool& ok) -> const float* {      // rr: row relative to the segment; col 0..33
+        const int y = yseg + rr, x = x0 - 1 + col;
+        ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
+        return ok ? in_img + ((long)y * a.W + x) * a.ld_in : in_img;
+    };
+    auto item_store = [&](int rr, int col, f32x4 x, bool ok) __attribute__((always_inline)) {
+        if (affine) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + EC_AFF + 16 * f4), sh = *reinterpret_cast<const f32x4*>(lds + EC_AFF + 256 + 16 * f4);
+            x = x * sc + sh;
+            if (in_relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+        }
+        const f32x4 v = ok ? x : f32x4{0.f, 0.f, 0.f, 0.f};              // zero padding applies AFTER the affine
+        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+        const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
+        const bf16x4 lo = __builtin_convertvector(rest, bf16x4);
+        const int slot = (rr + 1 + EC_RING) % EC_RING;
+        char* px = lds + EC_WLO + slot * EC_ROWB + col * 256;
+        const unsigned sw = (unsigned)(col & 15);
+        *reinterpret_cast<bf16x4*>(px + ((st_piece ^ sw) << 4) + st_in) = hi;
+        *reinterpret_cast<bf16x4*>(px + (((st_piece + 4) ^ sw) << 4) + st_in) = lo;
+    };
+    // prologue: rows -1 .. 4 of the segment (what step 0 reads) = three halves
+    for (int hf = 0; hf < 3; ++hf)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            int r, col;
+            if (!item_rc(u, r, col)) continue;
+            bool ok;
+            const float* src = item_src(2 * hf + r - 1, col, ok);
+            item_store(2 * hf + r - 1, col, *reinterpret_cast<const f32x4*>(src), ok);
+        }
+
+    // ---- fragment addresses: pixel column (li + kx), 16-byte piece = (8 c + h [+ 4 for lo]) ^ (2 kh) ^ swizzle(column)
+    unsigned a_kx[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) a_kx[kx] = (unsigned)((li + kx) * 256 + ((((li + kx) & 15) ^ (lh << 1)) << 4));
+    const unsigned wlo_lane = lds_base + (unsigned)(nt * 1024 + lh * 512 + li * 16);
+    const float bias = a.bias[32 * nt + li];
+
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    // ---- main loop in HALF-steps.  The two waves of a SIMD (wave w and w + 4: the same row, the two channel tiles) run the same
+    // program; in step they would both multiply, then both convert / store.  Waves 4-7 therefore run half a step behind waves 0-3
+    // (K-steps 0..17 of step t in half-step 2 t + grp, K-steps 18..35 + epilogue in 2 t + 1 + grp): while one wave of a SIMD converts
+    // the next rows or stores its outputs, its partner's MFMAs keep the matrix pipe busy.  One barrier per half-step.  The ring
+    // holds exactly the union of what the two groups read (rows 4 t - 1 .. 4 t + 8): the rows of step t + 1 are loaded in half-step
+    // 2 t and written in 2 t + 1 into the slots of rows only step t - 1 read, which both groups have left by then.
+    const int grp = nt;
+    f32x16 acc = zero16;
+    f32x4 st[5]; bool st_ok[5];
+    auto item5 = [&](int u, int& r, int& col) -> bool {      // item u of a step's 4 new rows: (row 0..3, column 0..33)
+        if (u < 4) { r = u; col = cg + 1; return true; }      // columns 1..32
+        r = cg >> 1; col = (cg & 1) * 33;                     // the halo columns 0 and 33: threads with cg < 8
+        return cg < 8;
+    };
+    unsigned rbase[3] = {0u, 0u, 0u};
+    bf16x8 ahi[2], alo[2], blo[2];
+    auto frag = [&](auto S, int buf) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        constexpr int c = s / 18, tap = (s >> 1) % 9, h = s & 1, ky = tap / 3, kx = tap % 3;
+        constexpr unsigned phi = (unsigned)((c * 8 + h) << 4), plo = phi + 64;
+        const unsigned ar = rbase[ky] + a_kx[kx];
+        const unsigned ad_hi = ar ^ phi, ad_lo = ar ^ plo;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ahi[buf]) : "v"(ad_hi));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(alo[buf]) : "v"(ad_lo));
+        if constexpr (s * 2048 < 65536)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(blo[buf]) : "v"(wlo_lane), "n"(s * 2048));
+        else {
+            const unsigned wl2 = wlo_lane + 32 * 2048;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(blo[buf]) : "v"(wl2), "n"((s - 32) * 2048));
+        }
+#endif
+    };
+    auto khalf = [&](auto HALF) __attribute__((always_inline)) {     // K-steps 18 HALF .. 18 HALF + 17; the operands of K-step s + 1 are read while s multiplies
+        constexpr int s0 = decltype(HALF)::value * (EC_KSTEPS / 2);
+        frag(std::integral_constant<int, s0>{}, s0 & 1);
+        ec_for<s0, s0 + EC_KSTEPS / 2>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value, b = s & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (s + 1 < s0 + EC_KSTEPS / 2) {
+                frag(std::integral_constant<int, s + 1>{}, b ^ 1);
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ahi[b]), "+v"(alo[b]), "+v"(blo[b]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ahi[b]), "+v"(alo[b]), "+v"(blo[b]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the halo kernel's pass order: x_lo * w_hi, x_hi * w_lo, x_hi * w_hi
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[b], whi[s], s == 0 ? zero16 : acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[b], blo[b], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[b], whi[s], acc, 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
+        // this wave's row of step t: 32 pixels x 32 channels; acc[r] = pixel (r & 3) + 8 (r >> 2) + 4 lh, channel 32 nt + li
+        if (abl & 2) { asm volatile("" :: "v"(acc)); return; }
+        const int y = yseg + 4 * t + mr;
+        // values + statistics in the accumulator layout (a lane = one channel, 16 pixels), then a 4 x 4 transpose inside every quad
+        // of lanes (DPP: lane j of a quad ends up with pixel j's four channels) so that a lane stores 16 contiguous bytes: 4 store
+        // instructions of 1 KB per wave and step instead of 16 of 256 B -- the CU issues one vector-memory instruction per ~46
+        // cycles whatever its size, and the narrow stores alone kept that path busy for 40 % of the kernel
+        double s1 = 0.0, s2 = 0.0;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[r] = a.relu ? fmaxf(acc[r] + bias, 0.f) : (acc[r] + bias) * a.scale;
+            const double dv = (double)v[r];
+            s1 += dv; s2 += dv * dv;
+        }
+        const bool b0 = lane & 1, b1 = lane & 2;
+        auto xch = [&](float& x0, float& x1, bool odd, auto CTRL) __attribute__((always_inline)) {   // 2 x 2 exchange with the lane CTRL selects
+            const float send = odd ? x0 : x1;
+            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), decltype(CTRL)::value, 0xf, 0xf, true));
+            x0 = odd ? recv : x0;
+            x1 = odd ? x1 : recv;
+        };
+        using X1 = std::integral_constant<int, 0xB1>;      // quad_perm [1,0,3,2]: lane ^ 1
+        using X2 = std::integral_constant<int, 0x4E>;      // quad_perm [2,3,0,1]: lane ^ 2
+        float* const ot = a.out + (((long)im * a.H + y) * a.W + x0 + 4 * lh + (lane & 3)) * a.ld_out + 32 * nt + (li & ~3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            xch(v[4 * g], v[4 * g + 1], b0, X1{});
+            xch(v[4 * g + 2], v[4 * g + 3], b0, X1{});
+            xch(v[4 * g], v[4 * g + 2], b1, X2{});
+            xch(v[4 * g + 1], v[4 * g + 3], b1, X2{});
+            // lane (quad position j) now holds pixel 8 g + j (+ 4 lh): channels 4 (li >> 2) .. + 3
+            const f32x4 w4 = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(ot + (long)(8 * g) * a.ld_out) = w4;
+        }
+        if (a.stats != nullptr) {
+            // InstanceNorm statistics of the stored values: fp64 sum / sum of squares per channel over the row's 32 pixels, one
+            // partial per (row, strip) -- [image][H * strips][64][2], reduced by pf_channel_stats_final (pf_conv2d_tile code 6)
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lh == 0) {
+                double* qd = a.stats + ((((long)im * a.H + y) * a.strips + sx) * 64 + 32 * nt + li) * 2;
+                qd[0] = s1; qd[1] = s2;
+            }
+        }
+    };
+    // Order inside a half-step: a wave that finished a step in its previous half-step writes that step's outputs FIRST, then runs
+    // its K-steps; its partner goes straight into its K-steps.  So the partner's MFMAs run while this wave stores, and this wave's
+    // MFMAs run while the partner converts the staged rows at the end of its half-step.
+    for (int hs = 0; hs <= 2 * nsteps + 1; ++hs) {
+        // (a raw barrier: __syncthreads() also waits vmcnt(0), i.e. for the output stores just issued and for the row loads in
+        // flight -- up to 2 us per half-step; only the LDS traffic has to be complete here)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int ts = hs >> 1;                              // the step whose successor's rows are staged in this pair of half-steps
+        const bool more = ts + 1 < nsteps && !(abl & 1);
+        if (!(hs & 1)) {                                     // loads of rows 4 ts + 5 .. 4 ts + 8, in flight during this half-step
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                int r, col;
+                const bool live = item5(u, r, col) && more;
+                const float* src = item_src(4 * ts + 5 + r, col, st_ok[u]);
+                st_ok[u] = st_ok[u] && live;
+                st[u] = live ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const int q = hs - grp;                              // this wave's own half-step
+        const int t = q >> 1;
+#if PF_EC_DEFER
+        if (q >= 2 && !(q & 1) && q <= 2 * nsteps && !(abl & 4)) epilogue(t - 1);       // the step finished in half-step q - 1
+#endif
+        if (q >= 0 && q < 2 * nsteps && !(abl & 4)) {
+            if (!(q & 1)) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+                    rbase[ky] = __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(((4 * t + mr + ky) % EC_RING) * EC_ROWB));
+                khalf(std::integral_constant<int, 0>{});
+            } else {
+                khalf(std::integral_constant<int, 1>{});
+#if !PF_EC_DEFER
+                epilogue(t);
+#endif
+            }
+        }
+        if (hs & 1) {                                        // convert + write the rows loaded in the previous half-step
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                int r, col;
+                if (item5(u, r, col) && more) item_store(4 * ts + 5 + r, col, st[u], st_ok[u]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Whether pf_conv2d hands this launch to pf_enc_conv64_kernel (PRIORFLOW_ENC_CONV64=0: never): one group, 3x3 stride 1, 64 -> 64,
+// fp32 rows in and out, LINEAR or RELU epilogue, a map of whole 32-column strips and 4-row steps that fills the chip.
+bool pf_enc_conv64_applies(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout) {
+    static const int mode = [] { const char* e = getenv("PRIORFLOW_ENC_CONV64"); return e ? atoi(e) : 1; }();     // 2: also on small maps (tests)
+    if (mode <= 0 || ngroups != 1) return false;
+    const pf_conv_desc& d = grp.d[0];
+    return d.precision == PF_PREC_BF16X3 && g.kh == 3 && g.kw == 3 && g.stride == 1 && d.c0 == 64 && d.c1 == 0 && d.cout == 64 &&
+           max_cout == 64 && d.in0 != nullptr && d.out != nullptr && d.out_split == nullptr && d.pre == nullptr &&
+           (d.epilogue == PF_EPI_LINEAR || d.epilogue == PF_EPI_RELU) && (g.W % 32) == 0 && (g.H % 8) == 0 &&
+           (d.ld0 % 4) == 0 && (d.off0 % 4) == 0 && (d.ld_out % 4) == 0 && (d.off_out % 4) == 0 &&
+           (mode >= 2 || (long)(g.M / g.N) * (g.H / 8) * (g.W / 32) >= 256);
+}
+
+int pf_enc_conv64_launch(const pfconv::ConvGroups& grp, const pfconv::ConvGeom& g, hipStream_t stream) {
+    const pf_conv_desc& d = grp.d[0];
+    EcArgs a;
+    a.in = d.in0 + d.off0; a.ld_in = d.ld0;
+    a.w = reinterpret_cast<const char*>(d.weight); a.bias = d.bias;
+    a.out = d.out + d.off_out; a.ld_out = d.ld_out;
+    a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_relu = d.in_relu;
+    a.stats = d.stats_out; a.scale = d.scale; a.relu = d.epilogue == PF_EPI_RELU;
+    a.Bn = g.M / g.N; a.H = g.H; a.W = g.W;
+    // rows per work item: the longest segment (a divisor of H, a multiple of 8: the weights are loaded once per item and a strip's
+    // rows are fetched once) that still gives every CU an item (4 images of 256 x 512: 64 rows, 256 items -- two rounds of
+    // 32-row items measured 146-159 us against 139)
+    a.seg = 8;
+    for (int sg = g.H; sg > 8; sg -= 8)
+        if (g.H % sg == 0 && (long)a.Bn * (g.H / sg) * (g.W / 32) >= 256) { a.seg = sg; break; }
+    a.nseg = g.H / a.seg; a.strips = g.W / 32;
+    const long items = (long)a.Bn * a.nseg * a.strips;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_enc_conv64_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(pf_enc_conv64_kernel, dim3((unsigned)items), dim3(512), EC_LDS, stream, a);
+    return (int)hipGetLastError();
+}

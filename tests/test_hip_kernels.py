@@ -403,7 +403,7 @@ def _check_fused_stats(lib, dev, cv, xin, cin, cout, B, h, w, expect_tile):
     d = cv.desc(xin, 0, cin, out, 0, EPI_LINEAR)
     tile = lib.conv2d_tile([d], B, h, w)
     assert tile == expect_tile
-    th = 8 if tile == 5 else 4
+    th = 8 if tile == 5 else 1 if tile == 6 else 4      # 6: the weights-stationary kernel, one partial per row and strip
     nblk = ((h + th - 1) // th) * ((w + 31) // 32)
     part = torch.full((B, nblk, cout, 2), float("nan"), dtype=torch.float64, device=dev)
     d.stats_out = part.data_ptr()
@@ -490,7 +490,9 @@ def test_stem_as_space_to_depth_conv(lib, dev, prec):
 
 def test_conv_8row_tile_layer1_size(lib, dev):
     """Tile 5 (256 px x 64 ch, 8-row halo tile) is only chosen once the map can fill the chip:
-    run the encoder layer-1 shapes at 256x512 (core/extractor.py:122-127) against torch conv2d."""
+    run the encoder layer-1 shapes at 256x512 (core/extractor.py:122-127) against torch conv2d.  Round 5: the 3x3 64 -> 64
+    convolutions of that size take the weights-stationary kernel (pf_conv2d_tile code 6, csrc/pf_enc_conv.hip); the 4x4 stem
+    form stays on tile 5."""
     from prior_flow_amd._lib import EPI_LINEAR, EPI_RELU, PREC_BF16X3
     from prior_flow_amd.engine import Conv, pack_mfma, stem_s2d_weight
     B, h, w = 2, 256, 512
@@ -506,10 +508,10 @@ def test_conv_8row_tile_layer1_size(lib, dev):
     xin = kc.cl(x).to(dev)
     out = torch.empty(B * h * w, 64, device=dev)
     d = cv.desc(xin, 0, 64, out, 0, EPI_LINEAR, in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True)
-    assert lib.conv2d_tile([d], B, h, w) == 5
+    assert lib.conv2d_tile([d], B, h, w) == 6
     lib.conv2d([d], B, h, w, xin)
     kc.check(kc.uncl(out.cpu(), B, h, w), want, 1.5e-4, "8-row tile 3x3 affine")
-    _check_fused_stats(lib, dev, cv, xin, 64, 64, B, h, w, expect_tile=5)
+    _check_fused_stats(lib, dev, cv, xin, 64, 64, B, h, w, expect_tile=6)
     d = cv.desc(xin, 0, 64, out, 0, EPI_RELU)
     lib.conv2d([d], B, h, w, xin)
     kc.check(kc.uncl(out.cpu(), B, h, w), torch.relu(torch.nn.functional.conv2d(x, wt, b, padding=1)), 1.5e-4,
@@ -526,6 +528,34 @@ def test_conv_8row_tile_layer1_size(lib, dev):
     assert lib.conv2d_tile([d], B, h, w) == 5
     lib.conv2d([d], B, h, w, s2d)
     kc.check(kc.uncl(out.cpu(), B, h, w), want, 1e-4, "8-row tile 4x4 stem")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["1x256x512", "4x64x128", "2x40x96", "3x72x160"])
+def test_weights_stationary_conv_matches_halo_kernel_bitwise(shape, tmp_path):
+    """pf_enc_conv64_kernel (round 5: the encoders' 3x3 64 -> 64 convolutions with W_hi in registers, W_lo in LDS and the input in
+    a 10-row ring walked down a 32-column strip) against the halo kernel it replaces (PRIORFLOW_ENC_CONV64=0; both read once per
+    process -> child processes, tests/run_conv_l1_check.py): outputs bit-identical with and without the folded input norm + ReLU
+    and with the ReLU epilogue, and the InstanceNorm scale / shift that pf_channel_stats_final makes of the fused partials (per
+    row and strip instead of per 8-row tile) equal to 1e-6 (bit-identical in practice).  PRIORFLOW_ENC_CONV64=2 forces the kernel
+    onto maps too small to fill the chip (segments of 8 rows, several images, widths of 3 and 5 strips)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = {}
+    for mode in ("0", "2"):
+        path = str(tmp_path / f"l1_{mode}.pt")
+        subprocess.run([sys.executable, os.path.join(here, "run_conv_l1_check.py"), shape, path], check=True,
+                       env=dict(os.environ, PRIORFLOW_ENC_CONV64=mode), timeout=600)
+        outs[mode] = torch.load(path)
+    old, new = outs["0"], outs["2"]
+    assert [int(t) for t in new[3::4]] == [6, 6, 6] and all(int(t) in (3, 5) for t in old[3::4])
+    for k in range(3):
+        o0, sc0, sh0 = old[4 * k: 4 * k + 3]
+        o1, sc1, sh1 = new[4 * k: 4 * k + 3]
+        assert torch.isfinite(o1).all() and torch.equal(o0, o1), (k, float((o0 - o1).abs().max()))
+        assert float((sc0 - sc1).abs().max()) <= 1e-6 * float(sc0.abs().max() + 1e-30)
+        assert float((sh0 - sh1).abs().max()) <= 1e-6 * float(sh0.abs().max() + 1e-30) + 1e-7
 
 
 @pytest.mark.parametrize("which", ["fnet", "cnet"])
