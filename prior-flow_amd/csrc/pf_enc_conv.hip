@@ -102,17 +102,18 @@ pf_enc_conv64_kernel(const EcArgs a) {
     const float* const in_img = a.in + (long)im * a.H * a.W * a.ld_in + 4 * f4;
     // LDS byte offset of this thread's hi half inside a pixel: chunk (f4 >> 3), 16-byte piece ((f4 & 7) >> 1), half piece (f4 & 1)
     const unsigned st_piece = (unsigned)((f4 >> 3) * 8 + ((f4 & 7) >> 1)), st_in = (unsigned)((f4 & 1) * 8);
-    auto item_rc = [&](int u, int& r, int& col) -> bool {   // item u of a half: (row r in 0..1, column 0..33); false: no such item
-        if (u < 2) { r = u; col = cg + 1; return true; }     // columns 1..32: the strip itself
-        r = cg >> 1; col = (cg & 1) * 33;                    // columns 0 and 33 (the halo), rows 0..1: threads with cg < 4
-        return cg < 4;
-    };
-    auto item_src = [&](int rr, int col, bool& ok) -> const float* {      // rr: row relative to the segment; col 0..33
-        const int y = yseg + rr, x = x0 - 1 + col;
-        ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
-        return ok ? in_img + ((long)y * a.W + x) * a.ld_in : in_img;
-    };
-    auto item_store = [&](int rr, int col, f32x4 x, bool ok) __attribute__((always_inline)) {
+    // A thread's items always sit in the same two columns: cg + 1 (rows 0..3 of a step's new rows) and, for cg < 8, the halo column
+    // 33 (cg & 1) of row cg >> 1 -- column validity, source offset and LDS offsets are per-thread constants, a row adds scalars
+    const int hcol = (cg & 1) * 33, hrow = cg >> 1;
+    const bool has_halo = cg < 8;
+    const bool xok_m = x0 + cg < a.W, xok_h = hcol ? (x0 + 32 < a.W) : (x0 > 0);
+    const int goff_m = (x0 + cg) * a.ld_in, goff_h = (x0 - 1 + hcol) * a.ld_in;          // floats from the row start (valid when xok)
+    auto lds_px = [&](int col) { const unsigned sw = (unsigned)(col & 15);
+                                 return (unsigned)(EC_WLO + col * 256) + ((st_piece ^ sw) << 4) + st_in; };
+    auto lds_px_lo = [&](int col) { const unsigned sw = (unsigned)(col & 15);
+                                    return (unsigned)(EC_WLO + col * 256) + (((st_piece + 4) ^ sw) << 4) + st_in; };
+    const unsigned lm_hi = lds_px(cg + 1), lm_lo = lds_px_lo(cg + 1), lh_hi = lds_px(hcol), lh_lo = lds_px_lo(hcol);
+    auto convert_store = [&](f32x4 x, bool ok, unsigned off_hi, unsigned off_lo) __attribute__((always_inline)) {
         if (affine) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + EC_AFF + 16 * f4), sh = *reinterpret_cast<const f32x4*>(lds + EC_AFF + 256 + 16 * f4);
             x = x * sc + sh;
@@ -122,22 +123,38 @@ pf_enc_conv64_kernel(const EcArgs a) {
         const bf16x4 hi = __builtin_convertvector(v, bf16x4);
         const f32x4 rest = v - __builtin_convertvector(hi, f32x4);
         const bf16x4 lo = __builtin_convertvector(rest, bf16x4);
-        const int slot = (rr + 1 + EC_RING) % EC_RING;
-        char* px = lds + EC_WLO + slot * EC_ROWB + col * 256;
-        const unsigned sw = (unsigned)(col & 15);
-        *reinterpret_cast<bf16x4*>(px + ((st_piece ^ sw) << 4) + st_in) = hi;
-        *reinterpret_cast<bf16x4*>(px + (((st_piece + 4) ^ sw) << 4) + st_in) = lo;
+        *reinterpret_cast<bf16x4*>(lds + off_hi) = hi;
+        *reinterpret_cast<bf16x4*>(lds + off_lo) = lo;
     };
-    // prologue: rows -1 .. 4 of the segment (what step 0 reads) = three halves
-    for (int hf = 0; hf < 3; ++hf)
+    // rows rr0 .. rr0 + 3 (relative to the segment): item u < 4 = (row rr0 + u, column cg + 1), item 4 = the halo item
+    auto rows_load = [&](int rr0, bool live, f32x4 (&st)[5], bool (&ok)[5]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            int r, col;
-            if (!item_rc(u, r, col)) continue;
-            bool ok;
-            const float* src = item_src(2 * hf + r - 1, col, ok);
-            item_store(2 * hf + r - 1, col, *reinterpret_cast<const f32x4*>(src), ok);
+        for (int u = 0; u < 5; ++u) {
+            const int rr = rr0 + (u < 4 ? u : hrow), y = yseg + rr;
+            const bool yok = y >= 0 && y < a.H;                            // (u < 4: wave-uniform)
+            ok[u] = live && yok && (u < 4 ? xok_m : (xok_h && has_halo));
+            const float* src = in_img + (long)(yok ? y : 0) * a.W * a.ld_in + (u < 4 ? goff_m : goff_h);
+            st[u] = ok[u] ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto rows_store = [&](int rr0, bool live, const f32x4 (&st)[5], const bool (&ok)[5]) __attribute__((always_inline)) {
+        if (!live) return;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            if (u == 4 && !has_halo) continue;
+            const int rr = rr0 + (u < 4 ? u : hrow);
+            const unsigned rowb = (unsigned)(((rr + 1 + EC_RING) % EC_RING) * EC_ROWB);
+            convert_store(st[u], ok[u], rowb + (u < 4 ? lm_hi : lh_hi), rowb + (u < 4 ? lm_lo : lh_lo));
+        }
+    };
+    // prologue: rows -1 .. 4 of the segment (what step 0 reads); rows 5, 6 are staged again by the loop (harmless)
+    {
+        f32x4 pst[5]; bool pok[5];
+        rows_load(-1, true, pst, pok);
+        rows_store(-1, true, pst, pok);
+        rows_load(3, true, pst, pok);
+        rows_store(3, true, pst, pok);
+    }
 
     // ---- fragment addresses: pixel column (li + kx), 16-byte piece = (8 c + h [+ 4 for lo]) ^ (2 kh) ^ swizzle(column)
     unsigned a_kx[3];
@@ -159,19 +176,13 @@ pf_enc_conv64_kernel(const EcArgs a) {
     const int grp = nt;
     f32x16 acc = zero16;
     f32x4 st[5]; bool st_ok[5];
-    auto item5 = [&](int u, int& r, int& col) -> bool {      // item u of a step's 4 new rows: (row 0..3, column 0..33)
-        if (u < 4) { r = u; col = cg + 1; return true; }      // columns 1..32
-        r = cg >> 1; col = (cg & 1) * 33;                     // the halo columns 0 and 33: threads with cg < 8
-        return cg < 8;
-    };
-    unsigned rbase[3] = {0u, 0u, 0u};
+    unsigned ar9[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};        // LDS address of pixel (row ky, column li + kx) of this step, per tap
     bf16x8 ahi[2], alo[2], blo[2];
     auto frag = [&](auto S, int buf) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
         constexpr int c = s / 18, tap = (s >> 1) % 9, h = s & 1, ky = tap / 3, kx = tap % 3;
         constexpr unsigned phi = (unsigned)((c * 8 + h) << 4), plo = phi + 64;
-        const unsigned ar = rbase[ky] + a_kx[kx];
-        const unsigned ad_hi = ar ^ phi, ad_lo = ar ^ plo;
+        const unsigned ad_hi = ar9[ky * 3 + kx] ^ phi, ad_lo = ar9[ky * 3 + kx] ^ plo;
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("ds_read_b128 %0, %1" : "=v"(ahi[buf]) : "v"(ad_hi));
         asm volatile("ds_read_b128 %0, %1" : "=v"(alo[buf]) : "v"(ad_lo));
@@ -214,10 +225,13 @@ pf_enc_conv64_kernel(const EcArgs a) {
         double s1 = 0.0, s2 = 0.0;
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = a.relu ? fmaxf(acc[r] + bias, 0.f) : (acc[r] + bias) * a.scale;
-            const double dv = (double)v[r];
-            s1 += dv; s2 += dv * dv;
+        for (int r = 0; r < 16; ++r) v[r] = a.relu ? fmaxf(acc[r] + bias, 0.f) : (acc[r] + bias) * a.scale;
+        if (a.stats != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double dv = (double)v[r];
+                s1 += dv; s2 += dv * dv;
+            }
         }
         const bool b0 = lane & 1, b1 = lane & 2;
         auto xch = [&](float& x0, float& x1, bool odd, auto CTRL) __attribute__((always_inline)) {   // 2 x 2 exchange with the lane CTRL selects
@@ -259,16 +273,7 @@ pf_enc_conv64_kernel(const EcArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int ts = hs >> 1;                              // the step whose successor's rows are staged in this pair of half-steps
         const bool more = ts + 1 < nsteps && !(abl & 1);
-        if (!(hs & 1)) {                                     // loads of rows 4 ts + 5 .. 4 ts + 8, in flight during this half-step
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                int r, col;
-                const bool live = item5(u, r, col) && more;
-                const float* src = item_src(4 * ts + 5 + r, col, st_ok[u]);
-                st_ok[u] = st_ok[u] && live;
-                st[u] = live ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
+        if (!(hs & 1)) rows_load(4 * ts + 5, more, st, st_ok);      // rows 4 ts + 5 .. 4 ts + 8, in flight during this half-step
         const int q = hs - grp;                              // this wave's own half-step
         const int t = q >> 1;
 #if PF_EC_DEFER
@@ -277,8 +282,11 @@ pf_enc_conv64_kernel(const EcArgs a) {
         if (q >= 0 && q < 2 * nsteps && !(abl & 4)) {
             if (!(q & 1)) {
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-                    rbase[ky] = __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(((4 * t + mr + ky) % EC_RING) * EC_ROWB));
+                for (int ky = 0; ky < 3; ++ky) {
+                    const unsigned rb = __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(((4 * t + mr + ky) % EC_RING) * EC_ROWB));
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) ar9[ky * 3 + kx] = rb + a_kx[kx];
+                }
                 khalf(std::integral_constant<int, 0>{});
             } else {
                 khalf(std::integral_constant<int, 1>{});
@@ -287,13 +295,7 @@ pf_enc_conv64_kernel(const EcArgs a) {
 #endif
             }
         }
-        if (hs & 1) {                                        // convert + write the rows loaded in the previous half-step
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                int r, col;
-                if (item5(u, r, col) && more) item_store(4 * ts + 5 + r, col, st[u], st_ok[u]);
-            }
-        }
+        if (hs & 1) rows_store(4 * ts + 5, more, st, st_ok);        // convert + write the rows loaded in the previous half-step
     }
 }
 
