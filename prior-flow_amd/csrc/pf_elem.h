@@ -684,13 +684,22 @@ PF_HD void pf_lookup_bwd_elem(long idx, const PfLookupBwdArgs& a) {     // idx o
     const long row = idx / PF_CORR_CH;
     const long b = row / N, n = row % N;
     const int lvl = k / PF_TAPS, tap = k % PF_TAPS;
-    const int ta = tap / 9, tb = tap % 9;             // slow axis a offsets x (core/corr.py:120-126)
+    // Consecutive lanes take taps that are neighbours in X (channel = 81 lvl + 9 ta + tb with the slow axis a offsetting x,
+    // core/corr.py:120-126): their four corners then fall into the same one or two 64-byte lines of a map row, and a wave's atomic
+    // instruction is a few line requests instead of one per lane (channel order, tb fastest, walks down a column: every lane its
+    // own line)
+#ifdef PF_LKB_CHANNEL_ORDER
+    const int ta = tap / 9, tb = tap % 9;
+#else
+    const int ta = tap % 9, tb = tap / 9;
+#endif
+    const int kk = lvl * PF_TAPS + ta * 9 + tb;       // the channel this thread scatters
     const int Hl = a.H >> lvl, Wl = a.W >> lvl;
     const float inv = 1.f / (float)(1 << lvl);
     const float cx = a.coords[(b * 2 + 0) * N + n] * inv + (float)(ta - PF_CORR_RADIUS);
     const float cy = a.coords[(b * 2 + 1) * N + n] * inv + (float)(tb - PF_CORR_RADIUS);
     const long lsz = (long)Hl * Wl;
-    const float go = a.d_own[row * a.ld + k], gr = a.d_raw[row * a.ld + k];
+    const float go = a.d_own[row * a.ld + kk], gr = a.d_raw[row * a.ld + kk];
     const PfTaps t = pf_taps0(pf_pymod(cx, (float)Wl), cy, Hl, Wl);
     float* own = a.g_own[lvl] + row * lsz;
     for (int j = 0; j < 4; ++j)

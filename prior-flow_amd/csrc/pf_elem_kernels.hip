@@ -828,36 +828,191 @@ __global__ void __launch_bounds__(kBlock) pf_upsample_bwd_wave(const PfUpsampleB
         const float gu = a.g[(b * 2 + 0) * plane + fine], gv = a.g[(b * 2 + 1) * plane + fine];
         const float* mrow = a.mask + prow * a.ld + lane;
         float w[9], sk[9];
+        // every load of the pixel up front and unconditional (a neighbour outside the map reads the pixel itself and is not
+        // used): inside the per-neighbour branch each pair of coordinate loads was its own round trip to memory, nine in a row
+        float cu[9], cv[9];
+        bool ok[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+            ok[k] = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;           // wave-uniform
+            const long p = ok[k] ? (long)yy * a.W + xx : (long)n;
+            cu[k] = a.coords1[(b * 2 + 0) * N + p];
+            cv[k] = a.coords1[(b * 2 + 1) * N + p];
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { w[k] = mrow[64 * k]; mx = fmaxf(mx, w[k]); }
         float den = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { w[k] = expf(w[k] - mx); den = den + w[k]; }
-        float dot = 0.f;
+        float su[9], sv[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
             w[k] = w[k] / den;
-            sk[k] = 0.f;
-            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {      // wave-uniform
-                const long p = (long)yy * a.W + xx;
-                const float fu = 8.f * (a.coords1[(b * 2 + 0) * N + p] - (float)xx);
-                const float fv = 8.f * (a.coords1[(b * 2 + 1) * N + p] - (float)yy);
-                sk[k] = gu * fu + gv * fv;
-                float su = 8.f * w[k] * gu, sv = 8.f * w[k] * gv;
+            const float fu = 8.f * (cu[k] - (float)xx), fv = 8.f * (cv[k] - (float)yy);
+            sk[k] = ok[k] ? gu * fu + gv * fv : 0.f;
+            su[k] = 8.f * w[k] * gu; sv[k] = 8.f * w[k] * gv;
+        }
+        // the 18 butterflies are independent chains: interleaved, not one after the other
 #pragma unroll
-                for (int m = 1; m < 64; m <<= 1) { su += __shfl_xor(su, m); sv += __shfl_xor(sv, m); }
-                if (lane == 0) {
-                    atomicAdd(a.d_flow + (b * 2 + 0) * N + p, su);
-                    atomicAdd(a.d_flow + (b * 2 + 1) * N + p, sv);
-                }
+        for (int m = 1; m < 64; m <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { su[k] += __shfl_xor(su[k], m); sv[k] += __shfl_xor(sv[k], m); }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (ok[k] && lane == 0) {
+                const long p = (long)(y + k / 3 - 1) * a.W + (x + k % 3 - 1);
+                atomicAdd(a.d_flow + (b * 2 + 0) * N + p, su[k]);
+                atomicAdd(a.d_flow + (b * 2 + 1) * N + p, sv[k]);
             }
             dot = dot + w[k] * sk[k];
         }
         float* drow = a.d_mask + prow * a.ld_d + lane;
 #pragma unroll
         for (int k = 0; k < 9; ++k) drow[64 * k] = w[k] * (sk[k] - dot);
+    }
+}
+
+// Backward of the DCCL lookup, one query per wave (round 5).  pf_lookup_bwd_elem (pf_elem.h) issues eight global atomics per
+// (query, channel): 2 592 per query, and on the coarse levels most of them collide -- the 81 taps of level 3 land on a 3 x 3
+// patch of the other view's map, 36 serialised atomics per address.  Here a wave owns a query: its 324 taps (taps that are
+// neighbours in x on consecutive lanes) add into wave-private LDS windows, one per level and view -- 12 x 12 cells around the
+// own view's 10 x 10 footprint, 16 x 16 around the warped centre tap for the other view, x relative to the window modulo the
+// map width (the panorama wraps) -- and the window cells that were touched go to memory as ONE atomic each (~600 per query,
+// no two of a launch on the same address except where a narrow map folds a window onto itself).  A corner outside its window
+// (a warp that tears near a pole) falls back to the direct global atomic.  Per tap the arithmetic (pf_pymod / pf_taps0 /
+// pf_apply) is pf_lookup_bwd_elem's; the sums differ from it only in the order of the additions.  77 -> 42 us per launch at the
+// training crop (48 x 64 queries; profiles/microbench_train_elem.py).  A workgroup per query (one tap per thread, two barriers)
+// measured 48 us.
+constexpr int LKB_OWN = 12, LKB_OTH = 16;
+constexpr int LKB_OWN_CELLS = PF_CORR_LEVELS * LKB_OWN * LKB_OWN, LKB_CELLS = LKB_OWN_CELLS + PF_CORR_LEVELS * LKB_OTH * LKB_OTH;   // 1 600
+struct LkbXY { int x[2], y[2]; float w[4]; };           // pf_taps0 with the corners as (x, y): w = nw, ne, sw, se
+__device__ __forceinline__ LkbXY lkb_taps(float x, float y, int H, int W) {
+    LkbXY t;
+    const float ix = pf_roundtrip(x, W), iy = pf_roundtrip(y, H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float wx = ix - fx, wy = iy - fy;
+    const float ex = 1.f - wx, ey = 1.f - wy;
+    const bool xin0 = (fx >= 0.f) && (fx <= (float)(W - 1));
+    const bool xin1 = (fx >= -1.f) && (fx <= (float)(W - 2));
+    const bool yin0 = (fy >= 0.f) && (fy <= (float)(H - 1));
+    const bool yin1 = (fy >= -1.f) && (fy <= (float)(H - 2));
+    t.x[0] = xin0 ? (int)fx : 0; t.x[1] = xin1 ? (int)fx + 1 : 0;
+    t.y[0] = yin0 ? (int)fy : 0; t.y[1] = yin1 ? (int)fy + 1 : 0;
+    t.w[0] = (xin0 && yin0) ? ey * ex : 0.f;
+    t.w[1] = (xin1 && yin0) ? ey * wx : 0.f;
+    t.w[2] = (xin0 && yin1) ? wy * ex : 0.f;
+    t.w[3] = (xin1 && yin1) ? wy * wx : 0.f;
+    return t;
+}
+// window origin from a coordinate's floor (finite and near the map, else 0: such a tap has no weight anyway)
+__device__ __forceinline__ int lkb_origin(float p, int size, int back) {
+    const float f = floorf(pf_roundtrip(p, size));
+    return (f > -64.f && f < (float)(size + 64)) ? (int)f - back : 0;
+}
+__global__ void __launch_bounds__(kBlock) pf_lookup_bwd_rows(const PfLookupBwdArgs a, const long rows) {
+    __shared__ float win[(kBlock / 64) * LKB_CELLS];
+    __shared__ int origins[(kBlock / 64) * 4 * PF_CORR_LEVELS];            // per wave and level: own x, own y, other x, other y
+    const int lane = threadIdx.x & 63;
+    float* const mine = win + (threadIdx.x >> 6) * LKB_CELLS;
+    int* const org = origins + (threadIdx.x >> 6) * 4 * PF_CORR_LEVELS;
+    for (int c = lane; c < LKB_CELLS; c += 64) mine[c] = 0.f;
+    const long N = (long)a.H * a.W;
+    long row = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * (kBlock / 64);
+    // (no workgroup barrier anywhere: the four waves of a block walk their own queries.  A wave's LDS operations complete in
+    // issue order, so its reads below see its adds above; the fences only keep hipcc from reordering them)
+    for (; row < rows; row += stride) {
+        const long b = row / N, n = row % N;
+        const float c0x = a.coords[(b * 2 + 0) * N + n], c0y = a.coords[(b * 2 + 1) * N + n];
+        if (lane < PF_CORR_LEVELS) {
+            // window origins of level `lane`: own = one cell before tap (0, 0)'s floor; other = seven cells before the warped
+            // centre tap.  In LDS, read with the level as index (as register arrays hipcc spills them to scratch memory for that)
+            const int l = lane;
+            const int Hl = a.H >> l, Wl = a.W >> l;
+            const float inv = 1.f / (float)(1 << l);
+            const float cx = c0x * inv, cy = c0y * inv;
+            org[4 * l] = lkb_origin(pf_pymod(cx - (float)PF_CORR_RADIUS, (float)Wl), Wl, 1);
+            org[4 * l + 1] = lkb_origin(cy - (float)PF_CORR_RADIUS, Hl, 1);
+            const PfTaps tg = pf_taps0(pf_pymod(cx, (float)a.W), cy, a.H, a.W);
+            const float gx = pf_apply(tg, a.g_w2c), gy = pf_apply(tg, a.g_w2c + N);
+            org[4 * l + 2] = lkb_origin(pf_pymod(gx, (float)Wl), Wl, LKB_OTH / 2 - 1);
+            org[4 * l + 3] = lkb_origin(gy, Hl, LKB_OTH / 2 - 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = lane; k < PF_CORR_CH; k += 64) {
+            const int lvl = k / PF_TAPS, tap = k % PF_TAPS;
+            const int ta = tap % 9, tb = tap / 9;                 // lanes walk x first (channel = 81 lvl + 9 ta + tb, ta offsets x)
+            const int kk = lvl * PF_TAPS + ta * 9 + tb;
+            const int Hl = a.H >> lvl, Wl = a.W >> lvl;
+            const float inv = 1.f / (float)(1 << lvl);
+            const float cx = c0x * inv + (float)(ta - PF_CORR_RADIUS);
+            const float cy = c0y * inv + (float)(tb - PF_CORR_RADIUS);
+            const long lsz = (long)Hl * Wl;
+            const float go = a.d_own[row * a.ld + kk], gr = a.d_raw[row * a.ld + kk];
+            const int ox = org[4 * lvl], oy = org[4 * lvl + 1], qx = org[4 * lvl + 2], qy = org[4 * lvl + 3];
+            float* own = a.g_own[0];
+            float* oth = a.g_other[0];
+#pragma unroll
+            for (int l = 1; l < PF_CORR_LEVELS; ++l)          // (selects: indexing the by-value argument with lvl would put it in scratch)
+                if (lvl == l) { own = a.g_own[l]; oth = a.g_other[l]; }
+            own += row * lsz; oth += row * lsz;
+            float* const wo = mine + lvl * (LKB_OWN * LKB_OWN);
+            float* const wt = mine + LKB_OWN_CELLS + lvl * (LKB_OTH * LKB_OTH);
+            const LkbXY t = lkb_taps(pf_pymod(cx, (float)Wl), cy, Hl, Wl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (t.w[j] == 0.f) continue;
+                const int x = t.x[j & 1], y = t.y[j >> 1];
+                int xr = x - ox; xr = xr < 0 ? xr + Wl : (xr >= Wl ? xr - Wl : xr);
+                const int yr = y - oy;
+                if ((unsigned)xr < (unsigned)LKB_OWN && (unsigned)yr < (unsigned)LKB_OWN) atomicAdd(wo + yr * LKB_OWN + xr, go * t.w[j]);
+                else atomicAdd(own + (long)y * Wl + x, go * t.w[j]);
+            }
+            // cross view: the level-i coordinates index the LEVEL-0 grid (core/corr.py:132-133)
+            const PfTaps tg = pf_taps0(pf_pymod(cx, (float)a.W), cy, a.H, a.W);
+            const float gx = pf_apply(tg, a.g_w2c), gy = pf_apply(tg, a.g_w2c + N);
+            const LkbXY to = lkb_taps(pf_pymod(gx, (float)Wl), gy, Hl, Wl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (to.w[j] == 0.f) continue;
+                const int x = to.x[j & 1], y = to.y[j >> 1];
+                int xr = x - qx; xr = xr < 0 ? xr + Wl : (xr >= Wl ? xr - Wl : xr);
+                const int yr = y - qy;
+                if ((unsigned)xr < (unsigned)LKB_OTH && (unsigned)yr < (unsigned)LKB_OTH) atomicAdd(wt + yr * LKB_OTH + xr, gr * to.w[j]);
+                else atomicAdd(oth + (long)y * Wl + x, gr * to.w[j]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int c = lane; c < LKB_CELLS; c += 64) {
+            const float v = mine[c];
+            if (v == 0.f) continue;
+            mine[c] = 0.f;                                    // the window is clean again for the wave's next query
+            const bool c_own = c < LKB_OWN_CELLS;
+            const int cc = c_own ? c : c - LKB_OWN_CELLS;
+            const int cl = c_own ? cc / (LKB_OWN * LKB_OWN) : cc / (LKB_OTH * LKB_OTH);
+            const int cell = c_own ? cc % (LKB_OWN * LKB_OWN) : cc % (LKB_OTH * LKB_OTH);
+            const int yr = c_own ? cell / LKB_OWN : cell / LKB_OTH, xr = c_own ? cell % LKB_OWN : cell % LKB_OTH;
+            const int Wc = a.W >> cl;
+            const int bx = org[4 * cl + (c_own ? 0 : 2)], by = org[4 * cl + (c_own ? 1 : 3)];
+            float* dst = c_own ? a.g_own[0] : a.g_other[0];
+#pragma unroll
+            for (int l = 1; l < PF_CORR_LEVELS; ++l)
+                if (cl == l) dst = c_own ? a.g_own[l] : a.g_other[l];
+            // a filled cell came from an in-range (x, y) with x = origin + xr modulo the width (a narrow map folds the window)
+            int x = (bx + xr) % Wc; x = x < 0 ? x + Wc : x;
+            atomicAdd(dst + row * ((long)(a.H >> cl) * Wc) + (long)(by + yr) * Wc + x, v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -910,8 +1065,21 @@ int launch_upsample_bwd(const PfUpsampleBwdArgs& a, long total, void* stream) {
     return (int)hipGetLastError();
 }
 
+int launch_lookup_bwd(const PfLookupBwdArgs& a, long total, void* stream) {
+    // PRIORFLOW_LOOKUP_BWD=elem: the per-(query, channel) scatter (A/B and the statement the emulation runs)
+    static const bool per_elem = [] { const char* e = getenv("PRIORFLOW_LOOKUP_BWD"); return e && e[0] == 'e'; }();
+    if (per_elem) return pf_launch_elem<PfLookupBwdArgs, pf_lookup_bwd_elem>(a, total, stream);
+    const long rows = total / PF_CORR_CH;
+    if (rows <= 0) return PF_OK;
+    long blocks = (rows + kBlock / 64 - 1) / (kBlock / 64);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(pf_lookup_bwd_rows, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, rows);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
+#define PF_LOOKUP_BWD_LAUNCH(a, total, stream) launch_lookup_bwd(a, total, stream)
 #define PF_UPSAMPLE_BWD_LAUNCH(a, total, stream) launch_upsample_bwd(a, total, stream)
 #define PF_COMBINE_LAUNCH(a, total, stream) launch_combine(a, total, stream)
 #ifdef PF_LOOKUP_WAVES

@@ -64,3 +64,4 @@ MB_BATCH=8 python profiles/ab_corr.py 3 4 tile ring rs >> $O/ab_corr_kernels.txt
 fi
 for f in pytest_gpu.log smoke.log forward_breakdown.txt time_sizes.txt ab_corr_form.txt ab_corr_kernels.txt train_2rank_check.txt; do [ -f $O/$f ] && { echo "== $f"; tail -12 $O/$f | cut -c1-220; }; done
 for f in bench_n1.json bench_batch32.json train_step_time.json train_step_time_two_graphs.json train_step_time_eager.json train_step_time_batch8.json train_step_time_2rank_gloo.json; do [ -f $O/$f ] && { echo "== $f"; cut -c1-330 $O/$f; }; done
+exit 0

@@ -111,6 +111,7 @@ static int emu_stats(const float* y, int B, int Np, int C, float eps, float* sca
 #define PF_FLOW_OUT_LAUNCH(a, total, stream) pf_loop<PfFlowOutArgs, pf_flow_out_elem>(a, total)
 #define PF_LOOKUP_LAUNCH(a, total, stream) pf_loop<PfLookupArgs, pf_lookup_elem>(a, total)
 #define PF_COMBINE_LAUNCH(a, total, stream) pf_loop<PfCombineArgs, pf_combine_elem>(a, total)
+#define PF_LOOKUP_BWD_LAUNCH(a, total, stream) pf_loop<PfLookupBwdArgs, pf_lookup_bwd_elem>(a, total)
 #define PF_UPSAMPLE_BWD_LAUNCH(a, total, stream) pf_loop<PfUpsampleBwdArgs, pf_upsample_bwd_elem>(a, total)
 
 #include "pf_api_elem.inc"

@@ -682,6 +682,52 @@ def test_gru_half_step_with_hoisted_context_equals_full_convolutions(lib, dev, s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H8,W8", [(1, 48, 64), (2, 24, 40), (1, 16, 16)])
+def test_lookup_backward_per_query_kernel_matches_the_per_channel_scatter(dev, B, H8, W8, tmp_path):
+    """pf_dccl_lookup_bwd: the wave-per-query kernel (LDS windows, one global atomic per touched cell; default) against the
+    per-(query, channel) scatter pf_lookup_bwd_elem (PRIORFLOW_LOOKUP_BWD=elem, read once per process -> child processes): the
+    same eight pyramid gradients up to the order of the additions.  (16, 16): level 3 is a 2 x 2 map -- every window folds onto
+    itself; coordinates run outside the map on every side; a random sampling grid tears the other view's windows apart (the
+    direct-atomic fallback)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import math, sys, torch
+sys.path.insert(0, {root!r})
+from prior_flow_amd import _lib
+from prior_flow_amd.engine import rotation_x
+lib = _lib.load(); dev = torch.device('cuda:0')
+B, H8, W8 = {B}, {H8}, {W8}; N = H8 * W8
+g = torch.Generator().manual_seed(11)
+xs = torch.arange(W8).view(1, 1, 1, W8).expand(B, 1, H8, W8).float()
+ys = torch.arange(H8).view(1, 1, H8, 1).expand(B, 1, H8, W8).float()
+coords = (torch.cat([xs, ys], 1) + (torch.rand(B, 2, H8, W8, generator=g) * 30 - 15)).contiguous().to(dev)
+g8 = torch.empty(2, H8, W8, device=dev); lib.sample_grid(g8, rotation_x(math.pi / 2))
+g_rand = torch.stack([torch.rand(H8, W8, generator=g) * (W8 + 4) - 2, torch.rand(H8, W8, generator=g) * (H8 + 4) - 2]).to(dev).contiguous()
+d_own = (torch.rand(B * N, 324, generator=g) - 0.5).to(dev)
+d_raw = (torch.rand(B * N, 324, generator=g) - 0.5).to(dev)
+res = []
+for grid in (g8, g_rand):
+    own = [torch.zeros(B * N, (H8 >> i) * (W8 >> i), device=dev) for i in range(4)]
+    oth = [torch.zeros(B * N, (H8 >> i) * (W8 >> i), device=dev) for i in range(4)]
+    for _ in range(2):                      # accumulated into: two launches
+        lib.dccl_lookup_bwd(coords, grid, d_own, d_raw, own, oth)
+    res += [t.cpu() for t in own + oth]
+torch.save(res, sys.argv[1])
+"""
+    outs = {}
+    for mode in ("rows", "elem"):
+        path = str(tmp_path / f"lkb_{mode}.pt")
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, PRIORFLOW_LOOKUP_BWD=mode), timeout=600)
+        outs[mode] = torch.load(path)
+    assert len(outs["rows"]) == len(outs["elem"]) == 16
+    for i, (r, e) in enumerate(zip(outs["rows"], outs["elem"])):
+        assert float(e.abs().max()) > 0.1, i
+        assert float((r - e).abs().max()) < 3e-5 * max(1.0, float(e.abs().max())), ("view / level", i, float((r - e).abs().max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 64, 128), (2, 24, 40), (1, 17, 27)])
 def test_lookup_window_kernel_matches_per_thread_kernel_bitwise(dev, shape, tmp_path):
     """pf_lookup_win_kernel (a wave per pixel: shared x / y tap geometry, cooperative window loads through LDS;
