@@ -208,7 +208,8 @@ typedef struct pf_conv_desc {
     const float* in_scale; const float* in_shift; int in_relu;
     /* optional InstanceNorm statistics of THIS conv's output, fused into its epilogue (PF_EPI_LINEAR only):
      * stats_out[((image*nblk + tile)*cout + c)*2 + {0,1}] = fp64 sum / sum of squares of output channel c over one workgroup
-     * tile.  Halo-kernel tiles 3/4/5: nblk = tiles per image = ceil(H8/TH)*ceil(W8/32), TH = 8 for tile 5 else 4 (tile 6: TH = 1).  Generic
+     * tile.  nblk = pf_conv2d_stats_blocks(...).  Halo-kernel tiles 3/4/5: nblk = tiles per image = ceil(H8/TH)*ceil(W8/32), TH = 8 for
+     * tile 5 else 4; tile 6: one partial per (segment of rows, row phase of the 4-row step, strip).  Generic
      * kernel (pf_conv2d_tile 0/1/2, bf16x3; the stride-2 layers): tiles of BM = 128/64/64 consecutive pixels, nblk = H8*W8/BM,
      * which must divide (PF_ERR_BAD_SHAPE otherwise).  Finish with pf_channel_stats_final.  NULL = none. */
     double* stats_out;
@@ -267,9 +268,13 @@ int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, voi
 /* Host-only introspection: which workgroup tile pf_conv2d would use for this launch -- generic kernel 0: 128x32,
  * 1: 64x64, 2: 64x128 (pixels x channels); halo kernel 3: 128x64, 4: 128x128, 5: 256x64 (8-row tile); 6: the
  * weights-stationary kernel of the encoders' 3x3 64 -> 64 convolutions (round 5; core/extractor.py:16-17 at 1/2 resolution:
- * strips of 32 columns walked in 4-row steps, outputs bit-identical to tile 5, `stats_out` partials per (row, strip):
- * nblk = H8 * ceil(W8 / 32)) -- or a negative PF_ERR_* code.  Lets a profiler attribute measured time to the right kernel instantiation; launches nothing. */
+ * strips of 32 columns walked in 4-row steps, outputs bit-identical to tile 5) -- or a negative PF_ERR_* code.  Lets a profiler attribute measured time to the right kernel instantiation; launches nothing. */
 int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8);
+
+/* Host-only introspection: how many fp64 partial blocks PER IMAGE this launch writes to `stats_out` (the nblk of
+ * pf_channel_stats_final and of the buffer's size, [B][nblk][cout][2] doubles); 0 = this launch cannot fuse the statistics
+ * (generic kernel whose pixel tiles would straddle images, or not bf16x3); negative = PF_ERR_*.  Launches nothing. */
+int pf_conv2d_stats_blocks(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8);
 
 /* Host-only introspection, companion of pf_conv2d_tile for tiles 3 / 4: which wave organisation the launch takes --
  * 0: every wave stages and multiplies (pf_conv_halo_kernel), 1: four MFMA waves + four loader waves on the same tile

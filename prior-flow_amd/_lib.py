@@ -107,6 +107,7 @@ _SIGNATURES = {
     "pf_conv2d": [C.POINTER(ConvDesc), _i, _i, _i, _i, _fp],
     "pf_dccl_combine_conv1x1": [C.POINTER(CombineConvDesc), _i, _i, _i, _i, _fp],
     "pf_conv2d_tile": [C.POINTER(ConvDesc), _i, _i, _i, _i],
+    "pf_conv2d_stats_blocks": [C.POINTER(ConvDesc), _i, _i, _i, _i],
     "pf_conv2d_roles": [C.POINTER(ConvDesc), _i, _i, _i, _i],
     "pf_conv2d_direct": [_fp, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pf_conv2d_direct_group": [C.POINTER(DirectDesc), _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp],
@@ -420,6 +421,14 @@ class PfLib:
         rc = self._dll.pf_conv2d_tile(arr, len(descs), B, H8, W8)
         if rc < 0:
             self._rc(rc, "pf_conv2d_tile")
+        return rc
+
+    def conv2d_stats_blocks(self, descs: Sequence[ConvDesc], B, H8, W8) -> int:
+        """fp64 partial blocks per image a launch with ``stats_out`` writes (0: the launch cannot fuse the statistics)."""
+        arr = (ConvDesc * len(descs))(*descs)
+        rc = self._dll.pf_conv2d_stats_blocks(arr, len(descs), B, H8, W8)
+        if rc < 0:
+            self._rc(rc, "pf_conv2d_stats_blocks")
         return rc
 
     def conv2d_roles(self, descs: Sequence[ConvDesc], B, H8, W8) -> int:

@@ -124,9 +124,21 @@ extern "C" int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int
     const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
     if (rc != PF_OK) return rc;
     const int tile = conv_tile(g, ngroups, max_cout, descs[0].precision);
-    // 6: the weights-stationary kernel of the encoders' 3x3 64 -> 64 convolutions (pf_enc_conv.hip): statistics partials per
-    // (row, 32-column strip) instead of per 8-row tile
+    // 6: the weights-stationary kernel of the encoders' 3x3 64 -> 64 convolutions (pf_enc_conv.hip): its statistics partials are
+    // per (segment, row phase, strip) -- pf_conv2d_stats_blocks
     return ((tile == 5 || tile == 3) && pf_enc_conv64_applies(grp, ngroups, g, max_cout)) ? 6 : tile;
+}
+
+extern "C" int pf_conv2d_stats_blocks(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {
+    ConvGroups grp; ConvGeom g; int max_cout;
+    const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
+    if (rc != PF_OK) return rc;
+    const int tile = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    const bool split = descs[0].precision == PF_PREC_BF16X3;
+    if ((tile == 5 || tile == 3) && pf_enc_conv64_applies(grp, ngroups, g, max_cout)) return pf_enc_conv64_stats_blocks(g);
+    if (tile >= 3) { const int th = tile == 5 ? 8 : 4; return ((g.H + th - 1) / th) * ((g.W + 31) / 32); }
+    const int bm = tile == 0 ? 128 : 64;             // generic kernel: tiles of bm consecutive pixels, which must not straddle images
+    return (split && g.N % bm == 0) ? g.N / bm : 0;
 }
 
 extern "C" int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8) {

@@ -351,6 +351,7 @@ int pf_conv_ws_choice(const pfconv::ConvGroups& grp, int ngroups, const pfconv::
 
 // pf_enc_conv.hip: the weights-stationary kernel of the encoders' 3x3 64 -> 64 convolutions (round 5)
 bool pf_enc_conv64_applies(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout);
+int pf_enc_conv64_stats_blocks(const pfconv::ConvGeom& g);
 int pf_enc_conv64_launch(const pfconv::ConvGroups& grp, const pfconv::ConvGeom& g, hipStream_t stream);
 
 // pf_conv_dma.hip: launcher of the all-DMA kernel.  `roles` as in pf_conv2d_roles (1: 128-px tile, 2: 256 px x 64 channels).

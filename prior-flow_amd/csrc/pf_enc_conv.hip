@@ -175,6 +175,7 @@ pf_enc_conv64_kernel(const EcArgs a) {
     // 2 t and written in 2 t + 1 into the slots of rows only step t - 1 read, which both groups have left by then.
     const int grp = nt;
     f32x16 acc = zero16;
+    double s1 = 0.0, s2 = 0.0;          // InstanceNorm statistics of this wave's rows of the segment (one partial per wave and item)
     f32x4 st[5]; bool st_ok[5];
     unsigned ar9[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};        // LDS address of pixel (row ky, column li + kx) of this step, per tap
     bf16x8 ahi[2], alo[2], blo[2];
@@ -222,7 +223,6 @@ pf_enc_conv64_kernel(const EcArgs a) {
         // of lanes (DPP: lane j of a quad ends up with pixel j's four channels) so that a lane stores 16 contiguous bytes: 4 store
         // instructions of 1 KB per wave and step instead of 16 of 256 B -- the CU issues one vector-memory instruction per ~46
         // cycles whatever its size, and the narrow stores alone kept that path busy for 40 % of the kernel
-        double s1 = 0.0, s2 = 0.0;
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = a.relu ? fmaxf(acc[r] + bias, 0.f) : (acc[r] + bias) * a.scale;
@@ -253,13 +253,15 @@ pf_enc_conv64_kernel(const EcArgs a) {
             const f32x4 w4 = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
             *reinterpret_cast<f32x4*>(ot + (long)(8 * g) * a.ld_out) = w4;
         }
-        if (a.stats != nullptr) {
-            // InstanceNorm statistics of the stored values: fp64 sum / sum of squares per channel over the row's 32 pixels, one
-            // partial per (row, strip) -- [image][H * strips][64][2], reduced by pf_channel_stats_final (pf_conv2d_tile code 6)
+        if (a.stats != nullptr && t == nsteps - 1) {
+            // InstanceNorm statistics of the stored values: fp64 sum / sum of squares per channel over this wave's rows of the
+            // segment (rows mr, mr + 4, ... x 32 pixels), one partial per (segment, row phase, strip) --
+            // [image][nseg * 4 * strips][64][2], reduced by pf_channel_stats_final (pf_conv2d_stats_blocks gives the count).
+            // (A partial per row and strip made that reduction 20 us instead of 5 at fnet's layer-1 size.)
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
             if (lh == 0) {
-                double* qd = a.stats + ((((long)im * a.H + y) * a.strips + sx) * 64 + 32 * nt + li) * 2;
+                double* qd = a.stats + (((((long)im * a.nseg + sg) * 4 + mr) * a.strips + sx) * 64 + 32 * nt + li) * 2;
                 qd[0] = s1; qd[1] = s2;
             }
         }
@@ -314,6 +316,19 @@ bool pf_enc_conv64_applies(const pfconv::ConvGroups& grp, int ngroups, const pfc
            (mode >= 2 || (long)(g.M / g.N) * (g.H / 8) * (g.W / 32) >= 256);
 }
 
+// rows per work item: the longest segment (a divisor of H, a multiple of 8: the weights are loaded once per item and a strip's
+// rows are fetched once) that still gives every CU an item (4 images of 256 x 512: 64 rows, 256 items -- two rounds of
+// 32-row items measured 146-159 us against 139)
+static int ec_segment(const pfconv::ConvGeom& g) {
+    const int Bn = g.M / g.N;
+    for (int sg = g.H; sg > 8; sg -= 8)
+        if (g.H % sg == 0 && (long)Bn * (g.H / sg) * (g.W / 32) >= 256) return sg;
+    return 8;
+}
+
+// fp64 statistics partials per image of a launch with stats_out: one per (segment, row phase of the 4-row step, strip)
+int pf_enc_conv64_stats_blocks(const pfconv::ConvGeom& g) { return (g.H / ec_segment(g)) * 4 * (g.W / 32); }
+
 int pf_enc_conv64_launch(const pfconv::ConvGroups& grp, const pfconv::ConvGeom& g, hipStream_t stream) {
     const pf_conv_desc& d = grp.d[0];
     EcArgs a;
@@ -323,12 +338,7 @@ int pf_enc_conv64_launch(const pfconv::ConvGroups& grp, const pfconv::ConvGeom& 
     a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_relu = d.in_relu;
     a.stats = d.stats_out; a.scale = d.scale; a.relu = d.epilogue == PF_EPI_RELU;
     a.Bn = g.M / g.N; a.H = g.H; a.W = g.W;
-    // rows per work item: the longest segment (a divisor of H, a multiple of 8: the weights are loaded once per item and a strip's
-    // rows are fetched once) that still gives every CU an item (4 images of 256 x 512: 64 rows, 256 items -- two rounds of
-    // 32-row items measured 146-159 us against 139)
-    a.seg = 8;
-    for (int sg = g.H; sg > 8; sg -= 8)
-        if (g.H % sg == 0 && (long)a.Bn * (g.H / sg) * (g.W / 32) >= 256) { a.seg = sg; break; }
+    a.seg = ec_segment(g);
     a.nseg = g.H / a.seg; a.strips = g.W / 32;
     const long items = (long)a.Bn * a.nseg * a.strips;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_enc_conv64_kernel),

@@ -888,13 +888,7 @@ class EncoderPlan:
         d = cv.desc(x, 0, cin, y, 0, EPI_LINEAR, **kw)
         fused = False
         if self.kind != "batch" and self.precision == PREC_BF16X3:
-            tile = lib.conv2d_tile([d], Bn, h, w)
-            if tile >= 3:
-                th = 8 if tile == 5 else 1 if tile == 6 else 4        # 6: the weights-stationary 64 -> 64 kernel, one partial per row and strip
-                nblk = ((h + th - 1) // th) * ((w + 31) // 32)
-            else:           # generic kernel (the stride-2 layers): tiles of 128 / 64 / 64 consecutive pixels (round 4)
-                bm = 128 if tile == 0 else 64
-                nblk = (h * w) // bm if tile >= 0 and (h * w) % bm == 0 else 0
+            nblk = lib.conv2d_stats_blocks([d], Bn, h, w)        # per-tile fp64 partials of the kernel this launch takes (0: none)
             if nblk > 0 and Bn * nblk * cout * 2 <= bufs["part"].numel():
                 d.stats_out = bufs["part"].data_ptr()
                 fused = True
@@ -925,8 +919,8 @@ class EncoderPlan:
         b["s2d"] = z(Bn * (H // 2) * (W // 2), 12)
         b["sc"] = [z(Bn * 128) for _ in range(3)]
         b["sh"] = [z(Bn * 128) for _ in range(3)]
-        # [image][<= 1024 tiles or 128 chunks][C][2]; the 64-channel layer's weights-stationary kernel: one partial per row and strip
-        b["part"] = z(Bn * max(1024 * 128, (H // 2) * ((W // 2 + 31) // 32) * 64) * 2, dt=torch.float64)
+        # [image][<= 1024 tiles or 128 chunks][C][2] (pf_conv2d_stats_blocks of the launch; a launch whose partials do not fit takes the separate pass)
+        b["part"] = z(Bn * 1024 * 128 * 2, dt=torch.float64)
         self._bufs = self._bufs_by_key[key] = b
 
     def _select(self, key) -> bool:

@@ -31,8 +31,7 @@ def run(shape, out_path):
             kw.update(in_scale=sc, in_shift=sh, in_relu=relu)
         d = cv.desc(x, 0, 64, out, 0, epi, **kw)
         tile = lib.conv2d_tile([d], Bn, H, W)
-        th = 8 if tile == 5 else 1 if tile == 6 else 4
-        nblk = ((H + th - 1) // th) * (W // 32)
+        nblk = lib.conv2d_stats_blocks([d], Bn, H, W)
         scale = shift = torch.zeros(1)
         if stats:
             part = torch.full((Bn * nblk * 64 * 2,), float("nan"), dtype=torch.float64, device=dev)

@@ -29,7 +29,7 @@ def emu():
         subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
                                "-I", CSRC, srcs[0], "-o", EMU_SO])
     from prior_flow_amd._lib import PfLib
-    return PfLib(EMU_SO, require_cuda=False, optional=("pf_debug_dirty_lds", "pf_conv2d", "pf_conv2d_tile", "pf_conv2d_roles", "pf_corr_pyramid", "pf_corr_pyramid_bf16x3", "pf_conv2d_wgrad",
+    return PfLib(EMU_SO, require_cuda=False, optional=("pf_debug_dirty_lds", "pf_conv2d", "pf_conv2d_tile", "pf_conv2d_stats_blocks", "pf_conv2d_roles", "pf_corr_pyramid", "pf_corr_pyramid_bf16x3", "pf_conv2d_wgrad",
                                                             "pf_dccl_combine_conv1x1", "pf_conv2d_wgrad_small", "pf_conv2d_wgrad_small_ws",
                                                             "pf_conv2d_wgrad_small_ws_floats", "pf_enc_stem"))
 

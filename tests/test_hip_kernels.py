@@ -403,8 +403,10 @@ def _check_fused_stats(lib, dev, cv, xin, cin, cout, B, h, w, expect_tile):
     d = cv.desc(xin, 0, cin, out, 0, EPI_LINEAR)
     tile = lib.conv2d_tile([d], B, h, w)
     assert tile == expect_tile
-    th = 8 if tile == 5 else 1 if tile == 6 else 4      # 6: the weights-stationary kernel, one partial per row and strip
-    nblk = ((h + th - 1) // th) * ((w + 31) // 32)
+    nblk = lib.conv2d_stats_blocks([d], B, h, w)
+    if tile in (3, 4, 5):
+        th = 8 if tile == 5 else 4
+        assert nblk == ((h + th - 1) // th) * ((w + 31) // 32)
     part = torch.full((B, nblk, cout, 2), float("nan"), dtype=torch.float64, device=dev)
     d.stats_out = part.data_ptr()
     lib.conv2d([d], B, h, w, xin)
