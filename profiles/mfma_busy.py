@@ -18,7 +18,7 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, c in acc.items():
-    if "pf_conv" not in k and "pf_corr" not in k and "pf_combine_conv" not in k and "pf_enc_stem" not in k:
+    if "pf_conv" not in k and "pf_corr" not in k and "pf_combine_conv" not in k and "pf_enc_stem" not in k and "pf_enc_conv" not in k:
         continue
     if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
         continue
