@@ -40,7 +40,8 @@ struct EcArgs {
     const char* w; const float* bias;
     float* out; int ld_out;                          // output rows (channel offset folded in)
     const float* in_scale; const float* in_shift; int in_relu;
-    double* stats;                                   // [image][H * strips][64][2] or NULL: one partial per (row, strip)
+    double* stats;                                   // [image][nseg * 4 * strips][64][2] or NULL: one partial per (segment, row phase, strip)
+    const float* res; int ld_res;                    // PF_EPI_RELU_RES: out = relu(res + relu(acc + bias)) (relu = 1); else NULL
     float scale; int relu;
     int Bn, H, W, seg, nseg, strips;                 // seg: rows per work item (a multiple of 4); nseg = H / seg; strips = W / 32
 };
@@ -242,7 +243,9 @@ pf_enc_conv64_kernel(const EcArgs a) {
         };
         using X1 = std::integral_constant<int, 0xB1>;      // quad_perm [1,0,3,2]: lane ^ 1
         using X2 = std::integral_constant<int, 0x4E>;      // quad_perm [2,3,0,1]: lane ^ 2
-        float* const ot = a.out + (((long)im * a.H + y) * a.W + x0 + 4 * lh + (lane & 3)) * a.ld_out + 32 * nt + (li & ~3);
+        const long opix = ((long)im * a.H + y) * a.W + x0 + 4 * lh + (lane & 3);
+        float* const ot = a.out + opix * a.ld_out + 32 * nt + (li & ~3);
+        const float* const rt = a.res != nullptr ? a.res + opix * a.ld_res + 32 * nt + (li & ~3) : nullptr;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             xch(v[4 * g], v[4 * g + 1], b0, X1{});
@@ -250,7 +253,11 @@ pf_enc_conv64_kernel(const EcArgs a) {
             xch(v[4 * g], v[4 * g + 2], b1, X2{});
             xch(v[4 * g + 1], v[4 * g + 3], b1, X2{});
             // lane (quad position j) now holds pixel 8 g + j (+ 4 lh): channels 4 (li >> 2) .. + 3
-            const f32x4 w4 = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            f32x4 w4 = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            if (a.res != nullptr) {                           // ResidualBlock tail (core/extractor.py:47), the residual in the stores' layout
+                const f32x4 h4 = *reinterpret_cast<const f32x4*>(rt + (long)(8 * g) * a.ld_res);
+                w4.x = fmaxf(h4.x + w4.x, 0.f); w4.y = fmaxf(h4.y + w4.y, 0.f); w4.z = fmaxf(h4.z + w4.z, 0.f); w4.w = fmaxf(h4.w + w4.w, 0.f);
+            }
             *reinterpret_cast<f32x4*>(ot + (long)(8 * g) * a.ld_out) = w4;
         }
         if (a.stats != nullptr && t == nsteps - 1) {
@@ -304,14 +311,15 @@ pf_enc_conv64_kernel(const EcArgs a) {
 }  // namespace
 
 // Whether pf_conv2d hands this launch to pf_enc_conv64_kernel (PRIORFLOW_ENC_CONV64=0: never): one group, 3x3 stride 1, 64 -> 64,
-// fp32 rows in and out, LINEAR or RELU epilogue, a map of whole 32-column strips and 4-row steps that fills the chip.
+// fp32 rows in and out, LINEAR, RELU or RELU_RES epilogue, a map of whole 32-column strips and 4-row steps that fills the chip.
 bool pf_enc_conv64_applies(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout) {
     static const int mode = [] { const char* e = getenv("PRIORFLOW_ENC_CONV64"); return e ? atoi(e) : 1; }();     // 2: also on small maps (tests)
     if (mode <= 0 || ngroups != 1) return false;
     const pf_conv_desc& d = grp.d[0];
     return d.precision == PF_PREC_BF16X3 && g.kh == 3 && g.kw == 3 && g.stride == 1 && d.c0 == 64 && d.c1 == 0 && d.cout == 64 &&
            max_cout == 64 && d.in0 != nullptr && d.out != nullptr && d.out_split == nullptr && d.pre == nullptr &&
-           (d.epilogue == PF_EPI_LINEAR || d.epilogue == PF_EPI_RELU) && (g.W % 32) == 0 && (g.H % 8) == 0 &&
+           (d.epilogue == PF_EPI_LINEAR || d.epilogue == PF_EPI_RELU || (d.epilogue == PF_EPI_RELU_RES && d.h != nullptr && (d.ld_h % 4) == 0)) &&
+           (g.W % 32) == 0 && (g.H % 8) == 0 &&
            (d.ld0 % 4) == 0 && (d.off0 % 4) == 0 && (d.ld_out % 4) == 0 && (d.off_out % 4) == 0 &&
            (mode >= 2 || (long)(g.M / g.N) * (g.H / 8) * (g.W / 32) >= 256);
 }
@@ -336,7 +344,8 @@ int pf_enc_conv64_launch(const pfconv::ConvGroups& grp, const pfconv::ConvGeom& 
     a.w = reinterpret_cast<const char*>(d.weight); a.bias = d.bias;
     a.out = d.out + d.off_out; a.ld_out = d.ld_out;
     a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_relu = d.in_relu;
-    a.stats = d.stats_out; a.scale = d.scale; a.relu = d.epilogue == PF_EPI_RELU;
+    a.stats = d.stats_out; a.scale = d.scale; a.relu = d.epilogue == PF_EPI_RELU || d.epilogue == PF_EPI_RELU_RES;
+    a.res = d.epilogue == PF_EPI_RELU_RES ? d.h : nullptr; a.ld_res = d.ld_h;
     a.Bn = g.M / g.N; a.H = g.H; a.W = g.W;
     a.seg = ec_segment(g);
     a.nseg = g.H / a.seg; a.strips = g.W / 32;

@@ -1036,14 +1036,27 @@ class EncoderPlan:
         bufs = self._bufs
         h, w = H // 2, W // 2
         x, xs = bufs["x0"][0], bufs["xs0"][0]
+        # Layer 1 (3x3 64 -> 64 at 1/2 resolution) on fp32 rows when pf_conv2d hands those launches to the weights-stationary
+        # kernel (pf_conv2d_tile 6, round 5): no twins on this level at all -- the stem writes 67 MB less, conv1's output and the
+        # residual tail stay fp32 rows, the stride-2 convs of layer 2 read fp32 anyway.  Same products, same order: same bits.
+        f0 = self.f_blocks[0]
+        l0_rows = (f0["stride"] == 1 and
+                   lib.conv2d_tile([f0["c1"].desc(x, 0, f0["cin"], bufs["r0"], 0, EPI_RELU)], Bn, h, w) == 6 and
+                   lib.conv2d_tile([f0["c2"].desc(bufs["r0"], 0, f0["cout"], x, 0, EPI_RELU_RES, h=x)], Bn, h, w) == 6)
         if self.stem_direct:
-            lib.enc_stem(images, self.f_stem_w7, self.f_stem_b7, out=x, out_split=xs, relu=True)
+            lib.enc_stem(images, self.f_stem_w7, self.f_stem_b7, out=x, out_split=None if l0_rows else xs, relu=True)
         else:
             lib.space_to_depth2(images, bufs["s2d"])
-            lib.conv2d([self.f_stem.desc(bufs["s2d"], 0, 12, x, 0, EPI_RELU, outs=xs)], Bn, h, w, x)
+            lib.conv2d([self.f_stem.desc(bufs["s2d"], 0, 12, x, 0, EPI_RELU, outs=None if l0_rows else xs)], Bn, h, w, x)
         lvl, cur = 0, 0
         for f in self.f_blocks:
             cin, cout, st = f["cin"], f["cout"], f["stride"]
+            if st == 1 and lvl == 0 and l0_rows:
+                yf, o = bufs["r0"], bufs["x0"][cur ^ 1]
+                lib.conv2d([f["c1"].desc(x, 0, cin, yf, 0, EPI_RELU)], Bn, h, w, x)
+                lib.conv2d([f["c2"].desc(yf, 0, cout, o, 0, EPI_RELU_RES, h=x)], Bn, h, w, o)
+                x, cur = o, cur ^ 1
+                continue
             if st != 1:
                 x_in = x                                    # fp32 input of the two stride-2 convs
                 lvl += 1

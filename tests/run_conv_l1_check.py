@@ -8,7 +8,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from prior_flow_amd import _lib
-from prior_flow_amd._lib import EPI_LINEAR, EPI_RELU, PREC_BF16X3
+from prior_flow_amd._lib import EPI_LINEAR, EPI_RELU, EPI_RELU_RES, PREC_BF16X3
 from prior_flow_amd.engine import Conv, pack_mfma, split_twin
 
 
@@ -24,9 +24,13 @@ def run(shape, out_path):
     sh = ((torch.rand(Bn, 64, generator=g) - 0.5)).to(dev)
     cv = Conv(*pack_mfma(w, b), 3, 3, 64, 64, PREC_BF16X3)
     res = []
-    for affine, relu, stats, epi in ((False, False, True, EPI_LINEAR), (True, True, True, EPI_LINEAR), (True, False, False, EPI_RELU)):
+    hres = (torch.rand(Bn * H * W, 64, generator=g) * 2 - 0.7).to(dev)          # the residual operand of the RELU_RES tail
+    for affine, relu, stats, epi in ((False, False, True, EPI_LINEAR), (True, True, True, EPI_LINEAR), (True, False, False, EPI_RELU),
+                                     (False, False, False, EPI_RELU_RES)):
         out = torch.full((Bn * H * W, 64), float("nan"), device=dev)
         kw = {}
+        if epi == EPI_RELU_RES:
+            kw.update(h=hres)
         if affine:
             kw.update(in_scale=sc, in_shift=sh, in_relu=relu)
         d = cv.desc(x, 0, 64, out, 0, epi, **kw)

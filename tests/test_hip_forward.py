@@ -2,6 +2,7 @@
 against the reference-generated golden flows and the CPU oracle (bar: mean EPE <= 1e-3,
 BASELINE.json).  Run with ``-m gpu`` on an MI355X."""
 import argparse
+import os
 
 import numpy as np
 import pytest
@@ -395,6 +396,37 @@ def test_folded_stem_normalisation_is_bitwise_the_materialised_one(params, monke
     a, b = run("0"), run("1")
     assert float(a.abs().mean()) > 0.1
     assert torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_weights_stationary_encoder_kernel_leaves_the_flow_bitwise(tmp_path):
+    """Round 5: layer 1 of both encoders on pf_enc_conv64_kernel (fnet: folded input norm + fused statistics; cnet: fp32 rows
+    instead of split twins on that level, residual tail in the epilogue) against the halo / all-DMA kernels it replaces
+    (PRIORFLOW_ENC_CONV64=0; read once per process -> child processes): the same products in the same order, so the flow is equal
+    bit for bit -- at 512x1024, where both encoders' launches fill the chip and take the kernel."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import argparse, sys, torch
+sys.path.insert(0, {root!r})
+from prior_flow_amd import det_state_dict, synthetic_pair
+from prior_flow_amd.modules import state_dict_shapes
+from prior_flow_amd.prior_raft import PriOr_RAFT
+m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+m.load_state_dict(det_state_dict(state_dict_shapes()), strict=True)
+m = m.cuda().eval()
+i1, i2 = synthetic_pair(1, 512, 1024, seed=21)
+with torch.no_grad():
+    flow = m(i1.cuda(), i2.cuda(), iters=2, test_mode=True)
+torch.save(flow.cpu(), sys.argv[1])
+"""
+    outs = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"flow_{mode}.pt")
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, PRIORFLOW_ENC_CONV64=mode), timeout=900)
+        outs[mode] = torch.load(path)
+    assert float(outs["0"].abs().mean()) > 0.05 and torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())
 
 
 def test_workspaces_and_graphs_of_several_shapes_stay_resident(params):

@@ -538,7 +538,7 @@ def test_weights_stationary_conv_matches_halo_kernel_bitwise(shape, tmp_path):
     """pf_enc_conv64_kernel (round 5: the encoders' 3x3 64 -> 64 convolutions with W_hi in registers, W_lo in LDS and the input in
     a 10-row ring walked down a 32-column strip) against the halo kernel it replaces (PRIORFLOW_ENC_CONV64=0; both read once per
     process -> child processes, tests/run_conv_l1_check.py): outputs bit-identical with and without the folded input norm + ReLU
-    and with the ReLU epilogue, and the InstanceNorm scale / shift that pf_channel_stats_final makes of the fused partials (per
+    with the ReLU epilogue and with the residual tail (PF_EPI_RELU_RES: cnet's folded-BatchNorm blocks), and the InstanceNorm scale / shift that pf_channel_stats_final makes of the fused partials (per
     row and strip instead of per 8-row tile) equal to 1e-6 (bit-identical in practice).  PRIORFLOW_ENC_CONV64=2 forces the kernel
     onto maps too small to fill the chip (segments of 8 rows, several images, widths of 3 and 5 strips)."""
     import subprocess
@@ -551,8 +551,8 @@ def test_weights_stationary_conv_matches_halo_kernel_bitwise(shape, tmp_path):
                        env=dict(os.environ, PRIORFLOW_ENC_CONV64=mode), timeout=600)
         outs[mode] = torch.load(path)
     old, new = outs["0"], outs["2"]
-    assert [int(t) for t in new[3::4]] == [6, 6, 6] and all(int(t) in (3, 5) for t in old[3::4])
-    for k in range(3):
+    assert [int(t) for t in new[3::4]] == [6, 6, 6, 6] and all(int(t) in (3, 5) for t in old[3::4])
+    for k in range(4):
         o0, sc0, sh0 = old[4 * k: 4 * k + 3]
         o1, sc1, sh1 = new[4 * k: 4 * k + 3]
         assert torch.isfinite(o1).all() and torch.equal(o0, o1), (k, float((o0 - o1).abs().max()))
