@@ -12,7 +12,8 @@
 // and walks DOWN a strip of 32 columns in steps of 4 rows: the input lives in a 10-row ring in LDS (the 6 rows a step reads + the
 // 4 new rows of the next step, staged -- affine + ReLU of the previous layer's norm, bf16 hi|lo split -- while the step multiplies),
 // so a pixel is fetched once per strip (+ 2 halo columns), not once per tile and chunk.  8 waves = 2 channel tiles x 4 rows, one
-// 32 x 32 accumulator each; one barrier per step.  K order, pass order and the statistics' summation order are the halo kernel's:
+// 32 x 32 accumulator each; the two channel tiles ALTERNATE between a matrix phase (a whole step) and a vector phase (epilogue +
+// staging), one barrier per phase.  K order, pass order and the statistics' summation order are the halo kernel's:
 // outputs and fused InstanceNorm partials are BIT-IDENTICAL to it (tests/test_hip_kernels.py).
 // LDS: 73 728 + 10 x 34 x 256 = 160 768 B of the 163 840.
 #include <stdlib.h>
@@ -28,11 +29,11 @@ constexpr int EC_WLO = EC_KSTEPS * 2048;             // [k-step][channel tile][k
 constexpr int EC_AFF = EC_WLO + EC_RING * EC_ROWB;   // input affine of the image: scale[64], shift[64] fp32
 constexpr int EC_LDS = EC_AFF + 512;
 constexpr int EC_WROW = 9 * 64 * 4;                  // bytes of one output channel's packed weights: [tap][64 ch as 2 x {hi[32], lo[32]}]
+#ifndef PF_EC_AHEAD                                  // K-steps the fragment reads run ahead of the MFMAs (1: 123-126 us, 2: 130-135 us on 4 images)
+#define PF_EC_AHEAD 1
+#endif
 #ifndef PF_EC_ABL                                    // timing-only diagnosis builds: 1 no staging, 2 no epilogue, 4 no K loop
 #define PF_EC_ABL 0
-#endif
-#ifndef PF_EC_DEFER                                  // 1: a step's outputs are written at the start of the wave's NEXT half-step (A/B)
-#define PF_EC_DEFER 0
 #endif
 
 struct EcArgs {
@@ -148,6 +149,36 @@ pf_enc_conv64_kernel(const EcArgs a) {
             convert_store(st[u], ok[u], rowb + (u < 4 ? lm_hi : lh_hi), rowb + (u < 4 ? lm_lo : lh_lo));
         }
     };
+    // The same for ONE group of four waves (256 threads) and TWO rows (the ping-pong schedule below: a group stages half of a
+    // step's new rows in its vector phase).  Thread -> channels f4 of columns 1 + cgl and 17 + cgl of both rows; threads with
+    // cgl < 4 also the halo column 33 (cgl & 1) of row cgl >> 1.
+    const int cgl = (tid & 255) >> 4;
+    const int hcol2 = (cgl & 1) * 33, hrow2 = cgl >> 1;
+    const bool has_halo2 = cgl < 4;
+    const bool xok_h2 = hcol2 ? (x0 + 32 < a.W) : (x0 > 0);
+    const int goff_g0 = (x0 + cgl) * a.ld_in, goff_g1 = (x0 + cgl + 16) * a.ld_in, goff_gh = (x0 - 1 + hcol2) * a.ld_in;
+    const unsigned lg0_hi = lds_px(cgl + 1), lg0_lo = lds_px_lo(cgl + 1), lg1_hi = lds_px(cgl + 17), lg1_lo = lds_px_lo(cgl + 17);
+    const unsigned lgh_hi = lds_px(hcol2), lgh_lo = lds_px_lo(hcol2);
+    auto grp_load = [&](int rr0, bool live, f32x4 (&st)[5], bool (&ok)[5]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int rr = rr0 + (u < 4 ? (u >> 1) : hrow2), y = yseg + rr;
+            const bool yok = y >= 0 && y < a.H;
+            ok[u] = live && yok && (u < 4 ? true : (xok_h2 && has_halo2));
+            const float* src = in_img + (long)(yok ? y : 0) * a.W * a.ld_in + (u < 4 ? ((u & 1) ? goff_g1 : goff_g0) : goff_gh);
+            st[u] = ok[u] ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto grp_store = [&](int rr0, bool live, const f32x4 (&st)[5], const bool (&ok)[5]) __attribute__((always_inline)) {
+        if (!live) return;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            if (u == 4 && !has_halo2) continue;
+            const int rr = rr0 + (u < 4 ? (u >> 1) : hrow2);
+            const unsigned rowb = (unsigned)(((rr + 1 + EC_RING) % EC_RING) * EC_ROWB);
+            convert_store(st[u], ok[u], rowb + (u < 4 ? ((u & 1) ? lg1_hi : lg0_hi) : lgh_hi), rowb + (u < 4 ? ((u & 1) ? lg1_lo : lg0_lo) : lgh_lo));
+        }
+    };
     // prologue: rows -1 .. 4 of the segment (what step 0 reads); rows 5, 6 are staged again by the loop (harmless)
     {
         f32x4 pst[5]; bool pok[5];
@@ -179,7 +210,8 @@ pf_enc_conv64_kernel(const EcArgs a) {
     double s1 = 0.0, s2 = 0.0;          // InstanceNorm statistics of this wave's rows of the segment (one partial per wave and item)
     f32x4 st[5]; bool st_ok[5];
     unsigned ar9[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};        // LDS address of pixel (row ky, column li + kx) of this step, per tap
-    bf16x8 ahi[2], alo[2], blo[2];
+    constexpr int NB = PF_EC_AHEAD + 1;
+    bf16x8 ahi[NB], alo[NB], blo[NB];       // fragments in flight: the reads run PF_EC_AHEAD K-steps ahead of the MFMAs
     auto frag = [&](auto S, int buf) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
         constexpr int c = s / 18, tap = (s >> 1) % 9, h = s & 1, ky = tap / 3, kx = tap % 3;
@@ -196,18 +228,16 @@ pf_enc_conv64_kernel(const EcArgs a) {
         }
 #endif
     };
-    auto khalf = [&](auto HALF) __attribute__((always_inline)) {     // K-steps 18 HALF .. 18 HALF + 17; the operands of K-step s + 1 are read while s multiplies
-        constexpr int s0 = decltype(HALF)::value * (EC_KSTEPS / 2);
-        frag(std::integral_constant<int, s0>{}, s0 & 1);
-        ec_for<s0, s0 + EC_KSTEPS / 2>([&](auto S) __attribute__((always_inline)) {
-            constexpr int s = decltype(S)::value, b = s & 1;
+    // A whole step: 36 K-steps, the operands of the next PF_EC_AHEAD K-steps in flight while one multiplies
+    auto kloop = [&]() __attribute__((always_inline)) {
+        ec_for<0, PF_EC_AHEAD>([&](auto S) __attribute__((always_inline)) { frag(S, decltype(S)::value % NB); });
+        ec_for<0, EC_KSTEPS>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value, b = s % NB;
+            constexpr int left = EC_KSTEPS - 1 - s;                 // K-steps after this one
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (s + 1 < s0 + EC_KSTEPS / 2) {
-                frag(std::integral_constant<int, s + 1>{}, b ^ 1);
-                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ahi[b]), "+v"(alo[b]), "+v"(blo[b]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ahi[b]), "+v"(alo[b]), "+v"(blo[b]));
-            }
+            if constexpr (left >= PF_EC_AHEAD) frag(std::integral_constant<int, s + PF_EC_AHEAD>{}, (s + PF_EC_AHEAD) % NB);
+            // (everything but the reads of the K-steps still ahead has arrived)
+            asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(ahi[b]), "+v"(alo[b]), "+v"(blo[b]) : "n"(3 * (left < PF_EC_AHEAD ? left : PF_EC_AHEAD)));
             __builtin_amdgcn_sched_barrier(0);
             // the halo kernel's pass order: x_lo * w_hi, x_hi * w_lo, x_hi * w_hi
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[b], whi[s], s == 0 ? zero16 : acc, 0, 0, 0);
@@ -215,6 +245,7 @@ pf_enc_conv64_kernel(const EcArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[b], whi[s], acc, 0, 0, 0);
         });
         __builtin_amdgcn_sched_barrier(0);
+
     };
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         // this wave's row of step t: 32 pixels x 32 channels; acc[r] = pixel (r & 3) + 8 (r >> 2) + 4 lh, channel 32 nt + li
@@ -273,38 +304,38 @@ pf_enc_conv64_kernel(const EcArgs a) {
             }
         }
     };
-    // Order inside a half-step: a wave that finished a step in its previous half-step writes that step's outputs FIRST, then runs
-    // its K-steps; its partner goes straight into its K-steps.  So the partner's MFMAs run while this wave stores, and this wave's
-    // MFMAs run while the partner converts the staged rows at the end of its half-step.
-    for (int hs = 0; hs <= 2 * nsteps + 1; ++hs) {
-        // (a raw barrier: __syncthreads() also waits vmcnt(0), i.e. for the output stores just issued and for the row loads in
-        // flight -- up to 2 us per half-step; only the LDS traffic has to be complete here)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int ts = hs >> 1;                              // the step whose successor's rows are staged in this pair of half-steps
-        const bool more = ts + 1 < nsteps && !(abl & 1);
-        if (!(hs & 1)) rows_load(4 * ts + 5, more, st, st_ok);      // rows 4 ts + 5 .. 4 ts + 8, in flight during this half-step
-        const int q = hs - grp;                              // this wave's own half-step
-        const int t = q >> 1;
-#if PF_EC_DEFER
-        if (q >= 2 && !(q & 1) && q <= 2 * nsteps && !(abl & 4)) epilogue(t - 1);       // the step finished in half-step q - 1
-#endif
-        if (q >= 0 && q < 2 * nsteps && !(abl & 4)) {
-            if (!(q & 1)) {
+    // ---- main loop: the two groups ALTERNATE.  In a half-step one group multiplies a whole step (36 K-steps, 108 MFMAs per wave)
+    // while the other does everything that is not matrix work: the epilogue of the step it has just finished (bias / ReLU /
+    // residual, transposes, stores, statistics) and the staging of half of the next step's new rows (loads first, their latency
+    // under the epilogue, then affine + split + LDS writes).  So on every SIMD one wave's MFMAs run beside its partner's vector
+    // and memory instructions all the time -- in the round's first schedule (both waves multiplied half a step per half-step, then
+    // both converted) the two waves of a SIMD shared the matrix pipe and then both left it idle: 13.8 K cycles per step for 6.9 K
+    // of MFMA, 142 us per launch on four images against 123 with the alternation.  Group 0 multiplies step t in half-step 2 t, group 1 in 2 t + 1.  New rows of step s (4 s + 1 .. 4 s + 4):
+    // group 1 stages the first two in half-step 2 s - 2, group 0 the last two in 2 s - 1; their ring slots held rows only step s - 2
+    // read, which both groups have left by then, and the slots the multiplying group reads (rows 4 t - 1 .. 4 t + 4) are never
+    // written in the same half-step.  One barrier per half-step.
+    for (int hs = 0; hs <= 2 * nsteps; ++hs) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (only the LDS traffic has to be complete here)
+        if ((hs & 1) == grp) {
+            const int t = (hs - grp) >> 1;
+            if (t < nsteps && !(abl & 4)) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const unsigned rb = __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(((4 * t + mr + ky) % EC_RING) * EC_ROWB));
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) ar9[ky * 3 + kx] = rb + a_kx[kx];
                 }
-                khalf(std::integral_constant<int, 0>{});
-            } else {
-                khalf(std::integral_constant<int, 1>{});
-#if !PF_EC_DEFER
-                epilogue(t);
-#endif
+                kloop();
             }
+        } else {
+            const int tf = (hs - 1 - grp) >> 1;                    // the step this group multiplied in the previous half-step (-1: none yet)
+            const int sn = tf + 1 + grp;                            // the step whose rows it stages now: group 1 runs one step further ahead
+            const int rr0 = 4 * sn + 1 + 2 * (1 - grp);             // group 1: rows 4 sn + 1, + 2; group 0: rows 4 sn + 3, + 4
+            const bool more = tf >= 0 && sn < nsteps && !(abl & 1); // (step 1's first two rows came with the prologue)
+            grp_load(rr0, more, st, st_ok);
+            if (tf >= 0 && tf < nsteps && !(abl & 4)) epilogue(tf);
+            grp_store(rr0, more, st, st_ok);
         }
-        if (hs & 1) rows_store(4 * ts + 5, more, st, st_ok);        // convert + write the rows loaded in the previous half-step
     }
 }
 
