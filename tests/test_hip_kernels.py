@@ -539,7 +539,7 @@ def test_weights_stationary_conv_matches_halo_kernel_bitwise(shape, tmp_path):
     a 10-row ring walked down a 32-column strip) against the halo kernel it replaces (PRIORFLOW_ENC_CONV64=0; both read once per
     process -> child processes, tests/run_conv_l1_check.py): outputs bit-identical with and without the folded input norm + ReLU
     with the ReLU epilogue and with the residual tail (PF_EPI_RELU_RES: cnet's folded-BatchNorm blocks), and the InstanceNorm scale / shift that pf_channel_stats_final makes of the fused partials (per
-    row and strip instead of per 8-row tile) equal to 1e-6 (bit-identical in practice).  PRIORFLOW_ENC_CONV64=2 forces the kernel
+    segment, row phase and strip instead of per 8-row tile) equal to 1e-6 (bit-identical in practice).  PRIORFLOW_ENC_CONV64=2 forces the kernel
     onto maps too small to fill the chip (segments of 8 rows, several images, widths of 3 and 5 strips)."""
     import subprocess
     import sys
