@@ -42,6 +42,7 @@ struct WgradArgs {
     const float* x1; int ld1, off1, c1;
     const float* dy; int ld_dy, off_dy, cout;
     float* dw;                    // [Cout_pad128][taps][cin_pad]
+    float* db;                    // [Cout] or NULL: db[o] += sum_p dY[p][o], by the workgroups of the first input-channel block
     int B, H, W, kh, kw, cin_pad, nsplit;
 };
 
@@ -80,6 +81,11 @@ pf_wgrad_kernel(const WgradArgs a) {
     constexpr int XROWS = (HPX + 15) / 16 * 16;
     __bf16* const dyt = lds;                                   // ((plane*4 + mb)*TPX + px)*32 + c
     __bf16* const xt = lds + 2 * 4 * TPX * 32;                 // ((plane*NCB + cb)*XROWS + hp)*32 + c
+    // bias gradient (round 5: it was a launch of its own per convolution, pf_col_sum_kernel): the workgroups of the first
+    // input-channel block add the fp32 dY values they stage anyway -- per thread over its 8 pixels of a tile, then into 128 LDS
+    // words, and once per workgroup into db
+    float* const bsum = reinterpret_cast<float*>(xt + 2 * NCB * XROWS * 32);
+    const bool do_db = a.db != nullptr && blockIdx.y == 0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,6 +102,7 @@ pf_wgrad_kernel(const WgradArgs a) {
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    if (do_db && tid < WG_O) bsum[tid] = 0.f;                 // (the first tile's barrier orders it before the first add)
 
     // Software pipeline over this split's tiles: the operands of tile i+1 are fetched into registers while
     // tile i is multiplied out of LDS (the first version loaded, waited, converted and computed serially and
@@ -133,6 +140,13 @@ pf_wgrad_kernel(const WgradArgs a) {
         }
     };
     auto store_y = [&]() __attribute__((always_inline)) {
+        if (do_db) {                                           // rows past the map / channels past cout were loaded as zeros
+            f32x4 sb = ry[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) sb = sb + ry[q];
+            float* bp = bsum + (tid & 31) * 4;
+            atomicAdd(bp, sb.x); atomicAdd(bp + 1, sb.y); atomicAdd(bp + 2, sb.z); atomicAdd(bp + 3, sb.w);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int e = tid + 512 * q, px = e >> 5, cg = (e & 31) * 4;
@@ -193,6 +207,10 @@ pf_wgrad_kernel(const WgradArgs a) {
             }
         }
     }
+    if (do_db) {
+        __syncthreads();
+        if (tid < WG_O && o0 + tid < a.cout) atomicAdd(a.db + o0 + tid, bsum[tid]);
+    }
     // ---- epilogue: D[row = output channel][col = input channel]; lane = column ---------------------------
     const int li = lane & 31, lh = lane >> 5;
     const int c = c00 + 32 * cb + li;
@@ -214,7 +232,7 @@ template <int KH, int KW>
 int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     constexpr int HPX = (TH + KH - 1) * (TW + KW - 1), XROWS = (HPX + 15) / 16 * 16;
     constexpr int NCB = KH * KW > 5 ? 1 : 2;
-    constexpr size_t lds = (size_t)(2 * 4 * TPX * 32 + 2 * NCB * XROWS * 32) * 2;
+    constexpr size_t lds = (size_t)(2 * 4 * TPX * 32 + 2 * NCB * XROWS * 32) * 2 + WG_O * sizeof(float);      // + the bias sums
     static_assert(lds <= 160 * 1024, "LDS budget");
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_wgrad_kernel<KH, KW>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -465,6 +483,9 @@ extern "C" int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const
     WgradArgs a;
     a.x0 = x0; a.ld0 = ld0; a.off0 = off0; a.c0 = c0; a.x1 = x1; a.ld1 = ld1; a.off1 = off1; a.c1 = c1;
     a.dy = dy; a.ld_dy = ld_dy; a.off_dy = off_dy; a.cout = cout; a.dw = dw;
+    // PRIORFLOW_WGRAD_DB=0: the bias gradient as its own launch (pf_col_sum_kernel), round 4's form (A/B)
+    static const bool fused_db = [] { const char* e = getenv("PRIORFLOW_WGRAD_DB"); return !(e && e[0] == '0'); }();
+    a.db = fused_db ? db : nullptr;
     a.B = B; a.H = H8; a.W = W8; a.kh = kh; a.kw = kw;
     a.cin_pad = (c0 + c1 + 31) / 32 * 32;
     // split-K: enough workgroups for ~4 per CU, at most one per pixel tile
@@ -483,7 +504,7 @@ extern "C" int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const
     else if (kh == 1 && kw == 1) rc = launch_wgrad<1, 1>(a, s);
     else return PF_ERR_BAD_SHAPE;
     if (rc) return rc;
-    if (db) {
+    if (db && !fused_db) {
         const long rows = (long)B * H8 * W8;
         const long chunks = (rows + 255) / 256;
         if (chunks > 65535) return PF_ERR_BAD_SHAPE;
