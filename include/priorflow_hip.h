@@ -353,6 +353,8 @@ int pf_flow_head_out(const float* x, int ld, int C, const float* weight, const f
 
 /* coords1 += delta (core/prior_raft.py:193,196).  delta: channel-last, 2 channels at column 0. */
 int pf_coords_add(float* coords1, const float* delta, int ld, int B, int H8, int W8, void* stream);
+/* dst = src + delta: the same update into the next iteration's coordinates (the training loop keeps every iteration's). */
+int pf_coords_add_to(const float* src, const float* delta, int ld, float* dst, int B, int H8, int W8, void* stream);
 
 /* upsample_flow (core/prior_raft.py:58-67): convex 8x upsampling of flow = coords1 - coords0.
  * mask: channel-last [B*N][ld] (576 logits, already scaled by 0.25).  out: [B,2,8*H8,8*W8]. */
@@ -472,9 +474,12 @@ int pf_gru_dx_finish(const float* f1, int ld_f1, const float* f2, int ld_f2, con
 int pf_pyramid_bwd(float* g0, const float* g1, const float* g2, const float* g3, int B, int H8, int W8, void* stream);
 int pf_dccl_combine_bwd(const float* d_corr, int ld_in, const float* g_back, float* d_raw, int ld,
                         int B, int H8, int W8, void* stream);
-int pf_dccl_lookup_bwd(const float* coords, const float* g_w2c, const float* d_own, const float* d_raw, int ld,
+/* Backward of pf_dccl_lookup (core/corr.py:113-144): the gradients of its two outputs (d_own, d_raw: [B*N][ld] rows, 324 channels)
+ * scattered into the two pyramids' level gradients (accumulated).  clear_raw != 0: every d_raw value read is replaced by 0, so
+ * the buffer is ready for the next pf_dccl_combine_bwd, which scatters into it (one fill launch per iteration less). */
+int pf_dccl_lookup_bwd(const float* coords, const float* g_w2c, const float* d_own, float* d_raw, int ld,
                        float* own0, float* own1, float* own2, float* own3,
-                       float* oth0, float* oth1, float* oth2, float* oth3, int B, int H8, int W8, void* stream);
+                       float* oth0, float* oth1, float* oth2, float* oth3, int B, int H8, int W8, int clear_raw, void* stream);
 
 /* Weight and bias gradient of a stride-1 convolution (what autograd computes for every nn.Conv2d of
  * core/update.py / core/extractor.py in `loss.backward()`, train_flow.py:135):

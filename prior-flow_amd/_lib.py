@@ -117,6 +117,7 @@ _SIGNATURES = {
     "pf_norm_act": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_flow_head_out": [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_coords_add": [_fp, _fp, _i, _i, _i, _i, _fp],
+    "pf_coords_add_to": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_upsample_flow": [_fp, _fp, _i, _fp, _i, _i, _i, _fp],
     "pf_to_channel_last": [_fp, _i, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_space_to_depth2": [_fp, _i, _fp, _i, _i, _i, _i, _fp],
@@ -131,7 +132,7 @@ _SIGNATURES = {
     "pf_gru_q_bwd": [_fp, _i] * 7 + [C.c_long, _i, _fp],
     "pf_gru_zr_bwd": [_fp, _i] * 7 + [C.c_long, _i, _fp],
     "pf_dccl_combine_bwd": [_fp, _i, _fp, _fp, _i, _i, _i, _i, _fp],
-    "pf_dccl_lookup_bwd": [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pf_dccl_lookup_bwd": [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_conv2d_wgrad": [_fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_seq_loss": [_fp, _fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, _i, _i, _i, _fp],
     "pf_sum_squares": [_fp, C.c_long, _fp, _i, _fp],
@@ -521,11 +522,18 @@ class PfLib:
                                             _ptr(delta), 0 if delta is None else delta.shape[-1], B, H, W,
                                             self._stream(x)), "pf_flow_head_out")
 
-    def coords_add(self, coords1, delta):
-        self._chk(coords1, delta)
+    def coords_add(self, coords1, delta, src=None):
+        """coords1 += delta, or (src given) coords1 = src + delta."""
+        self._chk(coords1, delta, src)
         B, _, H, W = coords1.shape
-        self._rc(self._dll.pf_coords_add(_ptr(coords1), _ptr(delta), delta.shape[-1], B, H, W,
-                                         self._stream(coords1)), "pf_coords_add")
+        if src is None:
+            self._rc(self._dll.pf_coords_add(_ptr(coords1), _ptr(delta), delta.shape[-1], B, H, W,
+                                             self._stream(coords1)), "pf_coords_add")
+        else:
+            if src.shape != coords1.shape:
+                raise PfError("pf_coords_add_to: src and dst differ in shape")
+            self._rc(self._dll.pf_coords_add_to(_ptr(src), _ptr(delta), delta.shape[-1], _ptr(coords1), B, H, W,
+                                                self._stream(coords1)), "pf_coords_add_to")
 
     def upsample_flow(self, coords1, mask, out):
         self._chk(coords1, mask, out)
@@ -664,12 +672,14 @@ class PfLib:
         self._rc(self._dll.pf_dccl_combine_bwd(_ptr(d_corr), d_corr.shape[-1], _ptr(g_back), _ptr(d_raw), d_raw.shape[-1],
                                                B, H8, W8, self._stream(d_corr)), "pf_dccl_combine_bwd")
 
-    def dccl_lookup_bwd(self, coords, g_w2c, d_own, d_raw, g_own, g_other):
-        """g_own / g_other: lists of 4 level gradients [B*N, H_i*W_i], accumulated into."""
+    def dccl_lookup_bwd(self, coords, g_w2c, d_own, d_raw, g_own, g_other, clear_raw=False):
+        """g_own / g_other: lists of 4 level gradients [B*N, H_i*W_i], accumulated into.  clear_raw: d_raw is left all zero."""
         self._chk(coords, g_w2c, d_own, d_raw, *g_own, *g_other)
         B, _, H, W = coords.shape
+        if d_raw.shape[-1] != d_own.shape[-1]:
+            raise PfError("pf_dccl_lookup_bwd: d_own and d_raw must share their row length")
         self._rc(self._dll.pf_dccl_lookup_bwd(_ptr(coords), _ptr(g_w2c), _ptr(d_own), _ptr(d_raw), d_own.shape[-1],
-                                              *[_ptr(t) for t in g_own], *[_ptr(t) for t in g_other], B, H, W,
+                                              *[_ptr(t) for t in g_own], *[_ptr(t) for t in g_other], B, H, W, int(clear_raw),
                                               self._stream(coords)), "pf_dccl_lookup_bwd")
 
     def conv2d_wgrad(self, x0, off0, c0, dy, off_dy, cout, dw, db, kh, kw, B, H8, W8, x1=None, off1=0, c1=0):

@@ -677,6 +677,7 @@ struct PfLookupBwdArgs {
     float* g_own[PF_CORR_LEVELS];         // level i: [B*N][H_i*W_i]  (accumulated)
     float* g_other[PF_CORR_LEVELS];
     int B, H, W, ld;
+    float* clear_raw;                     // NULL, or d_raw again: every value read is replaced by 0 (the next pf_dccl_combine_bwd scatters into it)
 };
 PF_HD void pf_lookup_bwd_elem(long idx, const PfLookupBwdArgs& a) {     // idx over B*N*324
     const long N = (long)a.H * a.W;
@@ -700,6 +701,7 @@ PF_HD void pf_lookup_bwd_elem(long idx, const PfLookupBwdArgs& a) {     // idx o
     const float cy = a.coords[(b * 2 + 1) * N + n] * inv + (float)(tb - PF_CORR_RADIUS);
     const long lsz = (long)Hl * Wl;
     const float go = a.d_own[row * a.ld + kk], gr = a.d_raw[row * a.ld + kk];
+    if (a.clear_raw) a.clear_raw[row * a.ld + kk] = 0.f;
     const PfTaps t = pf_taps0(pf_pymod(cx, (float)Wl), cy, Hl, Wl);
     float* own = a.g_own[lvl] + row * lsz;
     for (int j = 0; j < 4; ++j)
@@ -824,11 +826,12 @@ PF_HD void pf_upsample_bwd_elem(long idx, const PfUpsampleBwdArgs& a) {  // idx 
 }
 
 // coords1 += delta  (core/prior_raft.py:193,196); delta is channel-last [B*N][ld]
-struct PfCoordsAddArgs { float* coords1; const float* delta; int B, N, ld; };
+struct PfCoordsAddArgs { float* coords1; const float* delta; int B, N, ld; const float* src; };   // src: coords1 = src + delta (NULL: in place)
 PF_HD void pf_coords_add_elem(long idx, const PfCoordsAddArgs& a) {   // idx over B*N
     const long b = idx / a.N, n = idx % a.N;
-    a.coords1[(b * 2 + 0) * a.N + n] += a.delta[idx * a.ld + 0];
-    a.coords1[(b * 2 + 1) * a.N + n] += a.delta[idx * a.ld + 1];
+    const float* from = a.src ? a.src : a.coords1;
+    a.coords1[(b * 2 + 0) * a.N + n] = from[(b * 2 + 0) * a.N + n] + a.delta[idx * a.ld + 0];
+    a.coords1[(b * 2 + 1) * a.N + n] = from[(b * 2 + 1) * a.N + n] + a.delta[idx * a.ld + 1];
 }
 
 // ----------------------------------------------------------------------------------------------

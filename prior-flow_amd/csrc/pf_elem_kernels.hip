@@ -956,6 +956,7 @@ __global__ void __launch_bounds__(kBlock) pf_lookup_bwd_rows(const PfLookupBwdAr
             const float cy = c0y * inv + (float)(tb - PF_CORR_RADIUS);
             const long lsz = (long)Hl * Wl;
             const float go = a.d_own[row * a.ld + kk], gr = a.d_raw[row * a.ld + kk];
+            if (a.clear_raw) a.clear_raw[row * a.ld + kk] = 0.f;
             const int ox = org[4 * lvl], oy = org[4 * lvl + 1], qx = org[4 * lvl + 2], qy = org[4 * lvl + 3];
             float* own = a.g_own[0];
             float* oth = a.g_other[0];

@@ -222,8 +222,7 @@ class LoopFn(torch.autograd.Function):
             cv(*[(t + ".m0", S["h"][i + 1], 0, 128, S["mh"][i], 0, EPI_RELU, {}) for t, S in SS])
             cv(*[(t + ".m2", S["mh"][i], 0, 256, S["mask"][i], 0, EPI_LINEAR, dict(scale=0.25)) for t, S in SS])
             for S in (A, Bb):
-                S["c"][i + 1].copy_(S["c"][i])
-                lib.coords_add(S["c"][i + 1], S["delta"][i])          # coords1 += delta_flow (prior_raft.py:193,196)
+                lib.coords_add(S["c"][i + 1], S["delta"][i], src=S["c"][i])     # coords1 += delta_flow (prior_raft.py:193,196), every iteration's kept
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
@@ -265,6 +264,7 @@ class LoopFn(torch.autograd.Function):
         SS = (("a", A), ("b", Bb))
         for _t, S in SS:
             S["d_flow"].zero_()
+            S["d_raw"].zero_()           # once per backward: every pf_dccl_lookup_bwd below leaves it zero again (clear_raw)
         gh: Dict[str, Optional[torch.Tensor]] = {"a": None, "b": None}        # gradient of the hidden state an iteration hands on
         # The hidden-state chain (heads, GRU) is the only dependency between iterations; the motion encoders' data gradients, the
         # DCCL and warp backwards of iteration i hang off it and run on a side stream beside the chain of iteration i - 1.
@@ -328,10 +328,10 @@ class LoopFn(torch.autograd.Function):
                 dg(("a.cf2", A["d_cat"][i], 256, 16, A["d_cf1"][i], 0, EPI_MASK, dict(h=A["cf1"][i])))
                 dg(("a.cf1", A["d_cf1"][i], 0, 32, A["d_conf"], 0, EPI_LINEAR, {}))
                 for t, S in SS:
-                    S["d_raw"].zero_()
                     g_back = g_b2a_8 if t == "a" else g_a2b_8
-                    lib.dccl_combine_bwd(S["d_corr"], g_back, S["d_raw"], B, H8, W8)
-                    lib.dccl_lookup_bwd(S["c"][i], g_back, S["d_corr"], S["d_raw"], pg_a if t == "a" else pg_b, pg_b if t == "a" else pg_a)
+                    lib.dccl_combine_bwd(S["d_corr"], g_back, S["d_raw"], B, H8, W8)       # scatters into the zeroed d_raw
+                    lib.dccl_lookup_bwd(S["c"][i], g_back, S["d_corr"], S["d_raw"], pg_a if t == "a" else pg_b, pg_b if t == "a" else pg_a,
+                                        clear_raw=True)
                 lib.warp_gcorr_bwd(f1r, f2r, A["c"][i], False, A["d_conf"], 0, d_f1, d_f2)
                 lib.to_nchw(A["flow4"][i], 2, 2, A["flow_ba"])
                 lib.warp_gcorr_bwd(f1r, f2r, A["flow_ba"], True, A["d_conf"], 4, d_f1, d_f2)

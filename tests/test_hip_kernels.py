@@ -730,6 +730,42 @@ torch.save(res, sys.argv[1])
 
 
 @pytest.mark.gpu
+def test_lookup_backward_clears_its_raw_gradient_and_coords_add_to(lib, dev):
+    """Round 5, two launches per iteration less in the training loop: pf_dccl_lookup_bwd(clear_raw=1) leaves d_raw all zero (the
+    next pf_dccl_combine_bwd scatters into it) and gives the same gradients; pf_coords_add_to writes src + delta to another buffer
+    (the in-place form behind a copy, bit for bit)."""
+    import math
+    from prior_flow_amd.engine import rotation_x
+    B, H8, W8 = 2, 24, 40
+    N = H8 * W8
+    g = torch.Generator().manual_seed(3)
+    xs = torch.arange(W8).view(1, 1, 1, W8).expand(B, 1, H8, W8).float()
+    ys = torch.arange(H8).view(1, 1, H8, 1).expand(B, 1, H8, W8).float()
+    coords = (torch.cat([xs, ys], 1) + (torch.rand(B, 2, H8, W8, generator=g) * 10 - 5)).contiguous().to(dev)
+    g8 = torch.empty(2, H8, W8, device=dev)
+    lib.sample_grid(g8, rotation_x(math.pi / 2))
+    d_own = (torch.rand(B * N, 324, generator=g) - 0.5).to(dev)
+    d_raw = (torch.rand(B * N, 324, generator=g) - 0.5).to(dev)
+    outs = []
+    for clear in (False, True):
+        own = [torch.zeros(B * N, (H8 >> i) * (W8 >> i), device=dev) for i in range(4)]
+        oth = [torch.zeros(B * N, (H8 >> i) * (W8 >> i), device=dev) for i in range(4)]
+        raw = d_raw.clone()
+        lib.dccl_lookup_bwd(coords, g8, d_own, raw, own, oth, clear_raw=clear)
+        assert (float(raw.abs().max()) == 0.0) if clear else torch.equal(raw, d_raw)
+        outs.append(own + oth)
+    for a, b in zip(*outs):
+        assert float(a.abs().max()) > 0.1 and float((a - b).abs().max()) < 1e-5
+    delta = torch.zeros(B * N, 4, device=dev)
+    delta[:, :2] = (torch.rand(B * N, 2, generator=g) - 0.5).to(dev)
+    inplace = coords.clone()
+    lib.coords_add(inplace, delta)
+    dst = torch.full_like(coords, float("nan"))
+    lib.coords_add(dst, delta, src=coords)
+    assert torch.equal(dst, inplace) and not torch.equal(dst, coords)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 64, 128), (2, 24, 40), (1, 17, 27)])
 def test_lookup_window_kernel_matches_per_thread_kernel_bitwise(dev, shape, tmp_path):
     """pf_lookup_win_kernel (a wave per pixel: shared x / y tap geometry, cooperative window loads through LDS;
