@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of single pf_conv2d launches at the 512x1024 problem size (B=1, 64x128 map):
    python profiles/microbench_conv.py [reps] [which]
-which: c1 (1x1 324->256 x2), zr (grouped 1x5 384->256 GRU gates), q (1x5 384->128), c2 (3x3 256->128|192), fh1 (3x3 128->256 x3)
+which: l1 / l2 / l3 (encoder 3x3 convs, MB_BATCH images), c1 (1x1 324->256 x2), zr (grouped 1x5 384->256 GRU gates), q (1x5 384->128), c2 (3x3 256->128|192), fh1 (3x3 128->256 x3)
 Prints HIP-event time per launch and algorithmic TFLOP/s; used under rocprofv3 --pmc."""
 import os
 import sys
@@ -37,6 +37,54 @@ def conv(cin, cout, kh, kw):
     return Conv(wp, bp, kh, kw, cin, cout, prec)
 
 
+def time_launches(fn, reps):
+    """us per launch: back to back (default), or MB_COLD=1: each launch behind a 512 MB fill (operands from HBM, as in a forward
+    where the previous kernel wrote them), median of the per-launch event times."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    if os.environ.get("MB_COLD", "0") != "1":
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) * 1e3 / reps
+    spoil = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    ts = []
+    for _ in range(reps):
+        spoil.fill_(1)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
+if which in ("l2", "l3"):  # encoder layer-2 / layer-3 convs: 3x3 96 -> 96 at 1/4 (128 x 256), 128 -> 128 at 1/8 (64 x 128), MB_BATCH images;
+    # MB_AFFINE=1: with the folded input norm + ReLU and the fused statistics (fnet's form: the symmetric halo kernel)
+    from prior_flow_amd._lib import EPI_LINEAR
+    H8, W8, C = (128, 256, 96) if which == "l2" else (64, 128, 128)
+    N = H8 * W8
+    xin = rnd(BATCH * N, C)
+    yout = torch.empty(BATCH * N, C, device=dev)
+    cvx = conv(C, C, 3, 3)
+    kw = {}
+    if os.environ.get("MB_AFFINE", "0") == "1":
+        sc, sh = (torch.rand(BATCH, C, generator=g) + 0.5).to(dev), (torch.rand(BATCH, C, generator=g) - 0.5).to(dev)
+        kw = dict(in_scale=sc, in_shift=sh, in_relu=True)
+    descs = [cvx.desc(xin, 0, C, yout, 0, EPI_LINEAR, **kw)]
+    if kw:
+        nblk = lib.conv2d_stats_blocks(descs, BATCH, H8, W8)
+        part = torch.empty(BATCH * nblk * C * 2, dtype=torch.float64, device=dev)
+        descs = [cvx.desc(xin, 0, C, yout, 0, EPI_LINEAR, stats=part, **kw)]
+    flops = 2.0 * BATCH * N * C * 9 * C
+    us = time_launches(lambda: lib.conv2d(descs, BATCH, H8, W8, xin), reps)
+    print(f"{which} x{BATCH}{' affine+stats' if kw else ''}: tile {lib.conv2d_tile(descs, BATCH, H8, W8)} roles {lib.conv2d_roles(descs, BATCH, H8, W8)}  "
+          f"{us:.1f} us/launch  {flops / us / 1e6:.1f} TFLOP/s algorithmic")
+    sys.exit(0)
+
 if which == "l1":        # encoder layer-1 conv: 3x3 64 -> 64 at 1/2 resolution (256 x 512), MB_BATCH images
     H8, W8 = 256, 512
     N = H8 * W8
@@ -44,18 +92,16 @@ if which == "l1":        # encoder layer-1 conv: 3x3 64 -> 64 at 1/2 resolution 
     yout = torch.empty(BATCH * N, 64, device=dev)
     cv1 = conv(64, 64, 3, 3)
     descs = [cv1.desc(xin, 0, 64, yout, 0, EPI_RELU)]
+    if os.environ.get("MB_AFFINE", "0") == "1":        # fnet's form: folded input norm + ReLU, fused statistics
+        from prior_flow_amd._lib import EPI_LINEAR
+        sc, sh = (torch.rand(BATCH, 64, generator=g) + 0.5).to(dev), (torch.rand(BATCH, 64, generator=g) - 0.5).to(dev)
+        kw = dict(in_scale=sc, in_shift=sh, in_relu=True)
+        nblk = lib.conv2d_stats_blocks([cv1.desc(xin, 0, 64, yout, 0, EPI_LINEAR, **kw)], BATCH, H8, W8)
+        part = torch.empty(BATCH * nblk * 64 * 2, dtype=torch.float64, device=dev)
+        descs = [cv1.desc(xin, 0, 64, yout, 0, EPI_LINEAR, stats=part, **kw)]
     flops = 2.0 * BATCH * N * 64 * 9 * 64
-    for _ in range(3):
-        lib.conv2d(descs, BATCH, H8, W8, xin)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(reps):
-        lib.conv2d(descs, BATCH, H8, W8, xin)
-    e.record()
-    torch.cuda.synchronize()
-    us = s.elapsed_time(e) * 1e3 / reps
-    print(f"l1 x{BATCH}: tile {lib.conv2d_tile(descs, BATCH, H8, W8)}  {us:.1f} us/launch  {flops / us / 1e6:.1f} TFLOP/s algorithmic  "
+    us = time_launches(lambda: lib.conv2d(descs, BATCH, H8, W8, xin), reps)
+    print(f"l1 x{BATCH}{' affine+stats' if os.environ.get('MB_AFFINE', '0') == '1' else ''}{' cold' if os.environ.get('MB_COLD', '0') == '1' else ''}: tile {lib.conv2d_tile(descs, BATCH, H8, W8)}  {us:.1f} us/launch  {flops / us / 1e6:.1f} TFLOP/s algorithmic  "
           f"{BATCH * N * 64 * 8 / us / 1e6:.2f} TB/s in+out")
     sys.exit(0)
 net = [rnd(N, 128) for _ in range(2)]
