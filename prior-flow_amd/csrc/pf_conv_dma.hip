@@ -434,8 +434,15 @@ pf_conv_dma_kernel(const ConvGroups groups, const ConvGeom g) {
             p0[m] = pix0 + (long)(y0 + wy) * g.W + x0 + 4 * lh;
             plim[m] = p0[m] + (xlim > 0 ? xlim : 0);
         }
+#ifdef PF_DMA_ABL_NO_EPI                                  // (timing-only ablation: the accumulators stay alive, nothing is stored)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[0][NT - 1]), "v"(acc[1][NT - 1]));
+#endif
+        (void)d; (void)p0; (void)plim;
+#else
         if (ragged) tile_epilogue_pair<NT, true>(d, acc, n0 + 32 * NT * wn, li, p0, plim);
         else tile_epilogue_pair<NT, false>(d, acc, n0 + 32 * NT * wn, li, p0, plim);
+#endif
         have = next_item(jm, it);
         // The fragments of the next item's first step were fetched during this item's last step, but keeping them (64 VGPRs)
         // alive across the epilogue (accumulators + GRU operands) does not fit the register file: fetch them again -- their
