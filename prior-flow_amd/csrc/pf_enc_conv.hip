@@ -199,12 +199,8 @@ pf_enc_conv64_kernel(const EcArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
-    // ---- main loop in HALF-steps.  The two waves of a SIMD (wave w and w + 4: the same row, the two channel tiles) run the same
-    // program; in step they would both multiply, then both convert / store.  Waves 4-7 therefore run half a step behind waves 0-3
-    // (K-steps 0..17 of step t in half-step 2 t + grp, K-steps 18..35 + epilogue in 2 t + 1 + grp): while one wave of a SIMD converts
-    // the next rows or stores its outputs, its partner's MFMAs keep the matrix pipe busy.  One barrier per half-step.  The ring
-    // holds exactly the union of what the two groups read (rows 4 t - 1 .. 4 t + 8): the rows of step t + 1 are loaded in half-step
-    // 2 t and written in 2 t + 1 into the slots of rows only step t - 1 read, which both groups have left by then.
+    // ---- state of the main loop (below): the two waves of a SIMD are wave w and w + 4 -- the same row of a step, the two channel
+    // tiles -- and the channel tile is the wave's group
     const int grp = nt;
     f32x16 acc = zero16;
     double s1 = 0.0, s2 = 0.0;          // InstanceNorm statistics of this wave's rows of the segment (one partial per wave and item)
