@@ -64,6 +64,46 @@ def test_null_and_shape_errors_are_reported_without_a_gpu(built_lib):
     assert dll.pf_corr_pyramid(None, None, None, None, None, None, 1, 16, 32, 256, None) == -1
 
 
+def test_conv_launch_plan_is_host_logic(built_lib, monkeypatch):
+    """pf_conv2d_tile / pf_conv2d_stats_blocks launch nothing and need no GPU: which kernel a convolution takes and how many
+    statistics partials it writes is host arithmetic over the descriptor.  Round 5's weights-stationary encoder kernel (tile code
+    6): 3x3 stride 1, 64 -> 64, fp32 rows, bf16x3, a map of whole 32-column strips that fills the chip; its partials are one per
+    (segment of rows, row phase of the 4-row step, strip) with the longest segment that still gives every CU a work item."""
+    from prior_flow_amd import _lib
+    lib = _lib.PfLib(_lib.LIB_PATH, require_cuda=False)
+    fake = 0x1000                                   # never dereferenced by the two introspection calls
+
+    def desc(cin=64, cout=64, k=3, epi=_lib.EPI_LINEAR, **kw):
+        d = _lib.ConvDesc()
+        d.in0, d.ld0, d.off0, d.c0 = fake, cin, 0, cin
+        d.weight, d.bias = fake, fake
+        d.out, d.ld_out, d.off_out, d.cout = fake, cout, 0, cout
+        d.kh = d.kw = k
+        d.epilogue, d.scale, d.precision, d.stride = epi, 1.0, _lib.PREC_BF16X3, 1
+        for name, v in kw.items():
+            setattr(d, name, v)
+        return (_lib.ConvDesc * 1)(d)
+
+    plan = lambda a, B, H, W: (lib._dll.pf_conv2d_tile(a, 1, B, H, W), lib._dll.pf_conv2d_stats_blocks(a, 1, B, H, W))  # noqa: E731
+    # fnet's layer 1 at 512x1024 (four images): 64-row segments -> 4 segments x 4 row phases x 16 strips
+    assert plan(desc(), 4, 256, 512) == (6, 4 * 4 * 16)
+    assert plan(desc(), 2, 256, 512) == (6, 8 * 4 * 16)            # cnet's two images: 32-row segments
+    assert plan(desc(), 1, 256, 512) == (6, 16 * 4 * 16)           # one image: 16-row segments
+    assert plan(desc(), 128, 256, 512)[0] == 6                     # batch 32
+    assert plan(desc(epi=_lib.EPI_RELU_RES, h=fake, ld_h=64), 2, 256, 512)[0] == 6      # cnet's residual tail
+    # not this kernel: too small a map (8-row halo tile: partials per 8 x 32 tile), other channel counts, a width that is no
+    # multiple of 32, a twin output
+    assert plan(desc(), 1, 64, 128) == (3, 16 * 4)
+    t, n = plan(desc(), 1, 128, 256)                               # 128 work items: too few
+    assert t in (3, 5) and n == (128 // (8 if t == 5 else 4)) * 8
+    assert plan(desc(), 4, 128, 256)[0] == 6                       # 512 items
+    assert plan(desc(cin=96, cout=96), 4, 128, 256)[0] == 4
+    assert plan(desc(), 4, 256, 496)[0] == 5
+    assert plan(desc(out_split=fake, lds_out=2), 4, 256, 512)[0] == 5
+    # bad descriptors are refused by the same validation pf_conv2d runs
+    assert lib._dll.pf_conv2d_stats_blocks(desc(cin=62), 1, 1, 64, 128) < 0
+
+
 def test_state_dict_contract():
     from prior_flow_amd.prior_raft import PriOr_RAFT
     args = argparse.Namespace(mixed_precision=False, dropout=0.0)
