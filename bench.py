@@ -19,9 +19,11 @@ Extra objects on the JSON line:
                 with HIP events in a single-stream eager pass): an MFMA conv -> algorithmic FLOPs / time vs the dense bf16
                 MFMA peak (bf16x3 mode issues 3 MFMA FLOPs per algorithmic FLOP: mfma_pipe_util) or the fp32 MFMA peak;
                 a lookup / corr build -> algorithmic bytes (SURVEY.md 8(d)) / time vs 8 TB/s;
-  roofline_conv / roofline_corr / roofline_lookup / roofline_combine
-                the same object for the dominant MFMA conv, the fused correlation-volume + pyramid build (north_star's
-                HBM target), the DCCL lookup and the fused rotate-back + 1x1; kernels_by_time: the top launches by time;
+  roofline_conv / roofline_gru / roofline_corr / roofline_lookup / roofline_combine
+                the same object for the dominant MFMA conv, the SepConvGRU's convolutions (north_star's "MFMA utilisation on
+                the GRU convs": flops / time vs the bf16 peak + the committed PMC MFMA-busy fraction), the fused
+                correlation-volume + pyramid build (north_star's HBM target), the DCCL lookup and the fused rotate-back +
+                1x1; kernels_by_time: the top launches by time;
   cpu_baseline  the CPU oracle (oracle/priorflow_oracle.py, the checker -- never the product)
                 timed on the host cores on the same pair, rank 0 at N=1 only, plus the EPE of
                 the GPU flow against it (`parity`);
@@ -51,7 +53,7 @@ H, W, ITERS = 512, 1024, 12
 # `stats` = --kernel-trace --stats of the graph replay, `pmc` = the FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_traffic.py).
 # `in_replay_us` and `traffic` are attached only when an entry matches the run's workload; otherwise they are null with a note.
 PROFILE_INDEX = "profile_index.json"
-PROFILE = {"stats": None, "pmc": None, "round": None, "note": "no workload selected yet"}      # set by select_profile()
+PROFILE = {"stats": None, "pmc": None, "mfma": None, "round": None, "note": "no workload selected yet"}      # set by select_profile()
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 # what a loop of v_mfma_f32_32x32x16_bf16 and nothing else sustains on all 256 CUs with operands that toggle like real data
@@ -124,10 +126,10 @@ def select_profile(batch, gpus):
         entries = []
     for e in entries:
         if all(e.get(k) == v for k, v in want.items()):
-            PROFILE.update(stats=e.get("stats"), pmc=e.get("pmc"), round=e.get("round"),
+            PROFILE.update(stats=e.get("stats"), pmc=e.get("pmc"), mfma=e.get("mfma"), round=e.get("round"),
                            note="profiles/%s entry for %s" % (PROFILE_INDEX, want))
             return
-    PROFILE.update(stats=None, pmc=None, note="profiles/%s has no entry for %s: in_replay_us / traffic not reported "
+    PROFILE.update(stats=None, pmc=None, mfma=None, note="profiles/%s has no entry for %s: in_replay_us / traffic not reported "
                                               "(the committed profiles are of other workloads)" % (PROFILE_INDEX, want))
 
 
@@ -146,6 +148,23 @@ def pmc_traffic(kernel_substr):
     for name, v in kernels.items():
         if kernel_substr in name:
             return round(v["hbm_bytes_per_launch"])
+    return None
+
+
+def pmc_mfma_busy(kernel_substr):
+    """Matrix-pipe busy fraction of a kernel from the committed PMC pass (profiles/mfma_busy.py: SQ_VALU_MFMA_BUSY_CYCLES over
+    4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8, median over the launches of a single-stream eager run); None when no committed
+    profile matches this run's workload or the file has no such kernel."""
+    if not PROFILE.get("mfma"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", PROFILE["mfma"])) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, v in kernels.items():
+        if kernel_substr in name:
+            return round(v["mfma_busy_fraction"], 4)
     return None
 
 
@@ -335,7 +354,8 @@ def profile_kernels(model, i1, i2):
                           "mfma_issue_vs_real_data_rate": round(ach * 3 / SUSTAINED_BF16_MFMA_TFLOPS, 4),
                           "mfma_real_data_rate_source": "profiles/r3_mfma_rate.txt (MFMA-only loop, toggling operands, 256 CUs)"}
                          if split else {}),
-                      "gflop_per_forward": round(work / 1e9, 1)})
+                      "gflop_per_forward": round(work / 1e9, 1),
+                      "mfma_busy_pmc": pmc_mfma_busy(name)})
         elif work > 0:
             gbps = work / (ms * 1e-3) / 1e9
             o.update({"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -358,6 +378,18 @@ def profile_kernels(model, i1, i2):
         all_ms = sum(by[k][1] for k in convs)
         out["roofline_conv"]["all_conv_kernels"] = {"gflop": round(all_fl / 1e9, 1), "ms": round(all_ms, 3),
                                                     "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
+    # the SepConvGRU's convolutions (core/update.py:46-60; 1x5 then 5x1: z|r fused, then q) -- the north star asks for the MFMA
+    # utilisation "on the GRU convs", so they get an object of their own whatever kernel leads the forward
+    gru = [k for k in convs if ", 1, 5," in k[1] or ", 5, 1," in k[1]]
+    if gru:
+        out["roofline_gru"] = obj(*gru[0])
+        g_fl = sum(by[k][0] for k in gru)
+        g_ms = sum(by[k][1] for k in gru)
+        out["roofline_gru"]["all_gru_kernels"] = {
+            "kernels": [{"kernel": k[1], "launches": by[k][2], "avg_launch_us": round(by[k][1] / by[k][2] * 1e3, 1),
+                         "in_replay_us": replay_stats(k[1]), "mfma_busy_pmc": pmc_mfma_busy(k[1])} for k in gru],
+            "gflop": round(g_fl / 1e9, 1), "ms": round(g_ms, 3), "tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
+            "frac": round(g_fl / (g_ms * 1e-3) / 1e12 / peak_mfma, 4)}
     for kind, key in (("corr", "roofline_corr"), ("lookup", "roofline_lookup"), ("combine", "roofline_combine")):
         ks = [k for k in order if k[0] == kind]
         if ks:

@@ -242,6 +242,11 @@ typedef struct pf_conv_desc {
      * PF_EPI_GRU_ZR also writes r = sigmoid(.) to aux_out[.., 128 + j'] (j' = j - 128; r*h stays at aux_out[.., j'], so
      * ld_aux >= 256) and PF_EPI_GRU_Q also writes q = tanh(.) to aux_out[.., j] (ld_aux >= 128). */
     int save_gates;
+    /* Tile-choice hint (descs[0] of a launch): the number of further launches of the same geometry the caller runs BESIDE this one
+     * on other streams (round 6: branch A's and branch B's update blocks as two chains, core/prior_raft.py:196-211).  The host
+     * counts work items as if those launches' groups were groups of this one, so two half-chip launches keep the tile a
+     * two-group launch takes instead of falling back to the smaller tile that would fill the chip alone.  0 = none. */
+    int co_groups;
 } pf_conv_desc;
 
 /* The tail of DCCL.__call__ fused with the first motion-encoder convolution (core/corr.py:138,

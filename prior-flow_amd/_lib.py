@@ -64,6 +64,7 @@ class ConvDesc(C.Structure):
         ("zeros", _fp), ("zeros_bytes", _i),
         ("pre", _fp), ("ld_pre", _i), ("off_pre", _i),
         ("save_gates", _i),
+        ("co_groups", _i),
     ]
 
 

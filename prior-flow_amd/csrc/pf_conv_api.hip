@@ -71,6 +71,7 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
     g.cin_pad = (f.c0 + f.c1 + KC - 1) / KC * KC;
     g.nchunks = g.cin_pad / KC;
     g.stride = f.stride; g.Hin = H8 * f.stride; g.Win = W8 * f.stride; g.Nin = g.Hin * g.Win;
+    if (f.co_groups < 0 || f.co_groups > MAX_GROUPS) return PF_ERR_BAD_ARG;
     return PF_OK;
 }
 
@@ -80,6 +81,7 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
 // 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3; any map size: edge tiles may be partial)
 // 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, enough pixels to fill the chip)
+// `ngroups` here and in conv_dma_choice is the number of groups the chip sees at once: the launch's own plus pf_conv_desc.co_groups.
 static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
     const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1) ||
                             (g.kh == 4 && g.kw == 4) || (g.kh == 1 && g.kw == 1);
@@ -109,7 +111,7 @@ static int conv_dma_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g
     for (int i = 0; i < ngroups; ++i)
         if (grp.d[i].stats_out != nullptr || grp.d[i].in_scale != nullptr) return 0;
     if (tile_id == 5) return 2;            // Cout <= 64 on a big map (3x3 by conv_tile's rule): the 256 px x 64 channel tile
-    const long wgs256 = (long)(g.M / g.N) * ((g.H + 7) / 8) * ((g.W + 31) / 32) * ngroups * ((max_cout + 63) / 64);
+    const long wgs256 = (long)(g.M / g.N) * ((g.H + 7) / 8) * ((g.W + 31) / 32) * (ngroups + grp.d[0].co_groups) * ((max_cout + 63) / 64);
     // round 4: the 256 px x 64 channel tile for the 1x5 / 5x1 convolutions with Cout > 128 (the GRU's fused z|r) too: half the
     // weight bytes staged per output, twice the halo; +0.2 % at B = 1, +0.6 % at batch 32 (profiles/r4_ab_gru_tile.txt);
     // PRIORFLOW_DMA_GRU_WN1=0 restores the 128 px x 128 channel tile
@@ -123,7 +125,7 @@ extern "C" int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int
     ConvGroups grp; ConvGeom g; int max_cout;
     const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
     if (rc != PF_OK) return rc;
-    const int tile = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    const int tile = conv_tile(g, ngroups + descs[0].co_groups, max_cout, descs[0].precision);
     // 6: the weights-stationary kernel of the encoders' 3x3 64 -> 64 convolutions (pf_enc_conv.hip): its statistics partials are
     // per (segment, row phase, strip) -- pf_conv2d_stats_blocks
     return ((tile == 5 || tile == 3) && pf_enc_conv64_applies(grp, ngroups, g, max_cout)) ? 6 : tile;
@@ -133,7 +135,7 @@ extern "C" int pf_conv2d_stats_blocks(const pf_conv_desc* descs, int ngroups, in
     ConvGroups grp; ConvGeom g; int max_cout;
     const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
     if (rc != PF_OK) return rc;
-    const int tile = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    const int tile = conv_tile(g, ngroups + descs[0].co_groups, max_cout, descs[0].precision);
     const bool split = descs[0].precision == PF_PREC_BF16X3;
     if ((tile == 5 || tile == 3) && pf_enc_conv64_applies(grp, ngroups, g, max_cout)) return pf_enc_conv64_stats_blocks(g);
     if (tile >= 3) { const int th = tile == 5 ? 8 : 4; return ((g.H + th - 1) / th) * ((g.W + 31) / 32); }
@@ -145,7 +147,7 @@ extern "C" int pf_conv2d_roles(const pf_conv_desc* descs, int ngroups, int B, in
     ConvGroups grp; ConvGeom g; int max_cout;
     const int rc = conv_prepare(descs, ngroups, B, H8, W8, grp, g, max_cout);
     if (rc != PF_OK) return rc;
-    const int tile = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    const int tile = conv_tile(g, ngroups + descs[0].co_groups, max_cout, descs[0].precision);
     if (const int dma = conv_dma_choice(grp, ngroups, g, max_cout, tile)) return 16 + dma;
     return (tile == 3 || tile == 4) ? pf_conv_ws_choice(grp, ngroups, g, max_cout) : 0;
 }
@@ -156,7 +158,7 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
     if (rc != PF_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const bool split = descs[0].precision == PF_PREC_BF16X3;
-    const int tile_id = conv_tile(g, ngroups, max_cout, descs[0].precision);
+    const int tile_id = conv_tile(g, ngroups + descs[0].co_groups, max_cout, descs[0].precision);
     for (int i = 0; i < ngroups; ++i) {     // the input affine is implemented by the halo kernel only; the fused statistics by the
         if (descs[i].in_scale && tile_id < 3) return PF_ERR_BAD_SHAPE;      // halo kernel and (round 4) by the generic one when its
         if (descs[i].stats_out && descs[i].epilogue != PF_EPI_LINEAR) return PF_ERR_BAD_SHAPE;     // M tiles do not straddle images

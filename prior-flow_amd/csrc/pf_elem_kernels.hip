@@ -1319,5 +1319,5 @@ extern "C" int pf_motion_prep(const float* c1a, const float* c1b, const float* g
 }
 
 extern "C" const char* pf_version(void) {
-    return "priorflow-hip r4 gfx950 (bf16x3 / exact-fp32 MFMA implicit-GEMM convs, all-DMA convs on pre-split activations, MFMA encoder stem, fused corr+pyramid, fused combine+1x1, HIP encoders, HIP training backward as one loop node, capturable step)";
+    return "priorflow-hip r6 gfx950 (bf16x3 / exact-fp32 MFMA implicit-GEMM convs, all-DMA convs on pre-split activations, weights-stationary encoder convs, MFMA encoder stem, role-split corr+pyramid, fused combine+1x1, HIP encoders, HIP training backward as one loop node, capturable step)";
 }

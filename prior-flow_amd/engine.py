@@ -411,6 +411,9 @@ class Engine:
         # the results are bit-identical)
         self.presplit_on = os.environ.get("PRIORFLOW_PRESPLIT", "1") != "0"
         self.hoist_on = os.environ.get("PRIORFLOW_HOIST_CTX", "1") != "0"
+        # branch A's and branch B's update blocks as TWO chains of half-chip launches on two queues instead of two groups of one
+        # chain of launches (iteration_split; test_mode forwards of few pairs on the default pre-split path only)
+        self.split_ab = int(os.environ.get("PRIORFLOW_SPLIT_AB", "1"))
 
     def presplit(self, P) -> bool:
         return self.presplit_on and P["precision"] == PREC_BF16X3
@@ -484,9 +487,126 @@ class Engine:
         defer_b_join: another iteration follows and nothing on the calling stream reads branch B's coords
         before it: branch B's FlowHead tail is then not joined here but awaited by its consumers in the next
         motion_inputs() (saves one cross-queue dependency hop, ~8 us, at every iteration boundary)."""
+        if self.can_split(ws, P, need_b, mask_b, defer_b_join):
+            return self.iteration_split(ws, P, cur, need_b, mask_a)
         self.motion_inputs(ws, P, need_b)
         return self.update_blocks(ws, P, cur, need_b, mask_a, mask_b, inputs_ready=True,
                                   defer_b_join=defer_b_join)   # incl. coords1 += delta
+
+    # ---- round 6: the two branches as two chains ------------------------------------------------------------
+    def can_split(self, ws: Workspace, P, need_b: bool, mask_b: bool, defer_b_join: bool) -> bool:
+        """iteration_split applies to what the captured test_mode forward runs: side streams, the pre-split path with the hoisted
+        context and the fused combine, no B mask head, and B's result either deferred to the next iteration or not needed."""
+        return bool(self.split_ab and self.side is not None and self.forks == 15 and self.hoist(P) and ws.pre_ready
+                    and not mask_b and (defer_b_join or not need_b) and ws.B <= self.split_ab
+                    and os.environ.get("PRIORFLOW_FUSED_COMBINE", "1") != "0")
+
+    def iteration_split(self, ws: Workspace, P, cur: int, need_b: bool, mask_a: bool) -> int:
+        """One iteration (core/prior_raft.py:170-211) with branch A's chain (lookup, combine + 1x1, motion encoder, SepConvGRU,
+        FlowHead) on the calling stream and branch B's on a side stream, every convolution a launch of ONE group with
+        pf_conv_desc.co_groups = 1 (the tile a two-group launch takes; half the chip's work items each).  The two chains couple
+        only through the flow chain (pf_motion_prep reads both branches' coords1) at the head of an iteration, so B's chain may lag
+        A's by up to A's lookup + combine + convc2, and one chain's store bursts and prologues run under the other's K loops.
+        Arithmetic and launch arguments per branch are those of motion_inputs() + update_blocks(): bit-identical results."""
+        lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
+        like = ws.x_a
+        main = torch.cuda.current_stream()
+        s1, s2, sb = self.side
+        co = 1 if need_b else 0
+
+        def conv(d):
+            d.co_groups = co
+            lib.conv2d([d], B, H8, W8, like)
+
+        # Capture order decides the queues.  hipGraphInstantiate walks the graph depth first from its roots; a node's FIRST-captured
+        # successor inherits its queue, the k-th further one gets queue + k (mod 4), and a node keeps the queue of whoever reaches
+        # it first (observed; motion_inputs relies on the first half of the rule).  The walk descends branch A's chain through all
+        # iterations before anything else, so what hangs off A's last kernel of an iteration decides the rest: its successors are
+        # captured in the order A's next lookup (same queue), B's next lookup (queue + 1: B's whole chain follows), pf_motion_prep
+        # (queue + 2: the flow chain; its second successor, the confidence stem, queue + 3).  B's lookup waits for `start` only
+        # for this ordering -- B lags A, so the edge never delays it.  (With pf_motion_prep captured second the flow chain
+        # shared B's queue and ran behind B's lookup + combine + convc2: 429 us per iteration instead of 405.)
+        start = torch.cuda.Event()
+        start.record(main)
+        # ---- heads: lookup, rotate-back + add + convc1, convc2 (no dependence on the flow chain)
+        lib.dccl_lookup(ws.c1a, ws.pyr_a, ws.pyr_b, ws.g_b2a_8, ws.own, ws.raw, ws.g_b2a_8_il)
+        lib.dccl_combine_conv1x1([(ws.own, ws.raw, ws.g_b2a_8, P["a.c1"], None, 0, ws.c1_a_s)], B, H8, W8)
+        conv(P["a.c2"].desc(None, 0, 256, None, 0, EPI_RELU, in0s=ws.c1_a_s, outs=ws.cat_a_s))
+        b_prev = self._b_pending                # end of B's previous chain: the flow chain reads its coords1
+        if need_b:
+            sb.wait_event(start)
+            with torch.cuda.stream(sb):
+                lib.dccl_lookup(ws.c1b, ws.pyr_b, ws.pyr_a, ws.g_a2b_8, ws.own_b, ws.raw_b, ws.g_a2b_8_il)
+                lib.dccl_combine_conv1x1([(ws.own_b, ws.raw_b, ws.g_a2b_8, P["b.c1"], None, 0, ws.c1_b_s)], B, H8, W8)
+                conv(P["b.c2"].desc(None, 0, 256, None, 0, EPI_RELU, in0s=ws.c1_b_s, outs=ws.cat_b_s))
+        # ---- flow chain (s1) and confidence chain (s2): need both branches' coords1
+        s1.wait_event(start)
+        if b_prev is not None:
+            s1.wait_event(b_prev)
+        with torch.cuda.stream(s1):
+            self._flow_chain_head(ws, True)
+            head_done = torch.cuda.Event()
+            head_done.record(s1)
+            self._flow_chain_tail(ws, P, need_b)
+            flow_done = torch.cuda.Event()
+            flow_done.record(s1)
+        s2.wait_event(head_done)
+        with torch.cuda.stream(s2):
+            self._conf_chain(ws, P)
+        # ---- branch A's tail (calling stream)
+        main.wait_event(flow_done)
+        # B's tail needs the flow chain (s1) too, and s1 waits for B's previous tail (sb): two forked streams that wait on EACH
+        # OTHER's events crash hipStreamEndCapture on ROCm 7.2 (segmentation fault after "[hipGraph] Add EmptyNode"; one
+        # direction alone, or either stream against the capture's origin stream, is fine) -- so the flow chain's completion
+        # reaches sb through an event recorded on the calling stream, which has to wait for it anyway
+        relay = torch.cuda.Event()
+        relay.record(main)
+        main.wait_stream(s2)
+        conv(P["a.out"].desc(None, 0, 272, None, 128, EPI_RELU, in0s=ws.cat_a_s, outs=ws.x_a_s))
+        self._gru_branch(ws, P, "a", cur, conv)
+        nas = ws.net_a_s[cur]
+        if mask_a:              # the mask head's stem shares its input with the FlowHead's: two groups of one launch
+            d = [P["a.fh1"].desc(None, 0, 128, ws.fh_a, 0, EPI_RELU, in0s=nas), P["a.m0"].desc(None, 0, 128, ws.mh_a, 0, EPI_RELU, in0s=nas)]
+            d[0].co_groups = 0
+            lib.conv2d(d, B, H8, W8, like)
+            heads_done = torch.cuda.Event()
+            heads_done.record(main)
+            lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
+            s2.wait_event(heads_done)
+            with torch.cuda.stream(s2):
+                lib.conv2d([P["a.m2"].desc(ws.mh_a, 0, 256, ws.mask_a, 0, EPI_LINEAR, scale=0.25)], B, H8, W8, like)
+            main.wait_stream(s2)
+        else:
+            conv(P["a.fh1"].desc(None, 0, 128, ws.fh_a, 0, EPI_RELU, in0s=nas))
+            lib.flow_head_out(ws.fh_a, 256, P["a.fh2w"], P["a.fh2b"], ws.c1a, ws.delta_a)
+        # ---- branch B's tail (sb)
+        if need_b:
+            sb.wait_event(relay)
+            with torch.cuda.stream(sb):
+                conv(P["b.out"].desc(None, 0, 272, None, 128, EPI_RELU, in0s=ws.cat_b_s, outs=ws.x_b_s))
+                self._gru_branch(ws, P, "b", cur, conv)
+                conv(P["b.fh1"].desc(None, 0, 128, ws.fh_b, 0, EPI_RELU, in0s=ws.net_b_s[cur]))
+                lib.flow_head_out(ws.fh_b, 256, P["b.fh2w"], P["b.fh2b"], ws.c1b, ws.delta_b)
+                self._b_pending = torch.cuda.Event()
+                self._b_pending.record(sb)
+        else:                   # the last iteration of a test_mode forward: every side queue rejoins the calling stream
+            self._await_b(main)
+            main.wait_stream(s1)
+        return cur
+
+    def _gru_branch(self, ws: Workspace, P, t: str, cur: int, conv):
+        """SepConvGRU of ONE branch (core/update.py:46-60) on twins with the hoisted context: z|r, q horizontally, then vertically;
+        the hidden state ends in net_x[cur] again."""
+        net, zb, ns, xs, rhs = ((ws.net_a, ws.z_a, ws.net_a_s, ws.x_a_s, ws.rh_a_s) if t == "a" else
+                                (ws.net_b, ws.z_b, ws.net_b_s, ws.x_b_s, ws.rh_b_s))
+        c = cur
+        for tag in ("1", "2"):
+            conv(P[f"{t}.zr{tag}h"].desc(None, 0, 128, zb, 0, EPI_GRU_ZR, off1=128, c1=128, h=net[c], in0s=ns[c], in1s=xs,
+                                          auxs=rhs, pre=ws.pre[(t, tag)], off_pre=0))
+            conv(P[f"{t}.q{tag}h"].desc(None, 0, 128, net[c ^ 1], 0, EPI_GRU_Q, off1=128, c1=128, h=net[c], z=zb,
+                                         in0s=rhs, in1s=xs, outs=ns[c ^ 1], pre=ws.pre[(t, tag)], off_pre=256))
+            c ^= 1
+        assert c == cur
 
     def _await_b(self, stream, keep: bool = False):
         """Make `stream` wait for branch B's deferred FlowHead tail of the previous iteration, if any."""

@@ -429,6 +429,33 @@ torch.save(flow.cpu(), sys.argv[1])
     assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())
 
 
+@pytest.mark.parametrize("size,iters", [((256, 512), 3), ((512, 1024), 2), ((136, 216), 2)])
+def test_split_branch_chains_leave_the_flow_bitwise(params, size, iters, monkeypatch):
+    """Round 6 (Engine.iteration_split): branch A's and branch B's update blocks as two chains of one-group launches on two queues
+    (pf_conv_desc.co_groups) instead of two groups of one chain -- the same launch arguments per branch, so the flow is equal bit
+    for bit, eager and captured (replayed twice: branch B's chain lags branch A's across the iteration boundary)."""
+    from prior_flow_amd.prior_raft import PriOr_RAFT
+
+    def run(flag, graph):
+        monkeypatch.setenv("PRIORFLOW_SPLIT_AB", flag)
+        m = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
+        m.load_state_dict(params, strict=True)
+        m = m.cuda().eval()
+        m.use_graph = graph
+        with torch.no_grad():
+            outs = [m(i1, i2, iters=iters, test_mode=True).clone() for _ in range(2 if graph else 1)]
+        assert all(torch.equal(outs[0], o) for o in outs)
+        return outs[0]
+
+    i1, i2 = gc.synthetic_pair(1, size[0], size[1], seed=13)
+    i1, i2 = i1.cuda(), i2.cuda()
+    ref = run("0", False)
+    assert float(ref.abs().mean()) > 0.05
+    for graph in (False, True):
+        out = run("1", graph)
+        assert torch.equal(ref, out), (graph, float((ref - out).abs().max()))
+
+
 def test_workspaces_and_graphs_of_several_shapes_stay_resident(params):
     """an evaluation loop over mixed sizes (or B = 1 / B = 2 in turn) must not re-allocate its workspace and re-capture
     its graph on every switch: the model keeps a few shapes resident (least recently used first out) together with the graphs
