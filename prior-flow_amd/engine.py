@@ -412,8 +412,9 @@ class Engine:
         self.presplit_on = os.environ.get("PRIORFLOW_PRESPLIT", "1") != "0"
         self.hoist_on = os.environ.get("PRIORFLOW_HOIST_CTX", "1") != "0"
         # branch A's and branch B's update blocks as TWO chains of half-chip launches on two queues instead of two groups of one
-        # chain of launches (iteration_split; test_mode forwards of few pairs on the default pre-split path only)
-        self.split_ab = int(os.environ.get("PRIORFLOW_SPLIT_AB", "1"))
+        # chain of launches (iteration_split; test_mode forwards on the default pre-split path only; every batch size: +7.7 % at
+        # B = 1, +6.3 % at 2, +4.8 % at 4, +4 % at 8, +0.6 % at 32 -- profiles/r6_ab_split_chains.txt).  PRIORFLOW_SPLIT_AB=0: off.
+        self.split_ab = os.environ.get("PRIORFLOW_SPLIT_AB", "1") != "0"
 
     def presplit(self, P) -> bool:
         return self.presplit_on and P["precision"] == PREC_BF16X3
@@ -498,7 +499,7 @@ class Engine:
         """iteration_split applies to what the captured test_mode forward runs: side streams, the pre-split path with the hoisted
         context and the fused combine, no B mask head, and B's result either deferred to the next iteration or not needed."""
         return bool(self.split_ab and self.side is not None and self.forks == 15 and self.hoist(P) and ws.pre_ready
-                    and not mask_b and (defer_b_join or not need_b) and ws.B <= self.split_ab
+                    and not mask_b and (defer_b_join or not need_b)
                     and os.environ.get("PRIORFLOW_FUSED_COMBINE", "1") != "0")
 
     def iteration_split(self, ws: Workspace, P, cur: int, need_b: bool, mask_a: bool) -> int:

@@ -429,8 +429,8 @@ torch.save(flow.cpu(), sys.argv[1])
     assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())
 
 
-@pytest.mark.parametrize("size,iters", [((256, 512), 3), ((512, 1024), 2), ((136, 216), 2)])
-def test_split_branch_chains_leave_the_flow_bitwise(params, size, iters, monkeypatch):
+@pytest.mark.parametrize("size,iters,batch", [((256, 512), 3, 1), ((512, 1024), 2, 1), ((136, 216), 2, 1), ((256, 512), 3, 2)])
+def test_split_branch_chains_leave_the_flow_bitwise(params, size, iters, batch, monkeypatch):
     """Round 6 (Engine.iteration_split): branch A's and branch B's update blocks as two chains of one-group launches on two queues
     (pf_conv_desc.co_groups) instead of two groups of one chain -- the same launch arguments per branch, so the flow is equal bit
     for bit, eager and captured (replayed twice: branch B's chain lags branch A's across the iteration boundary)."""
@@ -447,7 +447,7 @@ def test_split_branch_chains_leave_the_flow_bitwise(params, size, iters, monkeyp
         assert all(torch.equal(outs[0], o) for o in outs)
         return outs[0]
 
-    i1, i2 = gc.synthetic_pair(1, size[0], size[1], seed=13)
+    i1, i2 = gc.synthetic_pair(batch, size[0], size[1], seed=13)
     i1, i2 = i1.cuda(), i2.cuda()
     ref = run("0", False)
     assert float(ref.abs().mean()) > 0.05
