@@ -276,11 +276,10 @@ def profile_kernels(model, i1, i2):
         ("conv2d", "conv", lambda d, Bc, H8, W8, like: conv_name(d, Bc, H8, W8),
              lambda d, Bc, H8, W8, like: sum(2.0 * Bc * H8 * W8 * x.cout * x.kh * x.kw * (x.c0 + x.c1) for x in d)),
         ("corr_pyramid", "corr", lambda *a: "pf_corr_kernel", lambda f1, f2, lv, Bc, H8, W8: corr_bytes(Bc, H8, W8, f1.shape[-1])),
-        # bf16x3: the role-split kernel (round 5) on maps with W/8 % 64 == 0 and H/8 % 8 == 0 unless PRIORFLOW_CORR_RING says otherwise
+        # bf16x3: the role-split kernel (round 5) on maps with W/8 % 64 == 0 and H/8 % 8 == 0 unless PRIORFLOW_CORR_RS=0
         ("corr_pyramid_bf16x3", "corr",
              lambda f1, f2, lv, Bc, H8, W8, c: ("pf_corr_rs_kernel" if W8 % 64 == 0 and H8 % 8 == 0 and c == 256
-                                                and os.environ.get("PRIORFLOW_CORR_RING", "2") == "2" else
-                                                "pf_corr_ring_kernel" if os.environ.get("PRIORFLOW_CORR_RING") == "1" else "pf_corr_kernel"),
+                                                and os.environ.get("PRIORFLOW_CORR_RS", "1") != "0" else "pf_corr_kernel"),
              lambda f1, f2, lv, Bc, H8, W8, c: corr_bytes(Bc, H8, W8, c)),
         # SURVEY.md 8(d), one branch: own 10x10 patch x 4 B x 4 levels read + 324 x 4 B written; cross <= 81 x 4 taps x 4 B x 4
         # levels read + 324 x 4 B written = 9 376 B per pixel (76.8 MB at 64x128)

@@ -47,7 +47,39 @@ from . import _lib
 from ._lib import EPI_LINEAR, PREC_BF16X3
 from .engine import Conv, pack_mfma, rotation_x
 
-STATS = {"hip": 0, "torch": 0}          # launches routed to the HIP library / left to torch (tests read this)
+class _LaunchStats:
+    """Launch counters {"hip": launches routed to the HIP library, "torch": launches left to torch} -- PER DEVICE (round 6; a
+    process-wide dict before): ``STATS[key]`` reads / writes the counter of the CURRENT device, so nn.DataParallel's worker threads or
+    two models training on two cards never add into one another's count (no process-global mutable state).  Tests and
+    profiles read ``STATS["hip"]`` on the device they drive; ``for_device`` / ``as_dict`` give the others."""
+
+    def __init__(self):
+        self._by_dev = {}
+
+    def _cur(self):
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        d = self._by_dev.get(dev)
+        if d is None:
+            d = self._by_dev.setdefault(dev, {"hip": 0, "torch": 0})
+        return d
+
+    def __getitem__(self, key):
+        return self._cur()[key]
+
+    def __setitem__(self, key, value):
+        self._cur()[key] = value
+
+    def for_device(self, dev) -> dict:
+        return self._by_dev.setdefault(torch.device("cuda", dev).index if not isinstance(dev, int) else dev, {"hip": 0, "torch": 0})
+
+    def as_dict(self) -> dict:
+        return {d: dict(c) for d, c in self._by_dev.items()}
+
+    def __repr__(self):
+        return repr(dict(self._cur()))
+
+
+STATS = _LaunchStats()
 
 
 def _rows(x: torch.Tensor) -> torch.Tensor:
@@ -125,12 +157,21 @@ class GradSink:
         if not self.active:
             return False
         dev = params[0].device
-        if self.arena is None or self.arena.numel() < self.want or self.arena.device != dev:
-            self.arena = torch.zeros(max(self.want, 1), device=dev) if self.want else None
-        elif self.arena is not None:
+        if not self.reserve(dev) and self.arena is not None:
             self.arena.zero_()
         self.want = 0
         return True
+
+    def reserve(self, dev) -> bool:
+        """Sizes the arena for the step about to run from what the previous step asked for; True when a new (zeroed) one was
+        allocated.  ``GraphedTrainStep`` calls this BEFORE it starts capturing, so the arena is an ordinary allocation and not part
+        of the graph's private pool, and keeps a reference to the arena its graph was captured on: a later step of a larger model
+        on this device REPLACES ``self.arena`` (this method never frees or resizes in place), so the captured graph's pointer stays
+        valid for as long as its stepper lives."""
+        if self.arena is None or self.arena.numel() < self.want or self.arena.device != dev:
+            self.arena = torch.zeros(max(self.want, 1), device=dev) if self.want else None
+            return True
+        return False
 
     def packed(self, op: int, taps: int, cin_pad: int, device):
         """Zeroed (dw [op, taps, cin_pad], db [op]) for pf_conv2d_wgrad to accumulate into."""
@@ -178,7 +219,10 @@ class GradSink:
     def abort(self):
         """Ends the step without touching the gradients (an exception is on its way out)."""
         for st in self.join_streams:          # (also on the way out of a failed step: later work must not overtake the side stream)
-            torch.cuda.current_stream().wait_stream(st)
+            try:
+                torch.cuda.current_stream().wait_stream(st)
+            except RuntimeError:              # e.g. inside an invalidated graph capture: the original exception must not be masked
+                pass
         self.jobs, self.slow, self.keep, self.join_streams, self.active = [], [], [], [], False
 
 
@@ -416,40 +460,9 @@ class HipSmallConv(torch.autograd.Function):
         return None, dw, db, None
 
 
-class HipFrozenBatchNorm(torch.autograd.Function):
-    """nn.BatchNorm2d with frozen statistics (freeze_bn, train_flow.py:107-108): y = x * s + t with
-    s = gamma * rstd, t = beta - mean * s.  Backward: dx = s * g (pf_norm_bwd, fixed statistics); d gamma = sum g * xhat,
-    d beta = sum g from the same kernel's per-(image, channel) sums (its InstanceNorm branch run on xhat = x * rstd -
-    mean * rstd; the dx of that pass is discarded)."""
-
-    @staticmethod
-    def forward(ctx, x, gamma, beta, mean, var, eps):
-        rstd = torch.rsqrt(var + eps)
-        s = (gamma.detach() * rstd)
-        t = (beta.detach() - mean * s)
-        ctx.save_for_backward(_rows(x.detach()), s, rstd, mean)
-        ctx.shape = x.shape
-        return x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        xr, s, rstd, mean = ctx.saved_tensors
-        B, Cc, H, W = ctx.shape
-        gr = _rows(g)
-        Np = H * W
-        dx = torch.empty_like(xr)
-        rep = lambda v: v.view(1, Cc).expand(B, Cc).contiguous()
-        lib.norm_bwd(gr, xr, rep(s), rep(torch.zeros_like(s)), False, False, dx, B, Np, Cc)
-        coef = lib.norm_bwd_sums(gr, xr, rep(rstd), rep(-mean * rstd), B, Np, Cc)          # [B, C, 2]: mean g, mean g * xhat
-        STATS["hip"] += 2
-        dbeta = coef[:, :, 0].sum(0) * Np
-        dgamma = coef[:, :, 1].sum(0) * Np
-        return _nchw(dx, B, H, W), dgamma, dbeta, None, None, None
-
-
 class HipFrozenBnAct(torch.autograd.Function):
-    """HipFrozenBatchNorm [+ the ReLU behind it] in one launch forward (pf_bn_frozen_fwd) and three backward (pf_bn_frozen_bwd:
+    """nn.BatchNorm2d with frozen statistics (freeze_bn, train_flow.py:107-108: y = x * s + t with s = gamma * rstd,
+    t = beta - mean * s) [+ the ReLU behind it] in one launch forward (pf_bn_frozen_fwd) and three backward (pf_bn_frozen_bwd:
     masked sums -> d gamma / d beta, dx), instead of ~8 + ~15 elementwise PyTorch kernels per layer.  With the GradSink on,
     d gamma / d beta are added straight into the parameters' .grad."""
 
@@ -856,21 +869,17 @@ class HipInstanceNorm(torch.autograd.Function):
 
 
 # ---- module forwards (the parameter containers of modules.py carry no arithmetic of their own) ---------------
-_FUSED_BN = os.environ.get("PRIORFLOW_TRAIN_BN_FUSED", "1") != "0"
-
 
 def _norm(m: nn.Module, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
     """norm layer `m` on x; relu=True: followed by the ReLU (one pass for InstanceNorm)."""
     if isinstance(m, nn.InstanceNorm2d):
         return HipInstanceNorm.apply(x, relu)
-    if isinstance(m, nn.BatchNorm2d) and not m.training and m.weight is not None and _FUSED_BN:
+    if isinstance(m, nn.BatchNorm2d) and not m.training and m.weight is not None:
         # frozen statistics (freeze_bn): the reference's configuration
         return HipFrozenBnAct.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps, relu)
     if relu:
         return torch.relu(_norm(m, x))
     if isinstance(m, nn.BatchNorm2d):
-        if not m.training and m.weight is not None:          # PRIORFLOW_TRAIN_BN_FUSED=0: round 3's elementwise form
-            return HipFrozenBatchNorm.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps)
         if m.training and m.weight is not None:               # batch statistics (the `chairs` stage)
             return HipBatchNormTrain.apply(x, m.weight, m.bias, m)
         raise _lib.PfError("BatchNorm2d without affine parameters has no HIP path (the reference's encoders always carry them)")
@@ -1003,14 +1012,6 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
         _TAPE.gates = None
 
 
-class _NullCtx:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
-
-
 def _prepack_encoders(lib, *encoders):
     """Forward and data-gradient operands of every MFMA convolution of the encoders, packed together (ceil(n / 16) launches
     instead of one per operand in front of its first use); conv2d() / the backward nodes then find them in the pack cache."""
@@ -1025,25 +1026,22 @@ def _prepack_encoders(lib, *encoders):
 def _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a_8, iters, init_flow):
     import os
     _prepack_encoders(lib, model.cnet, model.fnet)
-    side = None
-    if os.environ.get("PRIORFLOW_TRAIN_FORK", "1") != "0":
-        # cnet beside fnet on a side stream (round 4): at the training crop an encoder launch fills a fraction of the chip, and
-        # autograd runs every backward node on its forward node's stream, so the two encoders' backwards overlap as well
-        # (inside train.GraphedTrainStep the fork / join become parallel branches of the captured graph)
-        side = getattr(model, "_train_side_stream", None)
-        if side is None:
-            side = model._train_side_stream = torch.cuda.Stream()
-        cur = torch.cuda.current_stream()
-        side.wait_stream(cur)
-    with torch.cuda.stream(side) if side is not None else _NullCtx():
+    # cnet beside fnet on a side stream (round 4): at the training crop an encoder launch fills a fraction of the chip, and
+    # autograd runs every backward node on its forward node's stream, so the two encoders' backwards overlap as well
+    # (inside train.GraphedTrainStep the fork / join become parallel branches of the captured graph)
+    side = getattr(model, "_train_side_stream", None)
+    if side is None:
+        side = model._train_side_stream = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
         cnet = encoder_forward(model.cnet, torch.cat([i1, i1b], 0))                             # :133-142
         net_a, inp_a = torch.tanh(cnet[:B, :128]), torch.relu(cnet[:B, 128:])
         net_b, inp_b = torch.tanh(cnet[B:, :128]), torch.relu(cnet[B:, 128:])
     fm = encoder_forward(model.fnet, torch.cat([i1, i2, i1b, i2b], 0)).float()                  # :144-149
-    if side is not None:
-        torch.cuda.current_stream().wait_stream(side)
-        for t in (net_a, inp_a, net_b, inp_b):
-            t.record_stream(torch.cuda.current_stream())
+    torch.cuda.current_stream().wait_stream(side)
+    for t in (net_a, inp_a, net_b, inp_b):
+        t.record_stream(torch.cuda.current_stream())
     f1a, f2a, f1b, f2b = fm[:B], fm[B:2 * B], fm[2 * B:3 * B], fm[3 * B:]
     pyr_a = corr_pyramid(f1a, f2a)                                                              # :151-159
     pyr_b = corr_pyramid(f1b, f2b)

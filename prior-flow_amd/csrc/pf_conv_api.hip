@@ -6,12 +6,6 @@
 using namespace pfconv;
 
 // validation + geometry shared by pf_conv2d and pf_conv2d_tile
-// PRIORFLOW_CONV_GENERIC=1 forces the generic kernel (A/B comparisons, debugging)
-static bool pf_conv_force_generic() {
-    static const bool v = [] { const char* e = getenv("PRIORFLOW_CONV_GENERIC"); return e && e[0] == '1'; }();
-    return v;
-}
-
 static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8,
                         ConvGroups& grp, ConvGeom& g, int& max_cout) {   // H8, W8: OUTPUT map size
     if (!descs || ngroups < 1 || ngroups > MAX_GROUPS) return PF_ERR_BAD_ARG;
@@ -85,13 +79,11 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
     const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1) ||
                             (g.kh == 4 && g.kw == 4) || (g.kh == 1 && g.kw == 1);
-    if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1 && !pf_conv_force_generic()) {
+    if (precision == PF_PREC_BF16X3 && halo_shape && g.stride == 1) {
         const long B = g.M / g.N;
         const long tiles4 = B * ((g.H + 3) / 4) * ((g.W + 31) / 32), tiles8 = B * ((g.H + 7) / 8) * ((g.W + 31) / 32);
         const long wgs128 = tiles4 * ngroups * ((max_cout + 127) / 128);
-        static const int force8 = [] { const char* e = getenv("PRIORFLOW_CONV_TH8"); return e ? atoi(e) : 0; }();   // A/B knob
-        if (force8 > 0 && g.kh == g.kw && g.kh > 1) return 5;
-        if (force8 >= 0 && max_cout <= 64 && g.kh == g.kw && g.kh > 1 && tiles8 * ngroups >= 512) return 5;     // -1: never (A/B)
+        if (max_cout <= 64 && g.kh == g.kw && g.kh > 1 && tiles8 * ngroups >= 512) return 5;
         return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
     }
     const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;
@@ -102,10 +94,9 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision
 
 // Pre-split operands (pf_conv_desc.in0_split): which tile the all-DMA kernel takes -- 0: not applicable (fp32 operands,
 // a shape / option it does not implement), else the pf_conv2d_roles code (1: 128-px tile, 2: 256 px x 64 channels).
-// PRIORFLOW_CONV_DMA=0 (A/B knob) sends every launch to the register-staged kernels, which need the fp32 operands.
+// (The engine's PRIORFLOW_PRESPLIT=0 is the A/B against the register-staged kernels: it hands over fp32 operands.)
 static int conv_dma_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, int tile_id) {
-    static const bool on = [] { const char* e = getenv("PRIORFLOW_CONV_DMA"); return !(e && e[0] == '0'); }();
-    if (!on || !grp.d[0].in0_split || tile_id < 3) return 0;
+    if (!grp.d[0].in0_split || tile_id < 3) return 0;
     const bool shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1);
     if (!shape || g.stride != 1) return 0;
     for (int i = 0; i < ngroups; ++i)
@@ -113,10 +104,8 @@ static int conv_dma_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g
     if (tile_id == 5) return 2;            // Cout <= 64 on a big map (3x3 by conv_tile's rule): the 256 px x 64 channel tile
     const long wgs256 = (long)(g.M / g.N) * ((g.H + 7) / 8) * ((g.W + 31) / 32) * (ngroups + grp.d[0].co_groups) * ((max_cout + 63) / 64);
     // round 4: the 256 px x 64 channel tile for the 1x5 / 5x1 convolutions with Cout > 128 (the GRU's fused z|r) too: half the
-    // weight bytes staged per output, twice the halo; +0.2 % at B = 1, +0.6 % at batch 32 (profiles/r4_ab_gru_tile.txt);
-    // PRIORFLOW_DMA_GRU_WN1=0 restores the 128 px x 128 channel tile
-    static const bool gru_wn1 = [] { const char* e = getenv("PRIORFLOW_DMA_GRU_WN1"); return !(e && e[0] == '0'); }();
-    if (gru_wn1 && g.kh != 3 && max_cout > 128 && wgs256 >= 256) return 2;
+    // weight bytes staged per output, twice the halo; +0.2 % at B = 1, +0.6 % at batch 32 (profiles/r4_ab_gru_tile.txt)
+    if (g.kh != 3 && max_cout > 128 && wgs256 >= 256) return 2;
     return (g.kh == 3 && max_cout > 64 && wgs256 >= 256) ? 2 : 1;
 }
 

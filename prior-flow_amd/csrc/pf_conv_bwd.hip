@@ -81,7 +81,7 @@ pf_wgrad_kernel(const WgradArgs a) {
     constexpr int XROWS = (HPX + 15) / 16 * 16;
     __bf16* const dyt = lds;                                   // ((plane*4 + mb)*TPX + px)*32 + c
     __bf16* const xt = lds + 2 * 4 * TPX * 32;                 // ((plane*NCB + cb)*XROWS + hp)*32 + c
-    // bias gradient (round 5: it was a launch of its own per convolution, pf_col_sum_kernel): the workgroups of the first
+    // bias gradient (round 5: it was a launch of its own per convolution before): the workgroups of the first
     // input-channel block add the fp32 dY values they stage anyway -- per thread over its 8 pixels of a tile, then into 128 LDS
     // words, and once per workgroup into db
     float* const bsum = reinterpret_cast<float*>(xt + 2 * NCB * XROWS * 32);
@@ -240,34 +240,6 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     dim3 grid((unsigned)((a.cout + WG_O - 1) / WG_O), (unsigned)((a.cin_pad + 32 * NCB - 1) / (32 * NCB)), (unsigned)a.nsplit);
     hipLaunchKernelGGL((pf_wgrad_kernel<KH, KW>), grid, dim3(512), lds, stream, a);
     return (int)hipGetLastError();
-}
-
-// db[o] += sum over pixels of dY[p][o]: block = 64 channels x 4 row lanes over a 256-row chunk (8 independent
-// loads in flight per thread), fp32 atomics across chunks.  (A first version with 2048-row chunks and one
-// dependent load per iteration took ~150 us -- longer than the weight gradient itself.)
-__global__ void __launch_bounds__(256) pf_col_sum_kernel(const float* __restrict__ dy, int ld, int off, int cout,
-                                                        long rows, float* __restrict__ db) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    const long lo = (long)blockIdx.y * 256 + part * 64;
-    float s = 0.f;
-    if (c < cout) {
-#pragma unroll
-        for (int j0 = 0; j0 < 64; j0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const long p = lo + j0 + j;
-                v[j] = p < rows ? dy[p * ld + off + c] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[j];
-        }
-    }
-    red[part][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (part == 0 && c < cout)
-        atomicAdd(db + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -483,9 +455,7 @@ extern "C" int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const
     WgradArgs a;
     a.x0 = x0; a.ld0 = ld0; a.off0 = off0; a.c0 = c0; a.x1 = x1; a.ld1 = ld1; a.off1 = off1; a.c1 = c1;
     a.dy = dy; a.ld_dy = ld_dy; a.off_dy = off_dy; a.cout = cout; a.dw = dw;
-    // PRIORFLOW_WGRAD_DB=0: the bias gradient as its own launch (pf_col_sum_kernel), round 4's form (A/B)
-    static const bool fused_db = [] { const char* e = getenv("PRIORFLOW_WGRAD_DB"); return !(e && e[0] == '0'); }();
-    a.db = fused_db ? db : nullptr;
+    a.db = db;            // the bias gradient rides in the weight-gradient kernel (round 5: 57 launches per step less)
     a.B = B; a.H = H8; a.W = W8; a.kh = kh; a.kw = kw;
     a.cin_pad = (c0 + c1 + 31) / 32 * 32;
     // split-K: enough workgroups for ~4 per CU, at most one per pixel tile
@@ -504,13 +474,5 @@ extern "C" int pf_conv2d_wgrad(const float* x0, int ld0, int off0, int c0, const
     else if (kh == 1 && kw == 1) rc = launch_wgrad<1, 1>(a, s);
     else return PF_ERR_BAD_SHAPE;
     if (rc) return rc;
-    if (db && !fused_db) {
-        const long rows = (long)B * H8 * W8;
-        const long chunks = (rows + 255) / 256;
-        if (chunks > 65535) return PF_ERR_BAD_SHAPE;
-        hipLaunchKernelGGL(pf_col_sum_kernel, dim3((unsigned)((cout + 63) / 64), (unsigned)chunks), dim3(256), 0, s,
-                           dy, ld_dy, off_dy, cout, rows, db);
-        rc = (int)hipGetLastError();
-    }
     return rc;
 }

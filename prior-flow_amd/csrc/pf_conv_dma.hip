@@ -470,13 +470,11 @@ int launch_conv_dma_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int
     gg.d_ntn = fd_make((unsigned)gg.ntn); gg.d_ntiles = fd_make((unsigned)gg.ntiles);
     gg.d_tx = fd_make((unsigned)((g.W + 31) / 32)); gg.d_ty = fd_make((unsigned)((g.H + TH - 1) / TH));
     // persistent: at most one workgroup per CU (the kernel's LDS footprint admits no second one), each walking its share of
-    // the work sequence; PRIORFLOW_DMA_WGS (A/B knob) overrides the cap, 0 = one workgroup per item.  Per DEVICE: the CU
-    // count and the > 64 KB dynamic-LDS attribute belong to the device that is current at launch time (one process may drive
-    // several cards).
+    // the work sequence.  Per DEVICE: the CU count and the > 64 KB dynamic-LDS attribute belong to the device that is current
+    // at launch time (one process may drive several cards).
     constexpr int MAX_DEV = 64;
     static int cus_of[MAX_DEV];              // 0 = not asked yet
     static bool attr_set[MAX_DEV];
-    static const int wgs_env = [] { const char* e = getenv("PRIORFLOW_DMA_WGS"); return e ? atoi(e) : -1; }();
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
     if (cus_of[dev] == 0) {
@@ -484,7 +482,7 @@ int launch_conv_dma_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         cus_of[dev] = n;
     }
-    int cap = wgs_env >= 0 ? wgs_env : cus_of[dev];
+    int cap = cus_of[dev];
     const long items = (long)gg.ntiles * gg.ntn * ngroups;
     // the kernel cuts the work sequence into 8 ranges (one per XCD) that the workgroups with blockIdx % 8 == range walk: a
     // capped grid needs at least one workgroup per range, or the ranges without one are never computed

@@ -829,10 +829,8 @@ int launch_conv_halo_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, in
     ConvGeom gg = g;
     gg.ntiles = B * ((g.H + TH - 1) / TH) * ((g.W + 31) / 32);
     gg.ntn = (max_cout + BN - 1) / BN;
-    static const bool xcd_map = [] { const char* e = getenv("PRIORFLOW_CONV_XCD"); return !(e && e[0] == '0'); }();   // A/B knob
-    gg.xcd_map = xcd_map ? 1 : 0;
-    dim3 grid((unsigned)gg.ntiles, (unsigned)gg.ntn, (unsigned)ngroups);
-    if (xcd_map) grid = dim3((unsigned)((long)gg.ntiles * gg.ntn * ngroups));
+    gg.xcd_map = 1;                       // XCD-aware 1-D grid (round 2: fabric-side fetches of a 5x1 GRU launch 89 -> 54 MB)
+    const dim3 grid((unsigned)((long)gg.ntiles * gg.ntn * ngroups));
     // up to ~130 KB of dynamic LDS: above the 64 KB default limit
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&pf_conv_halo_kernel<NT, KH, KW, AFFINE, TH>),

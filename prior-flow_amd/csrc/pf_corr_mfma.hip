@@ -60,8 +60,8 @@ __device__ __forceinline__ float dpp_get(float v) {
 // Global stores of the volume.  Non-temporal by default (round 5): a plain store keeps its line in the XCD's L2, so the
 // 356 MB write stream of a launch evicts the operand rows every workgroup of the XCD re-reads (the role-split kernel:
 // 181 us with plain stores, 109 us with nt stores, same instruction stream; the tile kernel 149 -> 144 us at B = 1 and
-// 1287 -> 1062 us at B = 8).  Only for stores of whole 128-byte lines: the ring kernel's 16- / 32-byte pieces stay plain
-// (nt: 360 us instead of 155).  -DPF_CORR_PLAIN_STORES restores plain stores (profiles/ab_corr_libs.py).
+// 1287 -> 1062 us at B = 8).  Only for stores of whole 128-byte lines (16- / 32-byte pieces took 360 us as nt
+// stores instead of 155).  -DPF_CORR_PLAIN_STORES restores plain stores (profiles/ab_corr_libs.py).
 template <class V>
 __device__ __forceinline__ void vol_store(V* p, const V& v) {
 #ifdef PF_CORR_PLAIN_STORES
@@ -351,43 +351,25 @@ pf_corr_kernel(const CorrArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// Ring kernel (fused pool, bf16x3, C = 256, W8 % 64 == 0): the HBM-bound form of the corr + pyramid build.
-//
-// What the measurements on MI355X said about the tile kernel above and the first ring kernels (profiles/r2_corr_*):
-//   * the kernel is bound by its STORES, and among them by the pooled levels: 24 % of the bytes, written as
-//     64- / 32- / 16-byte pieces of cache lines whose other half arrives 10 us later from the neighbouring block,
-//     cost as much as the 76 % of level 0 (store-only builds: level 0 alone 61 us, pooled levels alone 49 us,
-//     together 120 us; a fill kernel writes the same bytes in 56 us = 6.7 TB/s);
-//   * an LDS transpose in front of the stores buys nothing, and the stores of a wave must have left before the
-//     first operand tile issued after them can be consumed (vmcnt retires in issue order).
-// So this kernel is built around the store stream:
+// Building blocks of the role-split kernel below (they were the round-2 "ring kernel"'s, which lost to both other forms at
+// every size measured -- 165.5 against 101.9 us, profiles/r5_final_ab_corr_kernels.txt -- and was deleted in round 6):
 //   * the GEMM is TRANSPOSED: target pixels are the MFMA's A operand (rows), query pixels its B operand (columns).
-//     An accumulator register group then holds FOUR CONSECUTIVE TARGET COLUMNS of one query row (x = 8 g + 4 lh + i
-//     in register 4 g + i): level 0 is stored straight from registers, 16 bytes per lane, and every 2x2 pooling
-//     is a register-to-register add of one lane (same products, same k order, same pooling order as the tile
-//     kernel: bit-identical results);
-//   * a workgroup's unit of work is a ring tile of 2 map rows x 64 columns (128 target pixels): per query row
-//     it closes 2 x 256 contiguous bytes of level 0 and ONE WHOLE 128-byte line of level 1 in one burst; a
-//     workgroup owns a region of 8 map rows x 128 columns (8 tiles, ordered so that level-2 lines close after
-//     4 tiles: they are collected in a wave-private LDS image and stored as whole lines; level 3 follows from
-//     the two level-2 rows);
+//     An accumulator register group then holds FOUR CONSECUTIVE TARGET COLUMNS of one query row, so every 2x2 pooling is a
+//     register-to-register add of one lane (same products, same k order, same pooling order as the tile kernel);
+//   * the unit of work is a tile of 2 map rows x 64 columns (128 target pixels): per query row it closes 2 x 256
+//     contiguous bytes of level 0 and ONE WHOLE 128-byte line of level 1; level-2 lines close after 4 tiles and are
+//     collected in a wave-private LDS image, level 3 follows from two level-2 rows;
 //   * a wave keeps its 32 query rows x all 256 channels in REGISTERS for its whole life (128 VGPRs of bf16 hi|lo
-//     fragments, loaded once); the target operand streams through a 3-slot LDS ring by LDS-DMA
-//     (global_load_lds_dwordx4: no VGPR staging, no ds_write), two tiles ahead, retired by counted
-//     s_waitcnt vmcnt(N) in front of ONE raw barrier per K-step (a __syncthreads would add vmcnt(0));
-//   * 64 accumulator VGPRs per tile leave room for two workgroups per CU: one's stores run under the other's MFMAs.
+//     fragments, loaded once); the target operand streams through an LDS ring by LDS-DMA (global_load_lds_dwordx4: no VGPR
+//     staging, no ds_write), retired by counted s_waitcnt vmcnt(N) in front of ONE raw barrier per K-step.
 // DMA writes are lane-linear (8 rows x 128 B per wave instruction), so ring rows are unpadded and the 16-byte
 // pieces are XOR-swizzled by (row >> 1) & 7 on the source address and on the fragment reads (conflict-free
 // ds_read_b128).
 // ----------------------------------------------------------------------------------------------
-constexpr int RING_SLOTS = 3;
-constexpr int RING_AHEAD = RING_SLOTS - 1;           // tiles in flight
 constexpr int RING_TILE = 128 * 128;                 // bytes: 128 target pixels x 32 channels x {hi, lo} bf16
 constexpr int RING_IMG2 = 33;                        // row stride (floats) of the level-2 image [32 queries][32 columns]
 constexpr int RING_STAGE = 32 * RING_IMG2 + 32 * 16; // floats per wave: level-2 image + level-3 carry [32][16]
-constexpr int RING_LDS = RING_SLOTS * RING_TILE + 4 * RING_STAGE * 4;
 constexpr int RING_NK = 8;                           // K-steps: C = 256
-constexpr int RING_STORES = 24;                      // global stores of a tile's epilogue: 16 + 8 (+ level 2 / 3 lines: lower bound)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int I, int N, class F>
@@ -398,246 +380,15 @@ __device__ __forceinline__ void ring_for(F&& f) {
     }
 }
 
-// NCH: 64-column chunks per region (2: regions of 8 x 128, level-2 lines complete; 1: W8 % 128 != 0, regions of 8 x 64)
-template <bool MUL, int NCH>
-__global__ void __launch_bounds__(256, 2)
-pf_corr_ring_kernel(const CorrArgs a, const int ablate) {
-    // ablate (PRIORFLOW_CORR_ABLATE, timing-only diagnosis; results are garbage): 1 no global stores, 2 no DMA, 4 no MFMA,
-    // 8 no epilogue, 256 no pooled-level stores, 512 no level-0 stores
-    extern __shared__ __attribute__((aligned(16))) char ring[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-    float* const img2 = reinterpret_cast<float*>(ring + RING_SLOTS * RING_TILE) + wave * RING_STAGE;    // [32][RING_IMG2]
-    float* const carry3 = img2 + 32 * RING_IMG2;                                                         // [32][16]
-    constexpr int NTILES = 4 * NCH;                  // tiles of a region
-    constexpr int RW = 64 * NCH;                     // region width (map columns)
-
-    // ---- work mapping: XCD-contiguous ranges of q = ((batch * regions + region) * m_tiles + m) -------------------
-    // (workgroup ids go round-robin over the 8 XCDs: the workgroups of one XCD share target regions, whose operand
-    // rows stay in that XCD's L2 while the query tiles stream over them)
-    int b, m0, ty0, tx0;
-    {
-        const unsigned nwg = gridDim.x, orig = blockIdx.x;
-        const unsigned xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
-        const unsigned q = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
-        const unsigned rpb = (unsigned)a.W / RW;                       // regions per band of 8 map rows
-        const unsigned regions = (unsigned)(a.H >> 3) * rpb;
-        const unsigned bg = q / (unsigned)a.m_tiles;
-        m0 = (int)(q % (unsigned)a.m_tiles) * BM;
-        b = (int)(bg / regions);
-        const unsigned reg = bg % regions;
-        ty0 = (int)(reg / rpb) * 8;
-        tx0 = (int)(reg % rpb) * RW;
-    }
-    const long rowbytes = 4L * a.C;                  // split image: per 32-channel chunk {hi[32], lo[32]} bf16
-    const char* const f1b = reinterpret_cast<const char*>(a.f1) + (long)b * a.N * rowbytes;
-    const char* const f2b = reinterpret_cast<const char*>(a.f2) + (long)b * a.N * rowbytes;
-
-    // ---- query fragments (the MFMA's B operand: column = query li, K-half lh): registers, once -------------------
-    bf16x8 fq[RING_NK][4];
-    {
-        const char* qrow = f1b + (long)(m0 + 32 * wave + li) * rowbytes + 32 * lh;
-#pragma unroll
-        for (int ks = 0; ks < RING_NK; ++ks) {
-            fq[ks][0] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128);
-            fq[ks][1] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 16);
-            fq[ks][2] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 64);
-            fq[ks][3] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 80);
-        }
-        // retire these loads HERE, before the first DMA is issued: an ordinary load still pending at the loop header
-        // makes hipcc wait vmcnt(0) inside the loop, which would drain the DMA queue on every pass
-#pragma unroll
-        for (int ks = 0; ks < RING_NK; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fq[ks][i]));
-    }
-
-    // ---- target ring ---------------------------------------------------------------------------------------------
-    // Tile i of the region: map rows 2 rp, 2 rp + 1 with rp = 2 (i / (2 NCH)) + (i & 1), columns 64 ch .. with
-    // ch = (i >> 1) % NCH: the two row pairs of a level-2 row come back to back, then the other column chunk.
-    // Ring row 32 w + k of a tile: map row (w >> 1) of the pair, column 32 (w & 1) + k.  Wave w loads rows 32 w ..:
-    // piece j covers rows 32 w + 8 j + (lane >> 3); the swizzle term (r >> 1) & 7 repeats with period 2 in j, so
-    // pieces j and j + 2 differ by 16 columns only, added as a scalar.
-    unsigned dma_off[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 32 * wave + 8 * j + (lane >> 3);
-        dma_off[j] = (unsigned)((8 * j + (lane >> 3)) * (int)rowbytes + (((lane & 7) ^ ((r >> 1) & 7)) * 16));
-    }
-    auto tile_rp = [](int i) { return 2 * (i / (2 * NCH)) + (i & 1); };
-    auto tile_ch = [](int i) { return (i >> 1) % NCH; };
-    int d_tile = 0, d_ks = 0;                        // position of the DMA stream (RING_AHEAD tiles ahead of the compute stream)
-    auto issue_dma = [&](int slot) __attribute__((always_inline)) {
-        const int row = ty0 + 2 * tile_rp(d_tile) + (wave >> 1), col = tx0 + 64 * tile_ch(d_tile) + 32 * (wave & 1);
-        const char* src = f2b + ((long)row * a.W + col) * rowbytes + d_ks * 128;       // wave-uniform
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (!(ablate & 2)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                typedef __attribute__((address_space(3))) void lds_void;
-                lds_void* dst = (lds_void*)(ring + slot * RING_TILE + (4 * wave + j) * 1024);
-                __builtin_amdgcn_global_load_lds(src + (j >> 1) * 16 * rowbytes + dma_off[j & 1], dst, 16, 0, 0);
-            }
-        }
-#else
-        (void)src; (void)slot;
-#endif
-        // advance; past the end the last tile is re-read into a free slot (keeps the vmcnt counts uniform)
-        if (++d_ks == RING_NK) {
-            if (d_tile + 1 < NTILES) { d_ks = 0; ++d_tile; } else { d_ks = RING_NK - 1; }
-        }
-    };
-    // fragment read offsets: ring row 32 t + li, pieces (hi k0-7, hi k8-15, lo k0-7, lo k8-15) of K-half lh
-    unsigned t_piece[4];
-    {
-        const unsigned swz = (unsigned)((li >> 1) & 7), p0 = 2u * lh;
-        t_piece[0] = ((p0 + 0) ^ swz) * 16; t_piece[1] = ((p0 + 1) ^ swz) * 16;
-        t_piece[2] = ((p0 + 4) ^ swz) * 16; t_piece[3] = ((p0 + 5) ^ swz) * 16;
-    }
-    const char* const t_lane = ring + li * 128;
-
-    // acc[2 r + c][4 g + i]: target (map row r of the pair, column 32 c + 8 g + 4 lh + i of the tile), query row li
-    f32x16 acc[4];
-    const long N = a.N;
-    const int W1 = a.W >> 1, W2 = a.W >> 2, W3 = a.W >> 3;
-    const long N1 = N >> 2, N2 = N >> 4, N3 = N >> 6;
-    const long row0 = (long)b * N + m0 + 32 * wave;      // first query row of this wave
-    // store addresses = wave-uniform base (scalars) + ONE 32-bit per-lane byte offset per level; the pooled levels'
-    // offsets are recomputed where they are used from a lane id the compiler cannot see through (hoisted out of the loop
-    // they cost two registers each -- zero-extended -- and the kernel has none to spare)
-    const unsigned off0 = (unsigned)((li * N + 4 * lh) * 4);
-    auto opaque_lane = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
-    auto scaled = [&](float x) { return MUL ? x * a.scale_mul : x / a.inv_scale; };
-    auto pool = [](float tl, float tr, float bl, float br) { float q = tl + tr; q = q + bl; q = q + br; return q * 0.25f; };   // avg_pool2d's order
-    float hs[2][4];                                      // level-1 pair sums of an even row pair (level 2's top row)
-    const bool st0 = !(ablate & (1 | 512)), stp = !(ablate & (1 | 256));
-
-    auto epilogue = [&](int tile) __attribute__((always_inline)) {
-        const int rp = tile_rp(tile), ch = tile_ch(tile);
-        // ---- level 0: registers -> memory, 16 bytes per lane, 2 x 256 contiguous bytes per query row --------------
-        char* const l0 = reinterpret_cast<char*>(a.lvl[0] + row0 * N + (long)(ty0 + 2 * rp) * a.W + tx0 + 64 * ch) + off0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {scaled(acc[t][4 * g]), scaled(acc[t][4 * g + 1]), scaled(acc[t][4 * g + 2]), scaled(acc[t][4 * g + 3])};
-                if (st0) *reinterpret_cast<f32x4*>(l0 + ((long)(t >> 1) * a.W + 32 * (t & 1) + 8 * g) * 4) = v;   // plain: nt stores of 16- / 32-byte pieces take 360 us instead of 155
-            }
-        // ---- level 1: one whole 128-byte line per query row (register adds; operation order of F.avg_pool2d) -------
-        const int ol = opaque_lane(), oli = ol & 31, olh = ol >> 5;
-        char* const l1 = reinterpret_cast<char*>(a.lvl[1] + row0 * N1 + (long)((ty0 >> 1) + rp) * W1 + (tx0 >> 1) + 32 * ch)
-                         + (unsigned)((oli * N1 + 2 * olh) * 4);
-        f32x2 p1[2][4];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x16& top = acc[c];
-                const f32x16& bot = acc[2 + c];
-                p1[c][g].x = pool(scaled(top[4 * g]), scaled(top[4 * g + 1]), scaled(bot[4 * g]), scaled(bot[4 * g + 1]));
-                p1[c][g].y = pool(scaled(top[4 * g + 2]), scaled(top[4 * g + 3]), scaled(bot[4 * g + 2]), scaled(bot[4 * g + 3]));
-                if (stp) *reinterpret_cast<f32x2*>(l1 + (16 * c + 4 * g) * 4) = p1[c][g];   // plain: nt stores of 16- / 32-byte pieces take 360 us instead of 155
-            }
-        if (!(rp & 1)) {                             // upper row pair of a level-2 row: keep tl + tr (the first add of the pooling)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) hs[c][g] = p1[c][g].x + p1[c][g].y;
-            return;
-        }
-        // ---- level 2: values into the wave-private image [query][column]; whole lines leave once the row is complete ----
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float q = hs[c][g] + p1[c][g].x;
-                q = q + p1[c][g].y;
-                img2[oli * RING_IMG2 + 16 * ch + 8 * c + 2 * g + olh] = q * 0.25f;
-            }
-        if (ch != NCH - 1) return;
-        constexpr int C2 = 16 * NCH;                 // level-2 columns of the region
-        constexpr int LPR = C2 / 4;                  // lanes per query row (16 bytes each)
-        constexpr int RPI = 64 / LPR;                // query rows per store instruction
-        const int qr = ol / LPR, pc = ol % LPR;
-        char* const l2 = reinterpret_cast<char*>(a.lvl[2] + row0 * N2 + (long)((ty0 >> 2) + (rp >> 1)) * W2 + (tx0 >> 2))
-                         + (unsigned)((qr * N2 + 4 * pc) * 4);
-        char* const l3 = reinterpret_cast<char*>(a.lvl[3] + row0 * N3 + (long)(ty0 >> 3) * W3 + (tx0 >> 3))
-                         + (unsigned)((qr * N3 + 2 * pc) * 4);
-#pragma unroll
-        for (int k = 0; k < 32 / RPI; ++k) {
-            const float* src = img2 + (qr + RPI * k) * RING_IMG2 + 4 * pc;
-            const f32x4 v = {src[0], src[1], src[2], src[3]};
-            if (stp) *reinterpret_cast<f32x4*>(l2 + (long)RPI * k * N2 * 4) = v;   // plain: nt stores of 16- / 32-byte pieces take 360 us instead of 155
-            // ---- level 3 from the two level-2 rows of the region ------------------------------------------------------
-            float* c3 = carry3 + (qr + RPI * k) * 16 + 2 * pc;
-            if (rp == 1) {
-                c3[0] = v.x + v.y;
-                c3[1] = v.z + v.w;
-            } else {
-                float q0 = c3[0] + v.x, q1 = c3[1] + v.z;
-                q0 = q0 + v.y; q1 = q1 + v.w;
-                const f32x2 o = {q0 * 0.25f, q1 * 0.25f};
-                if (stp) *reinterpret_cast<f32x2*>(l3 + (long)RPI * k * N3 * 4) = o;   // plain: nt stores of 16- / 32-byte pieces take 360 us instead of 155
-            }
-        }
-    };
-
-#pragma unroll
-    for (int i = 0; i < RING_AHEAD; ++i) issue_dma(i);
-    int slot = 0;                                  // g % RING_SLOTS
-    for (int tile = 0; tile < NTILES; ++tile) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        ring_for<0, RING_NK>([&](auto KS) __attribute__((always_inline)) {
-            constexpr int ks = decltype(KS)::value;
-            // tile g was issued RING_AHEAD steps ago; younger vector-memory operations of this wave, in issue order: the
-            // 4 DMA pieces of each of the RING_AHEAD - 1 tiles behind it, and -- when the previous tile's epilogue lies in
-            // between -- its stores (a lower bound of their number: waiting for a few more is harmless)
-            // (An LDS arrival flag written by one more DMA per tile and polled by the consumer -- no vmcnt wait at all -- was
-            // measured too: 171 us against 152 us.  The stores ahead of a DMA block it inside the CU's memory pipeline anyway.)
-            if (ks < RING_AHEAD && tile > 0)
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(4 * (RING_AHEAD - 1) + RING_STORES) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(4 * (RING_AHEAD - 1)) : "memory");
-            issue_dma(slot == 0 ? RING_SLOTS - 1 : slot - 1);             // tile g + RING_AHEAD -> slot (g - 1) % RING_SLOTS
-            const char* tp = t_lane + slot * RING_TILE;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                bf16x8 ft[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ft[q] = *reinterpret_cast<const bf16x8*>(tp + t * 4096 + t_piece[q]);
-                if (ablate & 4) {
-                    asm volatile("" :: "v"(ft[0]), "v"(ft[1]), "v"(ft[2]), "v"(ft[3]));
-                    continue;
-                }
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {       // per element: (query lo * target hi) + (query hi * target lo) + (hi * hi), as the tile kernel
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][2 + k2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[2 + k2], fq[ks][k2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][k2], acc[t], 0, 0, 0);
-                }
-            }
-            slot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
-        });
-        if (!(ablate & 8)) epilogue(tile);
-        else asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
-    }
-    // the tail DMAs (re-reads) must land before the workgroup's LDS is released
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // ----------------------------------------------------------------------------------------------
-// Role-split kernel (round 5; fused pool, bf16x3, C = 256, W8 % 64 == 0, H8 % 8 == 0): the ring kernel's GEMM with the
-// whole store side moved to waves of their own.
+// Role-split kernel (round 5; fused pool, bf16x3, C = 256, W8 % 64 == 0, H8 % 8 == 0): a transposed GEMM whose
+// whole store side runs on waves of their own.
 //
 // What rounds 2-4 measured on the two kernels above (profiles/r2_corr_ablation.txt): GEMM alone 80-97 us, stores alone
 // 110-120 us, together 145-152 us -- the two phases of a wave add, because a wave that stores cannot issue MFMAs, its
 // s_waitcnt vmcnt for the next operand tile also waits for its own stores, and the stores leave in bursts (43-240 per
 // wave, then nothing while the next tile is multiplied).  Here a workgroup is 8 waves with fixed roles:
-//   * waves 0-3 (one per SIMD) are MFMA waves: the ring kernel's stream -- query fragments in registers, target tiles by
+//   * waves 0-3 (one per SIMD) are MFMA waves: query fragments in registers, target tiles by
 //     LDS-DMA through a 4-slot ring, counted vmcnt in front of one barrier per K-step -- and NOTHING else.  The stream is
 //     software-pipelined by hand: the fragments of a K-step's four 32 x 32 blocks ping-pong between two register sets, the
 //     barrier of K-step k + 1 stands in front of the LAST block of K-step k, so the LDS round trip of the first fragments
@@ -649,7 +400,7 @@ pf_corr_ring_kernel(const CorrArgs a, const int ablate) {
 //     pool and store it: per K-step 4 query rows = two level-0 stores of 4 x 256 contiguous bytes and one level-1 store
 //     of 4 whole lines.  The store stream of a CU is therefore even in time (3 stores per wave per K-step) instead of a
 //     burst per tile, every store instruction writes whole 128-byte lines, and no load ever waits behind a store's
-//     completion.  Level 2 goes through the ring kernel's wave-private image and leaves as whole lines, level 3 follows
+//     completion.  Level 2 goes through a wave-private image and leaves as whole lines, level 3 follows
 //     from two level-2 rows.
 // A work item is 128 query pixels x (RB map rows x 64 NCH columns) of targets, RB = 16 when H8 % 16 == 0 (512x1024:
 // 256 items of 16 tiles, one per CU), else 8.  Same products, same k order, same pooling order as the two kernels above:
@@ -763,7 +514,7 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
                 fq[ks][3] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 80);
             }
 #pragma unroll
-            for (int ks = 0; ks < RING_NK; ++ks)       // retired before the first DMA (see the ring kernel)
+            for (int ks = 0; ks < RING_NK; ++ks)       // retired HERE, before the first DMA is issued: an ordinary load still pending at the loop header makes hipcc wait vmcnt(0) inside the loop
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fq[ks][i]));
         }
@@ -1121,7 +872,7 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
     };
     auto finish = [&](const int dt) __attribute__((always_inline)) {
         // level 2: whole lines out of the wave-private image once both row pairs of all column chunks are in; level 3 from
-        // the two level-2 rows of an 8-row band (the ring kernel's code)
+        // the two level-2 rows of an 8-row band 
         const int rp = tile_rp(dt), ch = tile_ch(dt);
         if (!(rp & 1) || ch != NCH - 1) return;
         constexpr int C2 = 16 * NCH;                 // level-2 columns of the region
@@ -1264,15 +1015,10 @@ static int corr_launch(const float* f1, const float* f2, float* lvl0, float* lvl
         a.tiles_x = W8 / 32;
         a.n2_tiles = (H8 / 8) * a.tiles_x;
         a.m_tiles = a.N / BM;
-        // Ring kernel: measured against the tile kernel in one process (profiles/ab_corr.py, profiles/r2_corr_ablation.txt):
-        // 152 vs 145 us at B = 1 (both sit on the ~110 us their scattered store stream needs), 4-5 % faster from B = 8 on.
-        // PRIORFLOW_CORR_RING = 0 / 1 forces one of them (tests, A/B comparisons).
-        const char* env = getenv("PRIORFLOW_CORR_RING");
-        const char* ab = getenv("PRIORFLOW_CORR_ABLATE");            // timing-only diagnosis (profiles/ab_corr.py)
-        const int ablate = ab ? atoi(ab) : 0;
-        // 2: the role-split kernel (round 5), 1: the ring kernel, 0: the tile kernel
-        const int form = env ? (env[0] - '0') : 2;
-        if (split && C == 32 * RING_NK && (W8 % 64) == 0 && form == 2) {
+        // PRIORFLOW_CORR_RS=0 keeps the tile kernel on every map (the bitwise reference of the role-split kernel: tests, A/Bs)
+        const char* const rs_env = getenv("PRIORFLOW_CORR_RS");          // read per launch: the tests switch inside one process
+        const bool rs_on = !(rs_env && rs_env[0] == '0');
+        if (split && C == 32 * RING_NK && (W8 % 64) == 0 && rs_on) {
             const int nch = (W8 % 128) == 0 ? 2 : 1;                 // work items of RB x 128 (or RB x 64) target pixels
             const int RB = (H8 % 16) == 0 ? 16 : 8;
             dim3 grid((unsigned)((long)B * a.m_tiles * (H8 / RB) * (W8 / (64 * nch))));
@@ -1305,27 +1051,6 @@ static int corr_launch(const float* f1, const float* f2, float* lvl0, float* lvl
                         m[0], m[1], m[2], st[0], st[1], st[2], nb);
             }
 #endif
-            return (int)hipGetLastError();
-        }
-        const bool ring = form == 1;
-        if (split && C == 32 * RING_NK && (W8 % 64) == 0 && ring) {
-            const int nch = (W8 % 128) == 0 ? 2 : 1;                 // regions of 8 x 128 (or 8 x 64) target pixels
-            dim3 grid((unsigned)((long)B * a.m_tiles * (H8 / 8) * (W8 / (64 * nch))));
-            const bool mul = a.scale_mul != 0.f;
-            static const hipError_t attr = [] {
-                const void* k[4] = {reinterpret_cast<const void*>(&pf_corr_ring_kernel<true, 2>), reinterpret_cast<const void*>(&pf_corr_ring_kernel<true, 1>),
-                                    reinterpret_cast<const void*>(&pf_corr_ring_kernel<false, 2>), reinterpret_cast<const void*>(&pf_corr_ring_kernel<false, 1>)};
-                for (int i = 0; i < 4; ++i) {
-                    const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
-                    if (e != hipSuccess) return e;
-                }
-                return hipSuccess;
-            }();
-            if (attr != hipSuccess) return (int)attr;
-            if (mul && nch == 2) hipLaunchKernelGGL((pf_corr_ring_kernel<true, 2>), grid, dim3(256), RING_LDS, s, a, ablate);
-            else if (mul) hipLaunchKernelGGL((pf_corr_ring_kernel<true, 1>), grid, dim3(256), RING_LDS, s, a, ablate);
-            else if (nch == 2) hipLaunchKernelGGL((pf_corr_ring_kernel<false, 2>), grid, dim3(256), RING_LDS, s, a, ablate);
-            else hipLaunchKernelGGL((pf_corr_ring_kernel<false, 1>), grid, dim3(256), RING_LDS, s, a, ablate);
             return (int)hipGetLastError();
         }
         dim3 grid((unsigned)((long)a.m_tiles * a.n2_tiles * B));

@@ -1142,8 +1142,7 @@ static int pf_direct_conv_dispatch_n(const PfDirectConvArgs* ds, int n, long tot
                     q.relu = a.relu;
                 }
                 fm.B = m.p[0].B; fm.H = m.p[0].H; fm.W = m.p[0].W;
-                const int rc = pf_flow_stem_launch(fm, n, stream);
-                if (rc != -100) return rc;
+                return pf_flow_stem_launch(fm, n, stream);
             }
             return launch_stem7x7c2(m, n, stream);
         }

@@ -13,5 +13,5 @@ struct PfFlowStemMulti {
     int B, H, W;
 };
 
-// PF_OK / error code; -100: the kernel is switched off (PRIORFLOW_FLOW_STEM_MFMA=0), take the vector-ALU form
+// PF_OK / error code
 int pf_flow_stem_launch(const PfFlowStemMulti& m, int n, void* stream);

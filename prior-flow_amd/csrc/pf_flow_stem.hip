@@ -136,8 +136,6 @@ pf_flow_stem_kernel(const PfFlowStemMulti mm) {
 }  // namespace
 
 int pf_flow_stem_launch(const PfFlowStemMulti& m, int n, void* stream) {
-    static const bool on = [] { const char* e = getenv("PRIORFLOW_FLOW_STEM_MFMA"); return !(e && e[0] == '0'); }();
-    if (!on) return -100;
     if (n < 1 || n > 4 || m.B <= 0 || m.H <= 0 || m.W <= 0) return PF_ERR_BAD_SHAPE;
     const long tiles = (long)m.B * ((m.H + FS_TR - 1) / FS_TR) * ((m.W + 31) / 32);
     if (tiles >= (1L << 31) || (long)m.B * m.H * m.W >= (1L << 31)) return PF_ERR_BAD_SHAPE;

@@ -405,8 +405,9 @@ class Engine:
         # motion_inputs, 4: branch B's lookups, 8: the head tails; 1 is the encoders' fork in prior_raft.py)
         self.forks = int(os.environ.get("PRIORFLOW_FORKS", "15")) if side_streams is not None else 0
         self._b_pending = None      # event after branch B's deferred FlowHead tail (see iteration())
-        # capture-order switches (bit mask; see motion_inputs): 1 chains, 2 head tails, 4 lookups: calling stream first
-        self.order = int(os.environ.get("PRIORFLOW_ORDER", "15"))
+        # capture order (bit mask; see motion_inputs): 1 chains, 2 head tails, 4 lookups -- the calling stream's own chain is captured
+        # first at every fork (round 2's A/B: -330 us per forward; the PRIORFLOW_ORDER knob was retired in round 6)
+        self.order = 15
         # pre-split activations + all-DMA convs (bf16x3 only); PRIORFLOW_PRESPLIT=0 keeps the fp32-staged kernels (A/B knob:
         # the results are bit-identical)
         self.presplit_on = os.environ.get("PRIORFLOW_PRESPLIT", "1") != "0"
@@ -499,8 +500,7 @@ class Engine:
         """iteration_split applies to what the captured test_mode forward runs: side streams, the pre-split path with the hoisted
         context and the fused combine, no B mask head, and B's result either deferred to the next iteration or not needed."""
         return bool(self.split_ab and self.side is not None and self.forks == 15 and self.hoist(P) and ws.pre_ready
-                    and not mask_b and (defer_b_join or not need_b)
-                    and os.environ.get("PRIORFLOW_FUSED_COMBINE", "1") != "0")
+                    and not mask_b and (defer_b_join or not need_b))
 
     def iteration_split(self, ws: Workspace, P, cur: int, need_b: bool, mask_a: bool) -> int:
         """One iteration (core/prior_raft.py:170-211) with branch A's chain (lookup, combine + 1x1, motion encoder, SepConvGRU,
@@ -620,22 +620,15 @@ class Engine:
     def _flow_chain_head(self, ws: Workspace, ps: bool = False):
         """flows + flo_rotate + the two feature warps / groupwise correlations (:171-182) in ONE launch: produces
         flow4_a, flow2_b, the flow tails of x_a / x_b and conf_in.  flo_rotate(flow_B, W2C = grid(R_B2A^T) ==
-        grid(R_A2B), C2W = grid(R_B2A)) (:179).  PRIORFLOW_FUSED_PREP=0 keeps the five separate launches (A/B knob;
-        the results are bit-identical)."""
+        grid(R_A2B), C2W = grid(R_B2A)) (:179).  (The five separate kernels it replaced stay in the library for the training
+        tape; tests/test_hip_kernels.py pins the fused launch to them bit for bit.)"""
         lib = self.lib
         if ps:          # the GRU-input tails go to the split twins of x_a / x_b only
             lib.motion_prep(ws.c1a, ws.c1b, ws.g_a2b_8, ws.g_b2a_8, ws.f["f1a"], ws.f["f2a"], ws.flow4_a, ws.flow2_b,
                             ws.conf_in, None, 252, None, 254, xa_split=ws.x_a_s, xb_split=ws.x_b_s)
             return
-        if os.environ.get("PRIORFLOW_FUSED_PREP", "1") != "0":
-            lib.motion_prep(ws.c1a, ws.c1b, ws.g_a2b_8, ws.g_b2a_8, ws.f["f1a"], ws.f["f2a"], ws.flow4_a, ws.flow2_b,
-                            ws.conf_in, ws.x_a, 252, ws.x_b, 254)
-            return
-        lib.flow_prep(ws.c1a, None, ws.flow4_a, 0, ws.x_a, 252)
-        lib.flow_prep(ws.c1b, ws.flow_b, ws.flow2_b, 0, ws.x_b, 254)
-        lib.flo_rotate(ws.flow_b, ws.g_a2b_8, ws.g_b2a_8, ws.flow_ba, ws.flow4_a, 2, ws.x_a, 254)
-        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.c1a, False, ws.conf_in, 0)
-        lib.warp_gcorr(ws.f["f1a"], ws.f["f2a"], ws.flow_ba, True, ws.conf_in, 4)
+        lib.motion_prep(ws.c1a, ws.c1b, ws.g_a2b_8, ws.g_b2a_8, ws.f["f1a"], ws.f["f2a"], ws.flow4_a, ws.flow2_b,
+                        ws.conf_in, ws.x_a, 252, ws.x_b, 254)
 
     def _flow_chain_tail(self, ws: Workspace, P, need_b: bool):
         """7x7 flow stems + 3x3 (core/update.py:187-191, :94-95) -> cat_a[128:256], cat_b[192:256]."""
@@ -679,7 +672,7 @@ class Engine:
         A looks into B through grid(R_A2B^T)==grid(R_B2A) and rotates back with grid(R_B2A); B the other way."""
         lib, B, H8, W8 = self.lib, ws.B, ws.H8, ws.W8
         # bf16x3: rotate-back + add + convc1 are ONE launch (pf_dccl_combine_conv1x1): corr_a / corr_b never exist
-        fused = P["precision"] == PREC_BF16X3 and os.environ.get("PRIORFLOW_FUSED_COMBINE", "1") != "0"
+        fused = P["precision"] == PREC_BF16X3
         ps = self.presplit(P)
 
         def look_a():
@@ -950,8 +943,8 @@ class EncoderPlan:
         # bf16x3 mode: the stem as a 4x4 stride-1 conv over the space-to-depth image (halo kernel)
         self.stem_s2d = None
         # round 4: the stem straight from the NCHW image (pf_enc_stem, K = 176 instead of 512 and no space-to-depth pass);
-        # PRIORFLOW_STEM_DIRECT=0 keeps the space-to-depth form (A/B knob; same products, another summation order)
-        self.stem_direct = precision == PREC_BF16X3 and os.environ.get("PRIORFLOW_STEM_DIRECT", "1") != "0"
+        # (exact-fp32 mode keeps the space-to-depth form on the generic kernel)
+        self.stem_direct = precision == PREC_BF16X3
         if precision == PREC_BF16X3:
             wp, bp = pack_mfma(stem_s2d_weight(enc.conv1.weight), enc.conv1.bias)
             self.stem_s2d = Conv(wp, bp, 4, 4, 12, 64, precision)
@@ -1145,10 +1138,22 @@ class EncoderPlan:
             # block inputs / outputs exist in both forms (fp32: residual operand, stride-2 convs, final 1x1; twin: the 3x3 convs);
             # the intermediate y1 as a twin only; r = the folded downsample branch of a stride-2 block
             b[f"x{lvl}"] = [z(rows, c), z(rows, c)]
-            b[f"xs{lvl}"] = [split_twin(rows, c, self.dev), split_twin(rows, c, self.dev)]
-            b[f"y{lvl}"] = split_twin(rows, c, self.dev)
+            # level 0's twins (the largest maps: 3 x 0.27 GB per image pair at 512x1024) only when layer 1 does not run on fp32
+            # rows (_run_folded allocates them then): ADVICE r5 -- they were allocated and never used
+            b[f"xs{lvl}"] = [split_twin(rows, c, self.dev), split_twin(rows, c, self.dev)] if lvl else None
+            b[f"y{lvl}"] = split_twin(rows, c, self.dev) if lvl else None
             b[f"r{lvl}"] = z(rows, c)
         self._bufs = self._bufs_by_key[key] = b
+
+    def nbytes(self) -> int:
+        """Bytes of every resident activation set of this plan (PriOr_RAFT._workspace counts them against its byte cap)."""
+        def size(v):
+            if isinstance(v, torch.Tensor):
+                return v.numel() * v.element_size()
+            if isinstance(v, (list, tuple)):
+                return sum(size(t) for t in v)
+            return 0
+        return sum(size(v) for b in self._bufs_by_key.values() for v in b.values())
 
     def _run_folded(self, images, out, epilogue, aux, outs, auxs):
         lib = self.lib
@@ -1156,7 +1161,7 @@ class EncoderPlan:
         self._alloc_folded(Bn, H, W)
         bufs = self._bufs
         h, w = H // 2, W // 2
-        x, xs = bufs["x0"][0], bufs["xs0"][0]
+        x = bufs["x0"][0]
         # Layer 1 (3x3 64 -> 64 at 1/2 resolution) on fp32 rows when pf_conv2d hands those launches to the weights-stationary
         # kernel (pf_conv2d_tile 6, round 5): no twins on this level at all -- the stem writes 67 MB less, conv1's output and the
         # residual tail stay fp32 rows, the stride-2 convs of layer 2 read fp32 anyway.  Same products, same order: same bits.
@@ -1164,6 +1169,11 @@ class EncoderPlan:
         l0_rows = (f0["stride"] == 1 and
                    lib.conv2d_tile([f0["c1"].desc(x, 0, f0["cin"], bufs["r0"], 0, EPI_RELU)], Bn, h, w) == 6 and
                    lib.conv2d_tile([f0["c2"].desc(bufs["r0"], 0, f0["cout"], x, 0, EPI_RELU_RES, h=x)], Bn, h, w) == 6)
+        if not l0_rows and bufs["xs0"] is None:
+            rows0 = Bn * h * w
+            bufs["xs0"] = [split_twin(rows0, 64, self.dev), split_twin(rows0, 64, self.dev)]
+            bufs["y0"] = split_twin(rows0, 64, self.dev)
+        xs = None if l0_rows else bufs["xs0"][0]
         if self.stem_direct:
             lib.enc_stem(images, self.f_stem_w7, self.f_stem_b7, out=x, out_split=None if l0_rows else xs, relu=True)
         else:

@@ -207,7 +207,10 @@ def validate(model, dataset: Iterable, iters: int = 12, name: str = "synthetic",
     great-circle distance.  The per-pixel maps come from ``pf_flow_metrics`` (one launch per sample), the sums stay on the device
     in fp64 until the end.  Returns ``{name + "-epe", name + "-SEPE"}`` and prints the reference's line."""
     lib = _lib.load()
-    was_training = getattr(model, "training", False)
+    # every module's own flag, not just the root's: a caller that froze its BatchNorm layers (freeze_bn, train_flow.py:107-108)
+    # must get them back frozen -- a blanket model.train() would put them into training mode (batch statistics, running stats
+    # mutated) while an already captured GraphedTrainStep keeps replaying the frozen kernels (ADVICE r5)
+    modes = {m: m.training for m in model.modules()} if isinstance(model, torch.nn.Module) else {}
     model.eval()
     epe_sum = None
     pixels, sd_means = 0, []
@@ -229,8 +232,8 @@ def validate(model, dataset: Iterable, iters: int = 12, name: str = "synthetic",
         sd_means.append(sd.double().mean())
     if epe_sum is None:
         raise ValueError("validate: empty dataset")
-    if was_training:
-        model.train()           # (the reference's callers do this themselves, train_flow.py:196-198)
+    for m, was in modes.items():            # (the reference's callers do model.train() + freeze_bn() themselves, train_flow.py:196-198)
+        m.training = was
     epe_v = float(epe_sum / pixels)
     sd_v = float(torch.stack(sd_means).mean())
     if verbose:

@@ -6,8 +6,9 @@ train_flow.py:101), so sub-module attribute names and parameter shapes below are
 part of the drop-in boundary: 217 entries, top-level prefixes
 ``fnet. cnet. ODDC. update_block.``.
 
-The update-block modules are *parameter containers only*: their arithmetic runs in
-the HIP library (``csrc/``), never through ``nn.Conv2d.forward``.
+Every module here is a *parameter container only* (round 6 removed the two plain-torch encoder ``forward``s that survived as
+CPU shape checks): the arithmetic runs in the HIP library (``csrc/``) -- inference through ``engine.EncoderPlan`` / ``engine.Engine``,
+training through ``autograd.encoder_forward`` / ``train_loop`` -- never through ``nn.Conv2d.forward``.
 """
 from __future__ import annotations
 
@@ -41,13 +42,6 @@ class ResidualBlock(nn.Module):
             self.norm3 = _norm(kind, ch)
             self.downsample = nn.Sequential(_conv(cin, ch, 1, 0, stride), self.norm3)
 
-    def forward(self, x):
-        y = self.relu(self.norm1(self.conv1(x)))
-        y = self.relu(self.norm2(self.conv2(y)))
-        if self.downsample is not None:
-            x = self.downsample(x)
-        return self.relu(x + y)
-
 
 class BasicEncoder(nn.Module):
     def __init__(self, output_dim, norm_fn, dropout=0.0):
@@ -67,18 +61,6 @@ class BasicEncoder(nn.Module):
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
-
-    def forward(self, x):
-        """x: one NCHW batch (callers concatenate the image list on dim 0 themselves).
-        Plain-torch statement of core/extractor.py:144-170, kept for the state_dict tree and for CPU shape checks;
-        the product never calls it: inference runs ``engine.EncoderPlan`` (HIP, either precision) and training
-        ``autograd.encoder_forward``."""
-        x = self.relu1(self.norm1(self.conv1(x)))
-        x = self.layer3(self.layer2(self.layer1(x)))
-        x = self.conv2(x)
-        if self.training and self.dropout is not None:
-            x = self.dropout(x)
-        return x
 
 
 # ---- update blocks (core/update.py) ----------------------------------------------------------

@@ -104,7 +104,9 @@ class PriOr_RAFT(nn.Module):
                     for t in v if isinstance(t, torch.Tensor))
         self._ws[key] = ws          # most recently used last
         keep = max(1, int(os.environ.get("PRIORFLOW_WS_KEEP", self.WS_KEEP)))
-        while len(self._ws) > 1 and (len(self._ws) > keep or sum(w.nbytes for w in self._ws.values()) > self.WS_BYTES):
+        # the encoders keep one activation set per resident shape as well (tens of GB at B = 32): they count against the cap
+        resident = lambda: sum(w.nbytes for w in self._ws.values()) + sum(p.nbytes() for p in (self._enc_plans or ()))  # noqa: E731
+        while len(self._ws) > 1 and (len(self._ws) > keep or resident() > self.WS_BYTES):
             old = next(iter(self._ws))
             del self._ws[old]
             for gk in [gk for gk in self._graphs if (gk[0], gk[1], gk[2], gk[4]) == old]:
@@ -143,41 +145,19 @@ class PriOr_RAFT(nn.Module):
             # is captured into the HIP graph as parallel branches) so that the latency-bound
             # kernels of one (stem, statistics) hide behind the other's convolutions
             cur = torch.cuda.current_stream()
-            s1, s2 = self._streams()[:2]
-            # Which queue gets which encoder (round 4, profiles/r4_encoder_order.txt).  The phase is bound by the SUM of the two
-            # encoders' kernel time, not by when cnet starts: with fnet on the calling stream and cnet forked behind it (default)
-            # cnet's first kernel only gets CUs at t = 1.5 ms, because every fnet launch of layers 1-2 fills the chip and a
-            # queued workgroup of the older queue wins a freed CU; with both on side streams ("both_side") or cnet on the
-            # calling stream ("cnet_main"), cnet starts at t = 0.2 ms and both chains run at half speed beside each other.
-            # Under the tracer the phase then ends 50-75 us earlier (2.44 / 2.47 against 2.51 ms); untraced, interleaved on one
-            # box, the forward is no faster (129.2 / 129.2 against 129.8 / 129.9 pairs/s): the default stays.
-            order = os.environ.get("PRIORFLOW_ENC_ORDER", "fnet_main")
-            if order == "fnet_main":
-                # fnet (the longer chain) stays on the calling stream and is enqueued first; cnet forks from an event
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
-                s1.wait_event(ev)
-                with torch.cuda.stream(s1):
-                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
-                cur.wait_stream(s1)
-            elif order == "cnet_main":
-                ev = torch.cuda.Event()
-                ev.record(cur)
+            s1 = self._streams()[0]
+            # Which queue gets which encoder (rounds 4 and 5, profiles/r4_encoder_order.txt): the phase is bound by the SUM of the
+            # two encoders' kernel time, not by when cnet starts -- with cnet on the calling stream or both on side streams cnet
+            # starts at t = 0.2 ms instead of 1.5 ms and both chains run at half speed beside each other; the untraced forward
+            # was no faster in either round, and the PRIORFLOW_ENC_ORDER knob was retired in round 6.  fnet (the longer chain)
+            # stays on the calling stream and is captured first; cnet forks from an event.
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
+            s1.wait_event(ev)
+            with torch.cuda.stream(s1):
                 cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
-                s1.wait_event(ev)
-                with torch.cuda.stream(s1):
-                    fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
-                cur.wait_stream(s1)
-            else:
-                s1.wait_stream(cur)
-                s2.wait_stream(cur)
-                with torch.cuda.stream(s1):
-                    cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
-                with torch.cuda.stream(s2):
-                    fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
-                cur.wait_stream(s1)
-                cur.wait_stream(s2)
+            cur.wait_stream(s1)
         else:
             cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
             fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
@@ -216,7 +196,7 @@ class PriOr_RAFT(nn.Module):
                 # (core/prior_raft.py:212-213), so 23 of 24 upsamples, every B mask head and
                 # branch B's last update are never observable.
                 cur = eng.iteration(ws, P, cur, need_b=not last, mask_a=last, mask_b=False,
-                                    defer_b_join=not last and os.environ.get("PRIORFLOW_DEFER_B", "1") != "0")
+                                    defer_b_join=not last)
                 if last:
                     eng.upsample(ws, "a", out_a[0])
             else:

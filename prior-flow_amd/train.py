@@ -399,6 +399,10 @@ class GraphedTrainStep:
         if self.graphs is None:
             self.static = tuple(t.detach().float().contiguous().clone() for t in (image1, image2, flow_gt, valid))
             self._set_hyper()
+            from .autograd import SINK
+            fdev = self.opt.flat.device
+            sink = SINK.for_device(fdev.index if fdev.index is not None else torch.cuda.current_device())
+            sink.reserve(fdev)                       # the gradient arena: allocated HERE, not inside the capture's private pool
             torch.cuda.synchronize()
             try:
                 graphs, (vec, keys) = self._capture()
@@ -406,6 +410,7 @@ class GraphedTrainStep:
                 self.static = None                   # nothing half-captured is kept (the sink was aborted by _body_a)
                 raise
             self.graphs, self.out_vec, self.out_keys = graphs, vec, keys
+            self._arena = sink.arena                 # the graph holds its raw pointer: alive for as long as this stepper is
         else:
             for dst, src in zip(self.static, (image1, image2, flow_gt, valid)):
                 dst.copy_(src)

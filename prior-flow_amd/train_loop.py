@@ -349,7 +349,7 @@ class LoopFn(torch.autograd.Function):
         # nodes only register their packed buffers), so the deferred launches -- 3.5 ms of chip-filling kernels -- go to the side
         # stream and run beside the correlation pyramids' and the encoders' backward (6 ms of mostly small kernels); the sink joins
         # the stream before it unpacks.  Without the sink the gradients are handed to autograd right away: same stream, as before.
-        defer_side = bool(SINK.active) and os.environ.get("PRIORFLOW_TRAIN_WGRAD_SIDE", "1") != "0"
+        defer_side = bool(SINK.active)
         wg_stream = side if defer_side else main
         if defer_side:
             ev_iter = torch.cuda.Event()
@@ -384,7 +384,7 @@ class LoopFn(torch.autograd.Function):
             wg("a.cf1", A["conf_in"], 0, 8, A["d_cf1"], 0, 32)
             for t in "ab":          # mask = 0.25 * conv: the output gradient stored for m2 is the un-scaled one
                 P.acc[t + ".m2"].scale = 0.25
-            stem_grads = []
+            stem_grads, stem_on_side = [], False
             for name, x, off, dy in (("a.f1a", A["flow4"], 0, A["d_t_a"]), ("a.f1b", A["flow4"], 2, A["d_t_ba"]), ("b.f1", Bb["flow2"], 0, Bb["d_t"])):
                 m = P.stems[name]
                 if SINK.active and m.weight.grad is not None and m.bias.grad is not None and m.weight.requires_grad and m.bias.requires_grad:
@@ -392,11 +392,22 @@ class LoopFn(torch.autograd.Function):
                     lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, m.weight.grad, m.bias.grad, 7, 7, 1, Bi, H8, W8)
                     stem_grads += [None, None]
                     continue
+                if not (m.weight.requires_grad or m.bias.requires_grad):
+                    stem_grads += [None, None]         # a frozen stem: nothing to compute (the launch was wasted)
+                    continue
                 dw, db = torch.zeros_like(m.weight), torch.zeros_like(m.bias)
                 lib.conv2d_wgrad_small(_flat(x), False, off, 2, _flat(dy), 0, 128, dw, db, 7, 7, 1, Bi, H8, W8)
                 stem_grads += [dw, db]
+                stem_on_side = defer_side             # handed to autograd, which consumes it on the CALLING stream
         if defer_side:
             SINK.join_streams.append(side)
+            if stem_on_side:
+                # a trainable stem outside the sink (its .grad not allocated yet): dw / db were produced on the side stream after
+                # the event the calling stream waited for -- join, or autograd's accumulation races the launch
+                main.wait_stream(side)
+                for t in stem_grads:
+                    if t is not None:
+                        t.record_stream(main)
         n_launch += 29 + 3
         STATS["hip"] += n_launch
         d_net_a, d_net_b = _nchw(gh["a"].contiguous(), B, H8, W8), _nchw(gh["b"].contiguous(), B, H8, W8)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Same-process A/B of the corr + pyramid kernels (tile kernel vs ring kernel and its tuning knobs), interleaved rounds:
+"""Same-process A/B of the corr + pyramid kernels (tile kernel vs role-split kernel), interleaved rounds:
    python profiles/ab_corr.py [rounds] [reps] [variant ...]      (MB_BATCH = pairs, MB_H8 / MB_W8 = map size)
-A variant is `name` (a predefined one) or `name:KEY=VAL,KEY=VAL` with KEY in RING, ABLATE, NB, STAGGER, ROT
-(-> PRIORFLOW_CORR_<KEY>).  Prints per-variant median / min HIP-event time per launch and the algorithmic HBM rate."""
+A variant is `tile` or `rs` (-> PRIORFLOW_CORR_RS=0 / 1; timing-only ablations of the role-split kernel are compile-time builds:
+profiles/ab_corr_libs.py).  Prints per-variant median / min HIP-event time per launch and the algorithmic HBM rate."""
 import os
 import statistics
 import sys
@@ -16,19 +16,13 @@ from prior_flow_amd import _lib
 args = sys.argv[1:]
 rounds = int(args[0]) if len(args) > 0 else 7
 reps = int(args[1]) if len(args) > 1 else 10
-PREDEF = {"tile": "RING=0", "ring": "RING=1", "rs": "RING=2", "rs-nostore": "RING=2,ABLATE=1", "rs-nodma": "RING=2,ABLATE=2",
-          "rs-nomfma": "RING=2,ABLATE=4", "rs-nostorewave": "RING=2,ABLATE=8", "rs-nodump": "RING=2,ABLATE=24",
-          "rs-onlymfma": "RING=2,ABLATE=26", "rs-onlystore": "RING=2,ABLATE=6", "rs-L0only": "RING=2,ABLATE=256",
-          "rs-pooledonly": "RING=2,ABLATE=512", "rs-onlystore-L0": "RING=2,ABLATE=262", "rs-onlystore-pooled": "RING=2,ABLATE=518", "nostore": "ABLATE=1", "nodma": "ABLATE=2", "nomfma": "ABLATE=4",
-          "noepi": "ABLATE=8", "onlymfma": "ABLATE=11", "onlyepi": "ABLATE=6", "nostore-nodma": "ABLATE=3"}
+PREDEF = {"tile": "RS=0", "rs": "RS=1"}
 variants = []
-for v in (args[2:] or ["tile", "ring", "rs"]):
+for v in (args[2:] or ["tile", "rs"]):
     name, _, spec = v.partition(":")
     spec = spec or PREDEF[name]
     variants.append((name, dict(kv.split("=") for kv in spec.split(","))))
-    if "RING" not in variants[-1][1]:          # the ablation switches of rounds 2-4 are the ring kernel's
-        variants[-1][1]["RING"] = "1"
-KEYS = ("RING", "ABLATE", "NB", "STAGGER", "ROT", "SLOTS")
+KEYS = ("RS",)
 lib = _lib.load()
 dev = torch.device("cuda:0")
 B, H8, W8, C = int(os.environ.get("MB_BATCH", "1")), int(os.environ.get("MB_H8", "64")), int(os.environ.get("MB_W8", "128")), 256

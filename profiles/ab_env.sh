@@ -6,6 +6,6 @@ REPS=$1; shift
 ARGS=${BENCH_ARGS:---no-cpu-baseline --no-batch32 --no-train-step --steps 60}
 for i in $(seq $REPS); do
 for cfg in "$@"; do
-  e=$cfg; [ "$cfg" = "-" ] && e="PRIORFLOW_DUMMY=0"
+  e=$cfg; [ "$cfg" = "-" ] && e="PF_AB_DEFAULTS=1"
   env $e python bench.py $ARGS 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-40s' % '$cfg', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"
 done; done

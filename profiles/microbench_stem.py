@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single launches of pf_enc_stem at the forward's shapes (fnet: 4 images of 512x1024 -> fp32 rows + statistics; cnet: 2 images ->
-split twin, ReLU), HIP-event time per launch.   python profiles/microbench_stem.py [reps]      (PRIORFLOW_STEM_STAGGER=n: A/B)"""
+split twin, ReLU), HIP-event time per launch.   python profiles/microbench_stem.py [reps]"""
 import os
 import sys
 
@@ -42,4 +42,4 @@ for name, Bn in (("fnet", 4), ("cnet", 2)):
         torch.cuda.synchronize()
         ts.append(s.elapsed_time(e) * 1e3 / reps)
     mb = rows * 64 * 4 / 1e6
-    print(f"stagger={os.environ.get('PRIORFLOW_STEM_STAGGER', '0'):>3} {name}: median {sorted(ts)[2]:6.1f} us  min {min(ts):6.1f} us   ({mb:.0f} MB out)")
+    print(f"{name}: median {sorted(ts)[2]:6.1f} us  min {min(ts):6.1f} us   ({mb:.0f} MB out)")

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Regenerates the committed round-5 measurement artefacts on the GPU box (run through gpurun from the repo root) into
-# gpurun_out/final5/; copy what is to be judged into profiles/ as r5_final_<name> (profiles/profile_index.json names the files
+# Regenerates the committed round-6 measurement artefacts on the GPU box (run through gpurun from the repo root) into
+# gpurun_out/final6/; profiles/adopt_final.sh copies what is to be judged into profiles/ as r6_final_<name> (profiles/profile_index.json names the files
 # bench.py reads for `in_replay_us` and `traffic`).  Parts: PART=all | core | train | ab (a gpurun call is limited to 20 minutes).
 export TMPDIR=/tmp
 ulimit -c 0
-O=gpurun_out/final5
+O=gpurun_out/final6
 mkdir -p $O
 PART=${PART:-all}
 B="--no-cpu-baseline --no-batch32 --no-train-step"
@@ -52,16 +52,14 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 tests/run_train_2rank.py --graphed 2>&1 | grep -E "rank|graphed" >> $O/train_2rank_check.txt
 fi
 if [ $PART = all ] || [ $PART = ab ]; then
-# same-box A/Bs, interleaved: the corr + pyramid build's three kernels inside the whole forward
-for i in 1 2; do for p in 0 2; do
-  PRIORFLOW_CORR_RING=$p python bench.py $B --steps 60 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=1  corr form=$p', d['value'], 'pairs/s', d['ms_per_step'], 'ms; corr alone', d['roofline_corr']['avg_launch_us'], 'us')"
-done; done > $O/ab_corr_form.txt
-for i in 1 2; do for p in 0 1 2; do
-  PRIORFLOW_CORR_RING=$p python bench.py --batch 32 --no-cpu-baseline --no-train-step --steps 4 --warmup 2 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=32 corr form=$p', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"
-done; done >> $O/ab_corr_form.txt
-python profiles/ab_corr.py 5 10 tile ring rs > $O/ab_corr_kernels.txt 2>&1
-MB_BATCH=8 python profiles/ab_corr.py 3 4 tile ring rs >> $O/ab_corr_kernels.txt 2>&1
+# same-box A/Bs, interleaved: round 6's split chains (two half-chip chains of one-group launches) against the round-5 schedule,
+# and the two corr + pyramid kernels inside the whole forward
+profiles/ab_env.sh 3 "PRIORFLOW_SPLIT_AB=0" "PRIORFLOW_SPLIT_AB=1" > $O/ab_split_chains.txt 2>&1
+BENCH_ARGS="--batch 32 --no-cpu-baseline --no-batch32 --no-train-step --steps 4 --warmup 2" profiles/ab_env.sh 2 "PRIORFLOW_SPLIT_AB=0" "PRIORFLOW_SPLIT_AB=1" >> $O/ab_split_chains.txt 2>&1
+profiles/ab_env.sh 2 "PRIORFLOW_CORR_RS=0" "PRIORFLOW_CORR_RS=1" > $O/ab_corr_form.txt 2>&1
+python profiles/ab_corr.py 5 10 tile rs > $O/ab_corr_kernels.txt 2>&1
+MB_BATCH=8 python profiles/ab_corr.py 3 4 tile rs >> $O/ab_corr_kernels.txt 2>&1
 fi
-for f in pytest_gpu.log smoke.log forward_breakdown.txt time_sizes.txt ab_corr_form.txt ab_corr_kernels.txt train_2rank_check.txt; do [ -f $O/$f ] && { echo "== $f"; tail -12 $O/$f | cut -c1-220; }; done
+for f in pytest_gpu.log smoke.log forward_breakdown.txt time_sizes.txt ab_split_chains.txt ab_corr_form.txt ab_corr_kernels.txt train_2rank_check.txt; do [ -f $O/$f ] && { echo "== $f"; tail -12 $O/$f | cut -c1-220; }; done
 for f in bench_n1.json bench_batch32.json train_step_time.json train_step_time_two_graphs.json train_step_time_eager.json train_step_time_batch8.json train_step_time_2rank_gloo.json; do [ -f $O/$f ] && { echo "== $f"; cut -c1-330 $O/$f; }; done
 exit 0

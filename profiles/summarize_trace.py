@@ -8,7 +8,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "pf_corr_kernel" in r["Kernel_Name"] or "pf_corr_rs_kernel" in r["Kernel_Name"] or "pf_corr_ring_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "pf_corr_kernel" in r["Kernel_Name"] or "pf_corr_rs_kernel" in r["Kernel_Name"]]
 starts = idx[0::2]
 if len(sys.argv) > 2:
     k = int(sys.argv[2])

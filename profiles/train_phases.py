@@ -26,7 +26,7 @@ def last(key):
 
 
 marks = [("prep + encoders fwd", 0)]
-i_corr = first("pf_corr_rs_kernel") or first("pf_corr_kernel") or first("pf_corr_ring_kernel")
+i_corr = first("pf_corr_rs_kernel") or first("pf_corr_kernel")
 marks.append(("corr pyramids", i_corr - 2 if i_corr else 0))
 i_loop = first("pf_motion_prep")
 marks.append(("loop forward", i_loop))

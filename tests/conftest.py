@@ -12,7 +12,7 @@ sys.dont_write_bytecode = False
 
 def _run_two_rank_graphed():
     """Two ranks of the captured training step on this box's one card over gloo (tests/test_hip_train_step.py).  Started from
-    pytest_configure, i.e. before anything in this process has initialised the GPU (`torch.cuda.device_count()` does not)."""
+    pytest_configure, i.e. before anything in this process has initialised the GPU."""
     import socket
     import subprocess
     with socket.socket() as s:
@@ -37,9 +37,13 @@ def pytest_configure(config):
         files = [str(a) for a in config.args]
         wanted = (not kexpr or "two_ranks" in kexpr or "graphed" in kexpr) and \
                  (all(not f.endswith(".py") for f in files) or any("test_hip_train_step" in f for f in files))
+        # count the cards WITHOUT the HIP runtime (visibility masks, else the KFD topology -- bench.visible_gpus, whose module imports
+        # nothing but the standard library): torch.cuda.device_count() falls back to hipGetDeviceCount where amdsmi is missing,
+        # which initialises HSA in this process just before it spawns GPU children.  With two or more cards the
+        # children take one each and the all-reduce runs over RCCL ("nccl"), else both share card 0 over gloo (run_train_2rank.py).
         try:
-            import torch
-            ngpu = torch.cuda.device_count()
+            from bench import visible_gpus
+            ngpu = visible_gpus()
         except Exception:
             ngpu = 0
         if wanted and ngpu > 0:

@@ -104,6 +104,68 @@ def test_conv_launch_plan_is_host_logic(built_lib, monkeypatch):
     assert lib._dll.pf_conv2d_stats_blocks(desc(cin=62), 1, 1, 64, 128) < 0
 
 
+def test_co_groups_hint_keeps_the_two_group_tile(built_lib):
+    """Round 6: branch A's and branch B's update blocks run as two chains of one-group launches (Engine.iteration_split).  The
+    tile choice counts work items per CHIP, so pf_conv_desc.co_groups = 1 tells it that a second launch of the same geometry runs
+    beside this one: the launch then takes the tile (and the all-DMA role) a two-group launch takes -- 128 items, half the CUs --
+    instead of the smaller tile with which it would fill the chip alone.  Host logic: no GPU needed."""
+    from prior_flow_amd import _lib
+    lib = _lib.PfLib(_lib.LIB_PATH, require_cuda=False)
+    fake = 0x1000
+
+    def desc(cin, cout, kh, kw, co, epi=_lib.EPI_RELU, **kw_):
+        d = _lib.ConvDesc()
+        d.in0_split, d.lds0, d.off0, d.c0 = fake, (cin + 31) // 32, 0, cin
+        d.weight, d.bias = fake, fake
+        d.out, d.ld_out, d.off_out, d.cout = fake, 256, 0, cout
+        d.kh, d.kw = kh, kw
+        d.epilogue, d.scale, d.precision, d.stride = epi, 1.0, _lib.PREC_BF16X3, 1
+        d.zeros, d.zeros_bytes = fake, 4096
+        d.co_groups = co
+        for name, v in kw_.items():
+            setattr(d, name, v)
+        return d
+
+    def plan(ds):
+        a = (_lib.ConvDesc * len(ds))(*ds)
+        return lib._dll.pf_conv2d_tile(a, len(ds), 1, 64, 128), lib._dll.pf_conv2d_roles(a, len(ds), 1, 64, 128)
+
+    gru = dict(epi=_lib.EPI_GRU_ZR, h=fake, ld_h=128, aux_split=fake, lds_aux=4)
+    for cin, cout, kh, kw, extra in ((256, 256, 1, 5, gru), (256, 256, 5, 1, gru), (128, 256, 3, 3, {}), (288, 126, 3, 3, {})):
+        two = plan([desc(cin, cout, kh, kw, 0, **extra), desc(cin, cout, kh, kw, 0, **extra)])
+        assert plan([desc(cin, cout, kh, kw, 1, **extra)]) == two, (cin, cout, kh, kw)
+    # without the hint a z|r launch of one branch falls back to the 128 px x 64 channel tile (256 items: the whole chip)
+    assert plan([desc(256, 256, 1, 5, 0, **gru)]) != plan([desc(256, 256, 1, 5, 1, **gru)])
+    bad = (_lib.ConvDesc * 1)(desc(256, 256, 1, 5, 9, **gru))
+    assert lib._dll.pf_conv2d_tile(bad, 1, 1, 64, 128) < 0            # more co-launched groups than a launch can hold: refused
+
+
+def test_every_profiled_kernel_has_its_counter_evidence():
+    """a new default kernel shipped without its PMC entry and the driver's bench line carried `traffic: null` for the
+    headline kernel.  Every library kernel the committed bench line of the current round names (`kernels_by_time`, the roofline
+    objects) must have an entry in the committed PMC traffic file of the same round, and every MFMA kernel one in the MFMA-busy
+    file (profiles/profile_index.json names the three)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    idx = json.load(open(os.path.join(root, "profiles", "profile_index.json")))["profiles"][0]
+    rnd = idx["round"]
+    bench = json.load(open(os.path.join(root, "profiles", f"r{rnd}_final_bench_n1.json")))
+    pmc = json.load(open(os.path.join(root, "profiles", idx["pmc"])))["kernels"]
+    busy = json.load(open(os.path.join(root, "profiles", idx["mfma"])))["kernels"]
+    alias = {"pf_lookup": "pf_lookup_elem", "pf_stem7x7c2_valu": "pf_flow_stem_kernel", "pf_stats_partial+final": "pf_stats_",
+             "pf_corr_kernel": "pf_corr_"}
+    named = [k["kernel"] for k in bench["kernels_by_time"]]
+    named += [bench[o]["kernel"] for o in ("roofline", "roofline_conv", "roofline_gru", "roofline_corr", "roofline_lookup", "roofline_combine")
+              if o in bench]
+    for name in named:
+        key = alias.get(name.split(" ")[0], name.replace(" bf16x3", "").replace(" fp32", ""))
+        assert any(key in k for k in pmc), f"{name}: no entry in profiles/{idx['pmc']} -- re-run profiles/pmc_traffic.py"
+        if "conv" in key and "kernel" in key or "pf_corr_" in key or "pf_enc_" in key:
+            assert any(key in k for k in busy), f"{name}: no entry in profiles/{idx['mfma']} -- re-run profiles/mfma_busy.py"
+    for o in ("roofline", "roofline_gru", "roofline_corr"):
+        assert bench[o].get("traffic") is not None, f"{o}: traffic is null on the committed bench line"
+
+
 def test_state_dict_contract():
     from prior_flow_amd.prior_raft import PriOr_RAFT
     args = argparse.Namespace(mixed_precision=False, dropout=0.0)

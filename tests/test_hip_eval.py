@@ -98,13 +98,17 @@ def test_plain_validate_loops_equal_the_references_arithmetic(capsys):
     model = PriOr_RAFT(argparse.Namespace(mixed_precision=False, dropout=0.0))
     model.load_state_dict(gc.det_state_dict(state_dict_shapes()), strict=True)
     model = model.cuda().train()
+    model.freeze_bn()                           # train_flow.py:107-108: every BatchNorm layer in eval mode inside a training model
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert bns and not any(m.training for m in bns)
     data = []
     for i in range(3):
         i1, i2 = gc.synthetic_pair(1, 128, 256, seed=177 + i)
         gt = torch.stack([gc.uni(f"val2/u{i}", (126, 250), -6, 6), gc.uni(f"val2/v{i}", (126, 250), -3, 3)])
         data.append((i1[0, :, 1:127, 3:253].contiguous(), i2[0, :, 1:127, 3:253].contiguous(), gt, None))
     res = ev.validate_MPF(model, iters=2, scene="EFT", dataset=data)
-    assert model.training
+    assert model.training and model.fnet.training and model.update_block.training
+    assert not any(m.training for m in bns), "validate() put frozen BatchNorm layers back into training mode (ADVICE r5)"
     assert "Validation (EFT) EPE:" in capsys.readouterr().out
     model.eval()
     epes, sds = [], []

@@ -255,22 +255,21 @@ def test_corr_pyramid(lib, dev, shape, prec):
 
 @pytest.mark.parametrize("shape", [(1, 64, 128), (2, 24, 128), (1, 48, 64), (3, 16, 64), (1, 32, 256), (2, 40, 64)],
                          ids=lambda s: "B%dx%dx%d" % s)
-@pytest.mark.parametrize("form", ["1", "2"], ids=["ring", "role_split"])
-def test_corr_ring_kernel_matches_tile_kernel_bitwise(lib, dev, shape, form, monkeypatch):
-    """The ring kernel (transposed GEMM, query fragments in registers, target tiles of 2 map rows x 64 columns streamed
-    by LDS-DMA, regions of 8 x 128 -- or 8 x 64 when W/8 is not a multiple of 128 -- per workgroup) performs the tile
+@pytest.mark.parametrize("form", ["1"], ids=["role_split"])
+def test_corr_role_split_kernel_matches_tile_kernel_bitwise(lib, dev, shape, form, monkeypatch):
+    """The role-split kernel (round 5: a transposed GEMM -- query fragments in registers, target tiles of 2 map rows x 64 columns
+    streamed by LDS-DMA -- on four MFMA waves, scaling / pooling / every global store on four store waves fed through an LDS
+    staging image; items of 16 or 8 map rows x 128 -- or 64 when W/8 is not a multiple of 128 -- columns) performs the tile
     kernel's arithmetic in the tile kernel's order: all four levels must be bit-identical, and nothing outside them may
-    be written.  (Maps whose width is not a multiple of 64, e.g. 640x1280, stay on the tile kernel.)  The same holds for
-    the role-split kernel (round 5: the ring kernel's GEMM on four MFMA waves, scaling / pooling / every global store on
-    four store waves fed through an LDS staging image; items of 16 or 8 map rows)."""
+    be written.  (Maps whose width is not a multiple of 64, e.g. 640x1280, stay on the tile kernel: PRIORFLOW_CORR_RS=0 everywhere.)"""
     B, h, w = shape
     n = h * w
     gen = torch.Generator().manual_seed(h * w + B)
     f = [(torch.rand(B * n, 256, generator=gen) * 3.4 - 1.7).to(dev) for _ in range(2)]
     sp = [lib.split_bf16(x, torch.empty(B * n, 8, 2, 32, dtype=torch.bfloat16, device=dev)) for x in f]
     out = {}
-    for rep, mode in enumerate(("0",) + (form,) * 5):      # the ring kernel repeatedly: a stale ring tile (a missed
-        monkeypatch.setenv("PRIORFLOW_CORR_RING", mode)              # DMA wait) would show up as a rare 128 x 32 patch
+    for rep, mode in enumerate(("0",) + (form,) * 5):      # the role-split kernel repeatedly: a stale ring tile (a missed
+        monkeypatch.setenv("PRIORFLOW_CORR_RS", mode)                # DMA wait) would show up as a rare 128 x 32 patch
         # one guard row of NaNs behind every level: must stay untouched
         lv = [torch.full((B * n + 1, (h >> i) * (w >> i)), float("nan"), device=dev) for i in range(4)]
         lib.corr_pyramid_bf16x3(sp[0], sp[1], [x[:B * n] for x in lv], B, h, w, 256)
@@ -278,7 +277,7 @@ def test_corr_ring_kernel_matches_tile_kernel_bitwise(lib, dev, shape, form, mon
         if rep >= 2:
             for i in range(4):
                 assert torch.equal(out[form][i], lv[i]) or i < 0 or bool(torch.isnan(lv[i][B * n]).all()) and \
-                    torch.equal(out[form][i][:B * n], lv[i][:B * n]), f"level {i}: ring kernel run {rep} differs from its first run"
+                    torch.equal(out[form][i][:B * n], lv[i][:B * n]), f"level {i}: run {rep} of the role-split kernel differs from its first run"
         else:
             out[mode] = lv
     for i in range(4):
