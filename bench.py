@@ -61,9 +61,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not t
 # Reported beside `peak` as context for `mfma_pipe_util`; `frac` stays against the nameplate.
 SUSTAINED_BF16_MFMA_TFLOPS = 1830.0
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
-TILE_NAMES = {0: "pf_conv_mfma_kernel<4,1,1> (128x32)", 1: "pf_conv_mfma_kernel<2,2,1> (64x64)",
-              2: "pf_conv_mfma_kernel<2,2,2> (64x128)", 3: "pf_conv_halo_kernel<1> (128x64)",
-              4: "pf_conv_halo_kernel<2> (128x128)"}
+# generic kernel by pf_conv2d_tile code, spelled as rocprofv3 prints the instantiation (the committed profiles are matched by name)
+TILE_NAMES = {0: "pf_conv_mfma_kernel<4, 1, 1", 1: "pf_conv_mfma_kernel<2, 2, 1", 2: "pf_conv_mfma_kernel<2, 2, 2"}
 
 
 def log(msg):
@@ -251,7 +250,7 @@ def profile_kernels(model, i1, i2):
         if tile >= 3:      # halo kernel <NT, KH, KW, AFFINE, TH>
             return "pf_conv_halo_kernel<%d, %d, %d, %s, %d>" % (
                 1 if tile == 3 else 2, d0.kh, d0.kw, "true" if d0.in_scale else "false", 8 if tile == 5 else 4)
-        return TILE_NAMES[tile].split(" ")[0][:-1] + (", true>" if d0.precision == 1 else ", false>")
+        return TILE_NAMES[tile] + (", true>" if d0.precision == 1 else ", false>")
 
     def wrap(attr, kind, name_fn, work_fn):
         orig = getattr(lib, attr)

@@ -457,7 +457,8 @@ class Engine:
     def build_pyramids(self, ws: Workspace, precision: int = PREC_F32):
         """corr + build_pyramid for both views (core/prior_raft.py:151-159)."""
         if precision == PREC_BF16X3:
-            self.lib.split_bf16(ws.f_all, ws.f_split)          # all four feature maps at once
+            if not getattr(ws, "f_split_ready", False):        # (round 6: fnet's last convolution writes the hi|lo rows itself)
+                self.lib.split_bf16(ws.f_all, ws.f_split)      # all four feature maps at once
             rows = ws.B * ws.N
             fs = [ws.f_split[i * rows:(i + 1) * rows] for i in range(4)]
             # (the two volumes on two queues -- one launch's store phase under the other's GEMM phase -- measured 138.9 against

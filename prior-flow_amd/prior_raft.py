@@ -140,6 +140,13 @@ class PriOr_RAFT(nn.Module):
         # context features: net (fp32 + split twin) and inp (first 128 columns of the GRU input x; twin only when the
         # update blocks run on pre-split activations)
         ctx = dict(outs=ws.net0_ab_s, auxs=ws.x_ab_s) if eng.presplit(self._weights()) else dict(aux=ws.x_ab)
+        # fnet's last convolution (1x1 128 -> 256) writes the features twice: fp32 rows (the warps' operand) and the bf16 hi|lo
+        # rows the corr GEMM multiplies -- the epilogue's twin equals pf_split_bf16 of the fp32 rows bit for bit, and the
+        # separate split launch (21-37 us of kernel time between the encoders and the corr build) is gone (round 6; the forward's
+        # wall time did not move: 147.1 against 147.2 pairs/s, profiles/r6_ab_head.txt -- the stretch overlaps cnet's tail)
+        from ._lib import PREC_BF16X3
+        fsplit = dict(outs=ws.f_split) if self._weights()["precision"] == PREC_BF16X3 and fplan.precision == PREC_BF16X3 else {}
+        ws.f_split_ready = bool(fsplit)
         if self.use_streams and int(os.environ.get("PRIORFLOW_FORKS", "15")) & 1:
             # cnet and fnet are independent: fork them onto two side streams (the fork/join
             # is captured into the HIP graph as parallel branches) so that the latency-bound
@@ -153,14 +160,14 @@ class PriOr_RAFT(nn.Module):
             # stays on the calling stream and is captured first; cnet forks from an event.
             ev = torch.cuda.Event()
             ev.record(cur)
-            fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
+            fplan.run(ws.img_f, ws.f_all, EPI_LINEAR, **fsplit)
             s1.wait_event(ev)
             with torch.cuda.stream(s1):
                 cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
             cur.wait_stream(s1)
         else:
             cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
-            fplan.run(ws.img_f, ws.f_all, EPI_LINEAR)
+            fplan.run(ws.img_f, ws.f_all, EPI_LINEAR, **fsplit)
 
     def _streams(self):
         if self._side_streams is None:
@@ -173,6 +180,9 @@ class PriOr_RAFT(nn.Module):
         # (joining cnet in front of the iterations instead of after the encoders -- its tail beside the corr build -- measured
         # 133.1 / 133.3 against 133.7 / 133.3 pairs/s in round 3 and was removed)
         self._encode(image1, image2, ws, eng)
+        # coords1 = coords0 (+ init_flow) needs nothing of the encoders: in front of the corr build instead of on the serial
+        # stretch between it and the first lookup (three small copies, ~19 us with their gaps; round 6)
+        eng.init_coords(ws, init_flow)
         if self.use_streams and eng.hoist(P):
             # the hoisted context convs (MFMA-bound) run beside the corr build (store-bound); the corr build stays on the calling
             # stream and is enqueued first
@@ -187,7 +197,6 @@ class PriOr_RAFT(nn.Module):
         else:
             eng.hoist_context(ws, P)               # iteration-invariant part of the GRU convs (pre-split path only)
             eng.build_pyramids(ws, P["precision"])
-        eng.init_coords(ws, init_flow)
         cur = 0
         for it in range(iters):
             last = it == iters - 1

@@ -456,6 +456,20 @@ def test_split_branch_chains_leave_the_flow_bitwise(params, size, iters, batch, 
         assert torch.equal(ref, out), (graph, float((ref - out).abs().max()))
 
 
+def test_fnet_writes_the_corr_operand_twins(model):
+    """Round 6: fnet's last convolution writes the bf16 hi|lo rows the corr GEMM multiplies next to the fp32 features (no
+    pf_split_bf16 launch between the encoders and the corr build): they must be pf_split_bf16 of the fp32 rows bit for bit."""
+    i1, i2 = gc.synthetic_pair(1, 256, 512, seed=3)
+    with torch.no_grad():
+        model(i1.cuda(), i2.cuda(), iters=1, test_mode=True)
+    ws = next(w for k, w in model._ws.items() if k[:3] == (1, 256, 512))
+    assert ws.f_split_ready
+    want = model._lib().split_bf16(ws.f_all, torch.empty_like(ws.f_split))
+    torch.cuda.synchronize()
+    assert float(ws.f_all.abs().mean()) > 1e-3
+    assert torch.equal(want.view(torch.int16), ws.f_split.view(torch.int16))
+
+
 def test_workspaces_and_graphs_of_several_shapes_stay_resident(params):
     """an evaluation loop over mixed sizes (or B = 1 / B = 2 in turn) must not re-allocate its workspace and re-capture
     its graph on every switch: the model keeps a few shapes resident (least recently used first out) together with the graphs
