@@ -419,8 +419,8 @@ __device__ __forceinline__ void ring_for(F&& f) {
 #ifndef PF_RS_PRIO
 #define PF_RS_PRIO 0
 #endif
-#ifndef PF_RS_SYNC               // 0: one s_barrier per K-step for all 8 waves (shipped); 1: counters in LDS (see "Synchronisation" below)
-#define PF_RS_SYNC 0
+#ifndef PF_RS_MFMA16             // 1: v_mfma_f32_16x16x32_bf16 on the MFMA waves (round 6); 0: v_mfma_f32_32x32x16_bf16 (round 5, bit-identical to the tile kernel)
+#define PF_RS_MFMA16 1
 #endif
 #ifdef PF_RS_STAMP               // diagnosis build: cycles per wave spent in barriers / behind waits / issuing stores
 __device__ unsigned long long pf_rs_dbg[2048 * 8 * 4];
@@ -430,9 +430,7 @@ constexpr int RS_SLOTS = 4;                          // divides the 8 K-steps of
 constexpr int RS_AHEAD = PF_RS_AHEAD;                // K-steps in flight (2 or 3)
 constexpr int RS_PITCH = 132;                        // floats per staging row: 2 x 64 targets + 16 bytes (conflict-free ds_write_b128)
 constexpr int RS_STAGE = 32 * RS_PITCH;              // floats per MFMA wave
-constexpr int RS_CNT_OFF = RS_SLOTS * RING_TILE + 4 * RS_STAGE * 4 + 4 * RING_STAGE * 4;   // 16 counters (unsigned) behind the images
-constexpr int RS_LDS = RS_CNT_OFF + 64;
-constexpr unsigned RS_SPIN_CAP = 1u << 22;           // a poll loop gives up after this many rounds (a hang must not outlive the kernel)
+constexpr int RS_LDS = RS_SLOTS * RING_TILE + 4 * RS_STAGE * 4 + 4 * RING_STAGE * 4;
 #define RS_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <bool MUL, int NCH>
@@ -463,36 +461,10 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
     auto tile_rp = [](int i) { return 2 * (i / (2 * NCH)) + (i & 1); };
     auto tile_ch = [](int i) { return (i >> 1) % NCH; };
     float* const stag_all = reinterpret_cast<float*>(ring + RS_SLOTS * RING_TILE);
-    constexpr bool FLAGSYNC = PF_RS_SYNC != 0;
-    // Synchronisation, experimental form (PF_RS_SYNC = 1; measured and NOT shipped: 111 us against 97 us per launch at 512x1024, 872
-    // against 834 us at batch 8, profiles/r5_corr_rs_flagsync.txt -- the LDS atomic + poll per K-step cost the four MFMA waves more
-    // (their side alone: 93 against 80 us) than the barrier waits it removes).  With one s_barrier per K-step for all eight waves a store wave that is held up in a
-    // global store (the CU accepts one 1-KB store per ~46 cycles; twelve are issued behind every barrier) arrives late and the
-    // four MFMA waves wait for it: 23 K of 167 K cycles per item in the barrier, 6 K without the stores (profiles/r5_corr_rs_stamps.txt).
-    // So nobody executes s_barrier in the loop.  Monotonic counters in LDS instead:
-    //   cnt[0]      K-step arrivals of the MFMA waves: a wave adds 1 once ITS pieces of K-step g have landed (counted vmcnt); the
-    //               fragments of K-step g may be read, and the slot of K-step g - 2 overwritten, once cnt[0] >= 4 (g + 1).  The
-    //               add is posted a block early and the poll read rides under three MFMAs that need nothing from memory;
-    //   cnt[4 + w]  staging images of MFMA wave w handed over (added behind the last ds_write of a tile's dump: LDS executes a
-    //               wave's instructions in order), polled by store wave w before it pulls an image;
-    //   cnt[8 + w]  images pulled by store wave w (added once its reads have returned), polled by MFMA wave w before a dump.
-    // A store wave may therefore lag a whole tile (eight K-steps) behind without holding anybody up.
-    unsigned* const cnt = reinterpret_cast<unsigned*>(ring + RS_CNT_OFF);
-    if (FLAGSYNC) {
-        if (tid < 16) cnt[tid] = 0u;
-        __syncthreads();
-    }
-    auto post = [&](unsigned* c) __attribute__((always_inline)) {             // one LDS atomic per wave
-        if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto spin_until = [&](const unsigned* c, unsigned target, bool sleepy) __attribute__((always_inline)) {
-        unsigned v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile unsigned*>(c));
-        for (unsigned n = 0; v < target && n < RS_SPIN_CAP; ++n) {
-            if (sleepy) __builtin_amdgcn_s_sleep(8);
-            v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile unsigned*>(c));
-        }
-    };
-
+    // Synchronisation: one s_barrier per K-step for all eight waves.  (Round 5 also built LDS arrival / full / empty counters in its
+    // place -- the store waves then never meet a barrier and may lag a whole tile: bit-identical, 111 against 97 us per launch,
+    // because the atomic + poll per K-step cost the four MFMA waves more than the barrier waits they remove,
+    // profiles/r5_corr_rs_flagsync.txt; the code was removed in round 6.)
     if (wave < 4) {
         // ================================ MFMA waves ================================================================
         if (ablate & 64) return;
@@ -503,21 +475,13 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
         const long rowbytes = 4L * a.C;
         const char* const f1b = reinterpret_cast<const char*>(a.f1) + (long)b * a.N * rowbytes;
         const char* const f2b = reinterpret_cast<const char*>(a.f2) + (long)b * a.N * rowbytes;
-        bf16x8 fq[RING_NK][4];
-        {
-            const char* qrow = f1b + (long)(m0 + 32 * wave + li) * rowbytes + 32 * lh;
-#pragma unroll
-            for (int ks = 0; ks < RING_NK; ++ks) {
-                fq[ks][0] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128);
-                fq[ks][1] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 16);
-                fq[ks][2] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 64);
-                fq[ks][3] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 80);
-            }
-#pragma unroll
-            for (int ks = 0; ks < RING_NK; ++ks)       // retired HERE, before the first DMA is issued: an ordinary load still pending at the loop header makes hipcc wait vmcnt(0) inside the loop
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fq[ks][i]));
-        }
+#if PF_RS_MFMA16
+        // v_mfma_f32_16x16x32_bf16: one instruction covers a whole 32-channel chunk.  Lane l holds, of operand row / column l & 15,
+        // the 8 channels 8 (l >> 4) ..: the 16-byte piece (l >> 4) of the row image's hi half, piece 4 + (l >> 4) of its lo half.
+        // A wave's 32 queries are two column tiles qt; fq[ks][2 qt + {0: hi, 1: lo}].
+        const int l15 = lane & 15, l4 = lane >> 4;
+#endif
+        bf16x8 fq[RING_NK][4];                           // loaded behind the first DMA pieces (below)
         // ring row 32 w + k of a tile: map row (w >> 1) of the pair, column 32 (w & 1) + k; wave w loads rows 32 w ..: piece j
         // covers rows 32 w + 8 j + (lane >> 3), the swizzle term (r >> 1) & 7 repeats with period 2 in j
         unsigned dma_off[4];                             // per-lane byte offsets of the 4 pieces from the wave's tile base
@@ -557,6 +521,19 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
         // The reads and their waits are inline assembly: hipcc's own wait insertion drains lgkmcnt to 0 in front of every MFMA
         // group, which exposes the round trip of the reads issued just before it (2 x ~120 cycles per K-step).
         unsigned t_addr[4];
+#if PF_RS_MFMA16
+        {
+            // block t = ring rows 32 t .. 32 t + 31 = two 16-row target tiles j; t_addr[2 j + {0: hi, 1: lo}] of ring row 16 j + l15
+            // (the swizzle term (row >> 1) & 7 does not depend on j or t); 16 lanes of a K group read 16 rows x one piece each:
+            // 2 x 8 swizzled positions x 4 banks = all 64 banks, conflict-free
+            const unsigned swz = (unsigned)((l15 >> 1) & 7);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                t_addr[q] = lds_base + (unsigned)(16 * (q >> 1) + l15) * 128u + ((((unsigned)l4 + 4u * (q & 1)) ^ swz) * 16u);
+        }
+        // D[target 4 (l >> 4) + i][query l & 15]: a lane's 4 accumulator registers are 4 consecutive targets of one query
+        float* const stag = stag_all + wave * RS_STAGE + l15 * RS_PITCH + 4 * l4;
+#else
         {
             const unsigned base = lds_base + (unsigned)li * 128u;
             const unsigned swz = (unsigned)((li >> 1) & 7), p0 = 2u * lh;
@@ -565,6 +542,16 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
         }
         float* const stag = stag_all + wave * RS_STAGE + li * RS_PITCH + 4 * lh;
 
+#endif
+#if PF_RS_MFMA16
+        // acc[t][2 j + qt][i]: target = ring row 32 t + 16 j + 4 (l >> 4) + i of the tile, query 16 qt + (l & 15)
+        f32x4 acc[4][4];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[t][g] = zero4;
+#else
         // acc[2 r + c][4 g + i]: target (map row r of the pair, column 32 c + 8 g + 4 lh + i of the tile), query row li
         f32x16 acc[4];
         f32x16 zero16;
@@ -572,6 +559,7 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
         for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = zero16;
+#endif
         bf16x8 fa[4], fb[4];                             // the two fragment register sets
 #pragma unroll
         for (int q = 0; q < 4; ++q) { fa[q] = bf16x8{}; fb[q] = bf16x8{}; }
@@ -591,6 +579,28 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
             if (ablate & 4) return;
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ft[0]), "+v"(ft[1]), "+v"(ft[2]), "+v"(ft[3]) : "n"(decltype(CNT)::value));
         };
+#if PF_RS_MFMA16
+        // One block of a K-step (32 targets x 32 queries = 2 x 2 tiles of 16 x 16): 12 MFMAs of 16 cycles, pass-major -- (query lo *
+        // target hi), (query hi * target lo), (hi * hi), each over the 4 tiles, so the same accumulator comes back every fourth
+        // instruction -- with gap(i) behind every second MFMA: the same six gaps of ~32 cycles per block as the 32x32x16 form.
+        // Per element the three passes now add over all 32 channels of the chunk at once (the 32x32x16 form: 16 + 16), so the
+        // sums differ from the tile kernel's in the last bits; the oracle is the pin (tests/test_hip_kernels.py).
+        auto block = [&](bf16x8 (&ft)[4], int t, int ks, bool fresh, auto&& gap) __attribute__((always_inline)) {
+            ring_for<0, 12>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value, pass = i / 4, g = i % 4, j = g >> 1, qt = g & 1;
+                if (!(ablate & (4 | 1024))) {
+                    if (pass == 0) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ft[2 * j], fq[ks][2 * qt + 1], fresh ? zero4 : acc[t][g], 0, 0, 0);
+                    else if (pass == 1) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ft[2 * j + 1], fq[ks][2 * qt], acc[t][g], 0, 0, 0);
+                    else acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ft[2 * j], fq[ks][2 * qt], acc[t][g], 0, 0, 0);
+                } else if ((ablate & 1024) && i == 0) asm volatile("" :: "v"(ft[0]), "v"(ft[1]), "v"(ft[2]), "v"(ft[3]));
+                if constexpr (i & 1) {
+                    RS_SB();
+                    gap(std::integral_constant<int, i / 2>{});
+                    RS_SB();
+                }
+            });
+        };
+#else
         // One 32 x 32 block of a K-step: 6 MFMAs -- per element (query lo * target hi) + (query hi * target lo) + (hi * hi) for
         // both 16-channel halves, the tile kernel's order -- with gap(i) issued behind MFMA i.  What goes into the gaps is
         // everything else this wave does: one DMA piece, or one ds_write_b128 of the staging dump (the LDS takes wide
@@ -609,32 +619,20 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
                 RS_SB();
             });
         };
-        // the two halves of a block on their own (PF_RS_SYNC = 1: the K-step synchronisation sits between them)
-        auto block_half = [&](bf16x8 (&ft)[4], int t, int ks, int k2, bool fresh) __attribute__((always_inline)) {
-            if (ablate & (4 | 1024)) return;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][2 + k2], (fresh && k2 == 0) ? zero16 : acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[2 + k2], fq[ks][k2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[k2], fq[ks][k2], acc[t], 0, 0, 0);
-        };
-        auto block_half_gaps = [&](bf16x8 (&ft)[4], int t, int ks, auto&& gap) __attribute__((always_inline)) {   // second half, gap(i) behind MFMA i
-            ring_for<0, 3>([&](auto I) __attribute__((always_inline)) {
-                constexpr int m = decltype(I)::value;
-                if (!(ablate & (4 | 1024))) {
-                    if (m == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[1], fq[ks][3], acc[t], 0, 0, 0);
-                    else if (m == 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[3], fq[ks][1], acc[t], 0, 0, 0);
-                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[1], fq[ks][1], acc[t], 0, 0, 0);
-                }
-                RS_SB();
-                gap(I);
-                RS_SB();
-            });
-        };
+#endif
         auto no_gap = [](auto) {};
+#if PF_RS_MFMA16
+        auto dump_piece = [&](int t, int g) __attribute__((always_inline)) {   // staging[query 16 qt + l15][32 t + 16 j + 4 l4 ..+3], g = 2 j + qt
+            if (ablate & 16) { asm volatile("" :: "v"(acc[t][g])); return; }
+            *reinterpret_cast<f32x4*>(stag + (g & 1) * 16 * RS_PITCH + 32 * t + 16 * (g >> 1)) = acc[t][g];
+        };
+#else
         auto dump_piece = [&](int t, int g) __attribute__((always_inline)) {   // staging[query li][64 r + 32 c + 8 g + 4 lh ..+3], t = 2 r + c
             if (ablate & 16) { asm volatile("" :: "v"(acc[t])); return; }
             const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
             *reinterpret_cast<f32x4*>(stag + 64 * (t >> 1) + 32 * (t & 1) + 8 * g) = v;
         };
+#endif
         using C0 = std::integral_constant<int, 0>;
         using C4 = std::integral_constant<int, 4>;
 
@@ -643,99 +641,39 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
                 dma_piece(cur_src, std::integral_constant<int, decltype(I)::value * 128>{}, decltype(I)::value, decltype(J)::value);
             });
         });
+        // Query fragments: once, into registers.  Issued BEHIND the first K-steps' DMA pieces (round 6: their latencies overlap; the
+        // loads in front cost ~1.5 us of a 100 us launch) and retired HERE: an ordinary load still pending at the loop header makes
+        // hipcc wait vmcnt(0) inside the loop (its counter does not see the DMA pieces, which are inline assembly; being older than
+        // the loads they only make its counted waits longer, never shorter).
+        {
+#if PF_RS_MFMA16
+            const char* qrow = f1b + (long)(m0 + 32 * wave + l15) * rowbytes + 16 * l4;
+#pragma unroll
+            for (int ks = 0; ks < RING_NK; ++ks) {
+                fq[ks][0] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128);
+                fq[ks][1] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 64);
+                fq[ks][2] = *reinterpret_cast<const bf16x8*>(qrow + 16 * rowbytes + ks * 128);
+                fq[ks][3] = *reinterpret_cast<const bf16x8*>(qrow + 16 * rowbytes + ks * 128 + 64);
+            }
+#else
+            const char* qrow = f1b + (long)(m0 + 32 * wave + li) * rowbytes + 32 * lh;
+#pragma unroll
+            for (int ks = 0; ks < RING_NK; ++ks) {
+                fq[ks][0] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128);
+                fq[ks][1] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 16);
+                fq[ks][2] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 64);
+                fq[ks][3] = *reinterpret_cast<const bf16x8*>(qrow + ks * 128 + 80);
+            }
+#endif
+#pragma unroll
+            for (int ks = 0; ks < RING_NK; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fq[ks][i]));
+        }
 #ifdef PF_RS_STAMP
         unsigned long long st_wait = 0, st_bar = 0;
         const unsigned long long st_begin = RS_T();
 #endif
-        if (FLAGSYNC) {
-            using C1 = std::integral_constant<int, 1>;
-            // arrival for K-step 0 (its pieces are the oldest RS_AHEAD - 1 groups behind)
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RS_AHEAD - 1)) : "memory");
-            post(cnt);
-            unsigned gstep = 0;                                        // global K-step
-            for (int tile = 0; tile < NT; ++tile) {
-                nxt_src = tile_src(tile + 1 < NT ? tile + 1 : tile);
-                ring_for<0, RING_NK>([&](auto KS) __attribute__((always_inline)) {
-                    constexpr int ks = decltype(KS)::value;
-                    constexpr int sbase = (ks % RS_SLOTS) * RING_TILE;
-                    constexpr int kd = ks + RS_AHEAD;
-                    const char* const dsrc = kd >= RING_NK ? nxt_src : cur_src;
-                    using DK = std::integral_constant<int, (kd % RING_NK) * 128>;
-                    const unsigned target = 4u * (gstep + 1u);
-                    // the poll read of this K-step's arrival count, in flight under the first half of the previous K-step's last block
-                    unsigned seen;
-                    {
-                        const unsigned ca = lds_base + RS_CNT_OFF;
-                        asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(ca) : "memory");
-                    }
-                    RS_SB();
-                    if (ks > 0 || tile > 0) {
-                        wait_for(fb, C1{});                            // everything but the poll read
-                        constexpr int pk = (ks + RING_NK - 1) % RING_NK;
-                        block_half(fb, 3, pk, 0, ks == 1);
-                    }
-                    RS_SB();
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(seen));
-                    if (__builtin_amdgcn_readfirstlane(seen) < target) spin_until(cnt, target, false);
-                    RS_SB();
-                    reads(fa, std::integral_constant<int, sbase>{});
-                    RS_SB();
-                    // second half of that block with this K-step's DMA pieces (slot of K-step g - 2: every wave is past it) in the gaps
-                    if (ks > 0 || tile > 0) {
-                        constexpr int pk = (ks + RING_NK - 1) % RING_NK;
-                        block_half_gaps(fb, 3, pk, [&](auto I) __attribute__((always_inline)) {
-                            dma_piece(dsrc, DK{}, kd % RS_SLOTS, decltype(I)::value);
-                        });
-                        dma_piece(dsrc, DK{}, kd % RS_SLOTS, 3);
-                    } else {
-                        ring_for<0, 4>([&](auto I) __attribute__((always_inline)) { dma_piece(dsrc, DK{}, kd % RS_SLOTS, decltype(I)::value); });
-                    }
-                    auto dump_gap = [&](int t, bool on) {
-                        return [&, t, on](auto I) __attribute__((always_inline)) {
-                            if constexpr (decltype(I)::value < 4) { if (on) dump_piece(t, decltype(I)::value); }
-                        };
-                    };
-                    RS_SB();
-                    reads(fb, std::integral_constant<int, sbase + 4096>{});
-                    RS_SB();
-                    wait_for(fa, C4{});
-                    if (ks == 0) block(fa, 0, ks, true, dump_gap(2, tile > 0));
-                    else block(fa, 0, ks, false, no_gap);
-                    RS_SB();
-                    reads(fa, std::integral_constant<int, sbase + 2 * 4096>{});
-                    RS_SB();
-                    wait_for(fb, C4{});
-                    if (ks == RING_NK - 1) spin_until(cnt + 8 + wave, (unsigned)tile, false);      // the store wave has pulled the previous image
-                    if (ks == 0) {
-                        block(fb, 1, ks, true, dump_gap(3, tile > 0));
-                        if (tile > 0) post(cnt + 4 + wave);                                        // image of tile - 1 complete (behind its last ds_write)
-                    } else if (ks == RING_NK - 1) block(fb, 1, ks, false, dump_gap(0, true));
-                    else block(fb, 1, ks, false, no_gap);
-                    RS_SB();
-                    // arrival for the next K-step: its pieces went out RS_AHEAD - 1 K-steps ago
-                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RS_AHEAD - 1)) : "memory");
-                    post(cnt);
-                    RS_SB();
-                    reads(fb, std::integral_constant<int, sbase + 3 * 4096>{});
-                    RS_SB();
-                    wait_for(fa, C4{});                                // the four youngest LDS operations are the reads above
-                    if (ks == RING_NK - 1) block(fa, 2, ks, false, dump_gap(1, true));
-                    else block(fa, 2, ks, ks == 0, no_gap);
-                    RS_SB();
-                    ++gstep;
-                });
-                cur_src = nxt_src;
-            }
-            wait_for(fb, C0{});
-            block(fb, 3, RING_NK - 1, false, no_gap);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dump_piece(2, g);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dump_piece(3, g);
-            post(cnt + 4 + wave);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the tail DMAs (re-reads) land before this wave leaves
-            return;
-        }
         for (int tile = 0; tile < NT; ++tile) {
             nxt_src = tile_src(tile + 1 < NT ? tile + 1 : tile);      // past the end the last tile is re-read (uniform vmcnt counts)
             ring_for<0, RING_NK>([&](auto KS) __attribute__((always_inline)) {
@@ -852,6 +790,9 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
         for (int i = 0; i < 4; ++i) { r0[i] = scaled(r0[i]); r1[i] = scaled(r1[i]); }
         // ---- level 0: 4 query rows x 256 contiguous bytes per store, both map rows ----------------------------------
         char* const l0 = reinterpret_cast<char*>(a.lvl[0] + (row0 + 4 * p) * N + (long)(ty0 + 2 * rp) * a.W + tx0 + 64 * ch) + off0;
+        // (Round 6 timed a wrong-on-purpose variant in which a store instruction writes ONE query row x 1 KB contiguous instead of
+        // 4 query rows x 256 B -- every byte of level 0 still written once: store side alone 86.9 against 86.3 us, whole kernel 97.5
+        // against 93.3 us, profiles/r6_corr_rs_m16.txt.  The layout of the store stream is not what bounds it.)
         if (st0) {
             vol_store(reinterpret_cast<f32x4*>(l0), r0);
             vol_store(reinterpret_cast<f32x4*>(l0 + 4L * a.W), r1);
@@ -913,18 +854,6 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
     unsigned long long st_bar = 0, st_work = 0, st_last = 0;
     const unsigned long long st_begin = RS_T();
 #endif
-    if (FLAGSYNC) {
-        for (int tile = 0; tile < NT; ++tile) {
-            spin_until(cnt + 4 + sw, (unsigned)tile + 1u, true);       // image of this tile handed over
-            if (!(ablate & 8)) pull();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            post(cnt + 8 + sw);                                        // ... and free again
-            if (ablate & 8) continue;
-            ring_for<0, 8>([&](auto P) __attribute__((always_inline)) { pass(P, tile); });
-            finish(tile);
-        }
-        return;
-    }
     // The staging image of tile i is complete behind the barrier of K-step (i + 1, 1).  Interval (tile, ks): pass (ks - 1) & 7 of
     // data tile (ks >= 1 ? tile - 1 : tile - 2).
     for (int tile = 0; tile < NT; ++tile) {
