@@ -128,7 +128,7 @@ class PriOr_RAFT(nn.Module):
             self._graphs.clear()
         return self._enc_plans
 
-    def _encode(self, image1, image2, ws: Workspace, eng: Engine):
+    def _encode(self, image1, image2, ws: Workspace, eng: Engine, init_flow=None):
         """Normalise, rotate to view B, run cnet / fnet (core/prior_raft.py:109-149) and leave the
         features in the workspace (channel-last): f1A,f2A,f1B,f2B; net = tanh(cnet[:128]),
         inp = relu(cnet[128:]) for both views."""
@@ -147,27 +147,32 @@ class PriOr_RAFT(nn.Module):
         from ._lib import PREC_BF16X3
         fsplit = dict(outs=ws.f_split) if self._weights()["precision"] == PREC_BF16X3 and fplan.precision == PREC_BF16X3 else {}
         ws.f_split_ready = bool(fsplit)
+        P = self._weights()
         if self.use_streams and int(os.environ.get("PRIORFLOW_FORKS", "15")) & 1:
-            # cnet and fnet are independent: fork them onto two side streams (the fork/join
-            # is captured into the HIP graph as parallel branches) so that the latency-bound
-            # kernels of one (stem, statistics) hide behind the other's convolutions
+            # cnet and fnet are independent: two queues (inside the HIP graph: parallel branches).  Round 6 order: the calling stream
+            # takes coords1 = coords0 (+ init_flow) -- three small copies that need nothing of the encoders --, cnet and, right behind
+            # it, the hoisted context terms of the GRU convolutions (they need only cnet's `inp`); fnet forks from an event.  cnet's
+            # chain is short, so the 90 us of hoisted convolutions run inside the encoder phase, which is bound by the SUM of the
+            # two encoders' work whatever their order (rounds 4 and 5: profiles/r4_encoder_order.txt), and the two corr + pyramid
+            # launches then have the chip to themselves: 134 / 142 -> 90 / 87 us per launch in the replay, first lookup 26 us earlier,
+            # 154.0 -> 155.1 pairs/s same box (profiles/r6_ab_cnet_first.txt).  Before, fnet came first, cnet only got CUs at
+            # t = 1.3 ms, and the hoisted convolutions shared the chip with the corr build: both were slowed (157 us for a 45 us launch).
             cur = torch.cuda.current_stream()
             s1 = self._streams()[0]
-            # Which queue gets which encoder (rounds 4 and 5, profiles/r4_encoder_order.txt): the phase is bound by the SUM of the
-            # two encoders' kernel time, not by when cnet starts -- with cnet on the calling stream or both on side streams cnet
-            # starts at t = 0.2 ms instead of 1.5 ms and both chains run at half speed beside each other; the untraced forward
-            # was no faster in either round, and the PRIORFLOW_ENC_ORDER knob was retired in round 6.  fnet (the longer chain)
-            # stays on the calling stream and is captured first; cnet forks from an event.
             ev = torch.cuda.Event()
             ev.record(cur)
-            fplan.run(ws.img_f, ws.f_all, EPI_LINEAR, **fsplit)
+            eng.init_coords(ws, init_flow)
+            cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
+            eng.hoist_context(ws, P)
             s1.wait_event(ev)
             with torch.cuda.stream(s1):
-                cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
+                fplan.run(ws.img_f, ws.f_all, EPI_LINEAR, **fsplit)
             cur.wait_stream(s1)
         else:
+            eng.init_coords(ws, init_flow)
             cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
             fplan.run(ws.img_f, ws.f_all, EPI_LINEAR, **fsplit)
+            eng.hoist_context(ws, P)               # iteration-invariant part of the GRU convs (pre-split path only)
 
     def _streams(self):
         if self._side_streams is None:
@@ -179,24 +184,8 @@ class PriOr_RAFT(nn.Module):
         P = self._weights()
         # (joining cnet in front of the iterations instead of after the encoders -- its tail beside the corr build -- measured
         # 133.1 / 133.3 against 133.7 / 133.3 pairs/s in round 3 and was removed)
-        self._encode(image1, image2, ws, eng)
-        # coords1 = coords0 (+ init_flow) needs nothing of the encoders: in front of the corr build instead of on the serial
-        # stretch between it and the first lookup (three small copies, ~19 us with their gaps; round 6)
-        eng.init_coords(ws, init_flow)
-        if self.use_streams and eng.hoist(P):
-            # the hoisted context convs (MFMA-bound) run beside the corr build (store-bound); the corr build stays on the calling
-            # stream and is enqueued first
-            cur, side = torch.cuda.current_stream(), self._streams()[0]
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            eng.build_pyramids(ws, P["precision"])
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                eng.hoist_context(ws, P)
-            cur.wait_stream(side)
-        else:
-            eng.hoist_context(ws, P)               # iteration-invariant part of the GRU convs (pre-split path only)
-            eng.build_pyramids(ws, P["precision"])
+        self._encode(image1, image2, ws, eng, init_flow)       # incl. coords1 = coords0 (+ init_flow) and the hoisted context terms
+        eng.build_pyramids(ws, P["precision"])
         cur = 0
         for it in range(iters):
             last = it == iters - 1
