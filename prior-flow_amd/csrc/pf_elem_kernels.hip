@@ -714,7 +714,111 @@ __global__ void __launch_bounds__(256) pf_flow_out_strip(const PfFlowOutN pn, co
         }
     }
 }
+// The same convolution for big batches (round 6): one wave per TILE of 4 x 4 pixels.  The strip form reads a 3 x 6 neighbourhood
+// per 4 pixels -- 4.5 KB of rows per pixel, fine while the map sits in the L2 / memory-side cache (8.4 MB at B = 1: 8 us per launch)
+// but 454 us per launch at batch 32, where 268 MB per branch stream from HBM.  A 4 x 4 tile reads 6 x 6 rows per 16 pixels: 2.25 KB
+// per pixel.  Per output pixel the products, the order of the additions inside a lane (channel slab, then ky, then kx) and the
+// cross-lane tree (partners at distance 32, 16, 8, 4, 2, 1) are the strip kernel's, so the results are bit-identical
+// (tests/test_hip_kernels.py); the strip form stays for small batches, where 4x fewer waves would not fill the chip.
+__global__ void __launch_bounds__(256) pf_flow_out_tile(const PfFlowOutArgs a, const long tiles, const int tpr, const int tpc) {
+    const int lane = threadIdx.x & 63;
+    long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 4;
+    const long N = (long)a.H * a.W;
+    for (; tile < tiles; tile += stride) {
+        const long b = tile / ((long)tpc * tpr);
+        const int rem = (int)(tile % ((long)tpc * tpr));
+        const int y0 = (rem / tpr) * 4, x0 = (rem % tpr) * 4;
+        float s[32];                                   // s[2 (4 row + col) + output]
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s[j] = 0.f;
+        for (int c = lane * 4; c < a.C; c += 256) {
+            float4 w0[9], w1[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                w0[k] = *reinterpret_cast<const float4*>(a.w + (long)k * a.C + c);
+                w1[k] = *reinterpret_cast<const float4*>(a.w + (long)(9 + k) * a.C + c);
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {              // input row y0 + r - 1: feeds output row r - ky (ky ascending with r: the strip kernel's order)
+                const int yy = y0 + r - 1;
+                if (yy < 0 || yy >= a.H) continue;                           // wave-uniform
+                const float* xrow = a.x + (b * N + (long)yy * a.W) * a.ld + c;
+                float4 v[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int xx = x0 + i - 1;
+                    v[i] = (xx >= 0 && xx < a.W) ? *reinterpret_cast<const float4*>(xrow + (long)xx * a.ld)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int orow = r - ky;                                 // compile-time after unrolling
+                    if (orow < 0 || orow > 3) continue;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float4 q = v[p + kx];
+                            const float4 u0 = w0[ky * 3 + kx], u1 = w1[ky * 3 + kx];
+                            s[2 * (4 * orow + p)] += q.x * u0.x + q.y * u0.y + q.z * u0.z + q.w * u0.w;
+                            s[2 * (4 * orow + p) + 1] += q.x * u1.x + q.y * u1.y + q.z * u1.z + q.w * u1.w;
+                        }
+                }
+            }
+        }
+        // halving exchange over the partner distances 32, 16, 8, 4, 2: afterwards a lane holds sum j = (lane >> 1) & 31 over
+        // 32 lanes; the last step (distance 1) completes it
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool up = lane & 32;
+            const float keep = up ? s[i + 16] : s[i], send = up ? s[i] : s[i + 16];
+            s[i] = keep + __shfl_xor(send, 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool up = lane & 16;
+            const float keep = up ? s[i + 8] : s[i], send = up ? s[i] : s[i + 8];
+            s[i] = keep + __shfl_xor(send, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool up = lane & 8;
+            const float keep = up ? s[i + 4] : s[i], send = up ? s[i] : s[i + 4];
+            s[i] = keep + __shfl_xor(send, 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool up = lane & 4;
+            const float keep = up ? s[i + 2] : s[i], send = up ? s[i] : s[i + 2];
+            s[i] = keep + __shfl_xor(send, 4);
+        }
+        {
+            const bool up = lane & 2;
+            const float keep = up ? s[1] : s[0], send = up ? s[0] : s[1];
+            s[0] = keep + __shfl_xor(send, 2);
+        }
+        float r = s[0];
+        r += __shfl_xor(r, 1);
+        const int j = (lane >> 1) & 31, pix = j >> 1, o = j & 1;
+        const int y = y0 + (pix >> 2), x = x0 + (pix & 3);
+        if ((lane & 1) == 0 && x < a.W && y < a.H) {
+            const long n = (long)y * a.W + x;
+            const float acc = r + a.bias[o];
+            if (a.delta) a.delta[(b * N + n) * a.ld_delta + o] = acc;
+            a.coords1[(b * 2 + o) * N + n] += acc;
+        }
+    }
+}
 int launch_flow_out(const PfFlowOutArgs& a, long total, void* stream) {
+    if (a.C % 4 == 0 && a.ld % 4 == 0 && (long)a.B * a.H * a.W >= 65536) {      // >= 8 pairs of 512x1024: the tile form
+        const int tpr = (a.W + 3) / 4, tpc = (a.H + 3) / 4;
+        const long tiles = (long)a.B * tpc * tpr;
+        long blocks = (tiles + 3) / 4;
+        if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+        hipLaunchKernelGGL(pf_flow_out_tile, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, tiles, tpr, tpc);
+        return (int)hipGetLastError();
+    }
     if (a.C % 4 == 0 && a.ld % 4 == 0) {
         const int spr = (a.W + 3) / 4;
         const long strips = (long)a.B * a.H * spr;

@@ -298,6 +298,33 @@ def test_corr_role_split_kernel_matches_tile_kernel(lib, dev, shape, monkeypatch
         assert torch.equal(q.reshape(B * n, -1), rs[i + 1][:B * n]), f"level {i + 1} is not the 2x2 mean of the kernel's level {i}"
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 128), (3, 150, 146), (16, 66, 70)], ids=lambda s: "B%dx%dx%d" % s)
+def test_flow_head_tile_form_matches_strip_form_bitwise(lib, dev, shape):
+    """Round 6: from 65 536 pixels per launch on (8 pairs of 512x1024), pf_flow_head_out runs one wave per 4 x 4 tile instead of per
+    strip of 4 pixels (2.25 instead of 4.5 KB of input rows per pixel: at batch 32 the map streams from HBM).  Same products, same
+    order of additions inside a lane, same cross-lane tree: the batched launch must equal, bit for bit, the per-image launches (which
+    are below the threshold and take the strip form) -- delta_flow and the updated coords1, on maps whose sides are and are not
+    multiples of 4 -- and torch's conv2d to rounding."""
+    B, h, w = shape
+    assert B * h * w >= 65536 and h * w < 65536
+    gen = torch.Generator().manual_seed(B * h + w)
+    x = (torch.rand(B * h * w, 256, generator=gen) * 2 - 1).to(dev)
+    wt = ((torch.rand(2, 9, 256, generator=gen) * 2 - 1) * 0.05).to(dev)
+    bias = torch.tensor([0.03, -0.07], device=dev)
+    c0 = (torch.rand(B, 2, h, w, generator=gen) * 50).to(dev)
+    c_all, d_all = c0.clone(), torch.full((B * h * w, 4), 9.0, device=dev)
+    lib.flow_head_out(x, 256, wt, bias, c_all, d_all)
+    n = h * w
+    for b in range(B):
+        cb, db = c0[b:b + 1].clone(), torch.full((n, 4), 9.0, device=dev)
+        lib.flow_head_out(x[b * n:(b + 1) * n], 256, wt, bias, cb, db)
+        assert torch.equal(db, d_all[b * n:(b + 1) * n]), f"image {b}: delta_flow differs between the two forms"
+        assert torch.equal(cb[0], c_all[b]), f"image {b}: coords1 differs between the two forms"
+    want = torch.nn.functional.conv2d(x.view(B, h, w, 256).permute(0, 3, 1, 2), wt.view(2, 3, 3, 256).permute(0, 3, 1, 2), bias, padding=1)
+    got = d_all[:, :2].view(B, h, w, 2).permute(0, 3, 1, 2)
+    assert float((got - want).abs().max()) < 2e-5 and float((d_all[:, 2:] - 9.0).abs().max()) == 0.0
+
+
 def test_corr_pyramid_vs_reference_golden(lib, dev):
     g = gc.load("corr_pyramid")
     f1, f2 = gc.fmaps("corr", B=2)
