@@ -625,7 +625,12 @@ class PyramidGrad:
 
     def buffers(self, like: List[torch.Tensor]) -> List[torch.Tensor]:
         if self.g is None:
-            self.g = [torch.zeros_like(t) for t in like]
+            # ONE zero fill for the four levels (round 6; a fill per level before: 8 launches per step)
+            flat = torch.zeros(sum(t.numel() for t in like), dtype=like[0].dtype, device=like[0].device)
+            self.g, o = [], 0
+            for t in like:
+                self.g.append(flat[o:o + t.numel()].view(t.shape))
+                o += t.numel()
         return self.g
 
     def take(self) -> Optional[List[torch.Tensor]]:
@@ -652,6 +657,7 @@ class HipCorrPyramid(torch.autograd.Function):
         ctx.shape = (B, C, H, W)
         ctx.acc = acc
         ctx.mark_non_differentiable(*lv)
+        ctx.set_materialize_grads(False)         # backward ignores its arguments: no zero tensors of the levels' sizes (8 fills per step)
         STATS["hip"] += 1
         return (*lv, torch.zeros(1, device=f1.device))
 
@@ -669,20 +675,20 @@ class HipCorrPyramid(torch.autograd.Function):
         # d f1 = dV f2 / sqrt(C), d f2 = dV^T f1 / sqrt(C): two GEMMs per image on the MFMA 1x1 convolution -- rows = the n
         # pixels of a feature map, "input channels" = the n pixels of the other one, weights = the other feature map^T
         d1, d2 = torch.empty(B * n, C, device=r1.device), torch.empty(B * n, C, device=r1.device)
-        zero_b = torch.zeros(C, device=r1.device)
         n4 = (n + 3) // 4 * 4                                 # the kernel reads 16 bytes at a time: K padded with zero columns
         for b in range(B):
             dvb = dv[b]
             dvt = dvb.t()
             for src, feat, dst in ((dvb, r2, d1), (dvt, r1, d2)):
                 src = F.pad(src, (0, n4 - n)) if n4 != n else src.contiguous()
-                wmat = feat[b * n:(b + 1) * n].t()                                   # [Cout = C][Cin = n]
-                if n4 != n:
-                    wmat = F.pad(wmat, (0, n4 - n))
-                wp, bp = pack_mfma(wmat.reshape(C, n4, 1, 1), zero_b)
-                cv = Conv(wp, bp, 1, 1, n4, C, PREC_BF16X3)
+                # the operand [Cout = C][Cin = n] is the other feature map TRANSPOSED: its rows [n][C], read as the weights of a
+                # 1x1 convolution n <- C, are packed by the device-side packer in its data-gradient mode (packed Cout = C, packed
+                # Cin = n rounded up: transpose, hi | lo split and zero padding in one launch; round 6 -- the torch packing
+                # before it cost ~8 launches per GEMM: a transposing copy, two fills, a copy and the split's elementwise kernels)
+                wp, bp = lib.pack_conv_weights(feat[b * n:(b + 1) * n].view(n, C, 1, 1), None, mode=1)
+                cv = Conv(wp, bp, 1, 1, n4, C, PREC_BF16X3, presplit=True)
                 lib.conv2d([cv.desc(src, 0, n4, dst[b * n:(b + 1) * n], 0, EPI_LINEAR, scale=s)], 1, H, W, src)
-        STATS["hip"] += 1 + 2 * B
+        STATS["hip"] += 1 + 4 * B
         return _nchw(d1, B, H, W), _nchw(d2, B, H, W), None
 
 
@@ -719,6 +725,50 @@ class HipDccl(torch.autograd.Function):
         STATS["hip"] += 2
         zero = torch.zeros(1, device=g.device)
         return None, None, None, zero, zero, None, None
+
+
+class SplitBatch(torch.autograd.Function):
+    """x[k * B:(k + 1) * B] for k = 0 .. n - 1 as n outputs (fnet's batch [f1_A | f2_A | f1_B | f2_B], core/prior_raft.py:144-149).
+    As plain slices autograd's backward was, per slice, a zero fill of the whole batch and a copy, then n - 1 adds; here it is one
+    concatenation (round 6: 11 PyTorch kernels -> 1)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        B = x.shape[0] // n
+        ctx.piece = (B,) + tuple(x.shape[1:])
+        return tuple(x[k * B:(k + 1) * B] for k in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        like = next(g for g in gs if g is not None)
+        return torch.cat([g if g is not None else like.new_zeros(ctx.piece) for g in gs], 0), None
+
+
+class ContextSplit(torch.autograd.Function):
+    """cnet's output [im1 | im1_B] x 256 channels -> net = tanh(first 128), inp = relu(last 128) of both views
+    (core/prior_raft.py:135-142), four outputs.  Written out with slices and torch.tanh / torch.relu the backward was four
+    zero fills, four copies, three adds and four elementwise kernels; here: two concatenations and two elementwise products
+    into one gradient tensor (round 6)."""
+
+    @staticmethod
+    def forward(ctx, cnet, B):
+        t = torch.tanh(cnet[:, :128])
+        r = torch.relu(cnet[:, 128:])
+        ctx.save_for_backward(t, r)
+        ctx.B = B
+        return t[:B], r[:B], t[B:], r[B:]
+
+    @staticmethod
+    def backward(ctx, g_net_a, g_inp_a, g_net_b, g_inp_b):
+        t, r = ctx.saved_tensors
+        z = lambda g, like: g if g is not None else torch.zeros_like(like)          # noqa: E731
+        B = ctx.B
+        g = torch.empty(t.shape[0], 256, t.shape[2], t.shape[3], dtype=t.dtype, device=t.device)
+        gt = torch.cat([z(g_net_a, t[:B]), z(g_net_b, t[B:])], 0)
+        gr = torch.cat([z(g_inp_a, r[:B]), z(g_inp_b, r[B:])], 0)
+        torch.addcmul(gt, gt * t, t, value=-1.0, out=g[:, :128])                     # g * (1 - t^2) = g - (g t) t
+        torch.mul(gr, (r > 0).to(gr.dtype), out=g[:, 128:])
+        return g, None
 
 
 def corr_pyramid(f1: torch.Tensor, f2: torch.Tensor):
@@ -979,6 +1029,22 @@ def _grids(H: int, W: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch.Te
     return _GRIDS[key]
 
 
+_COORDS0: dict = {}
+
+
+def _coords0(B: int, H8: int, W8: int, device) -> torch.Tensor:
+    """coords_grid (core/utils/utils.py:50-56) -- constant per shape: built once (it was two aranges, a cat and a copy per step)."""
+    key = (B, H8, W8, str(device))
+    c = _COORDS0.get(key)
+    if c is None:
+        if len(_COORDS0) > 16:
+            _COORDS0.clear()
+        xs = torch.arange(W8, device=device, dtype=torch.float32).view(1, 1, 1, W8).expand(B, 1, H8, W8)
+        ys = torch.arange(H8, device=device, dtype=torch.float32).view(1, 1, H8, 1).expand(B, 1, H8, W8)
+        c = _COORDS0[key] = torch.cat([xs, ys], 1).contiguous()
+    return c
+
+
 def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int = 12,
                   init_flow: Optional[torch.Tensor] = None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
     """PriOr_RAFT.forward(test_mode=False) with an autograd graph (core/prior_raft.py:107-215)."""
@@ -992,14 +1058,16 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
     H8, W8 = H // 8, W // 8
     g_a2b, g_a2b_8, g_b2a_8 = _grids(H, W, dev)
     with torch.no_grad():
-        i1 = (2 * (image1.float() / 255.0) - 1.0).contiguous()
-        i2 = (2 * (image2.float() / 255.0) - 1.0).contiguous()
-        rot = torch.empty(B, 6, H, W, device=dev)
-        lib.img_rotate(torch.cat([i1, i2], 1).contiguous(), g_a2b, rot)                         # :127
-        i1b, i2b = rot[:, :3].contiguous(), rot[:, 3:].contiguous()
-        xs = torch.arange(W8, device=dev, dtype=torch.float32).view(1, 1, 1, W8).expand(B, 1, H8, W8)
-        ys = torch.arange(H8, device=dev, dtype=torch.float32).view(1, 1, H8, 1).expand(B, 1, H8, W8)
-        coords0 = torch.cat([xs, ys], 1).contiguous()                                           # :50-56
+        # Input stage as in the inference engine (Engine.prepare_images; round 6 -- eleven elementwise / cat / copy kernels of
+        # PyTorch's before): 2 * (image / 255) - 1 of both images straight into the encoders' batches img_f = [im1 | im2 |
+        # im1_B | im2_B] and img_c = [im1 | im1_B] (pf_normalise_images: numpy's IEEE arithmetic bit for bit), img_rotate of
+        # [im1 | im2] as a batch of 2B three-channel images into the other half of fnet's batch (:121-127), one copy.
+        img_f = torch.empty(4 * B, 3, H, W, device=dev)
+        img_c = torch.empty(2 * B, 3, H, W, device=dev)
+        lib.normalise_images(image1.float().contiguous(), image2.float().contiguous(), img_f[:B], img_f[B:2 * B], img_c[:B])
+        lib.img_rotate(img_f[:2 * B], g_a2b, img_f[2 * B:])
+        img_c[B:].copy_(img_f[2 * B:3 * B])
+        coords0 = _coords0(B, H8, W8, dev)                                                      # :50-56
 
     _TAPE.gates = {}
     # The pack cache serves ONE tape (a convolution that runs 2 x iters times packs once; the backward's data-gradient packs are
@@ -1007,7 +1075,7 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
     # the allocator placed where a freed model's were, so nothing is carried from one forward to the next.
     _PACKS.clear()
     try:
-        return _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a_8, iters, init_flow)
+        return _train_forward_body(model, lib, B, img_c, img_f, coords0, g_a2b_8, g_b2a_8, iters, init_flow)
     finally:
         _TAPE.gates = None
 
@@ -1023,7 +1091,7 @@ def _prepack_encoders(lib, *encoders):
                     _pack(m.weight, None, "dgrad")
 
 
-def _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a_8, iters, init_flow):
+def _train_forward_body(model, lib, B, img_c, img_f, coords0, g_a2b_8, g_b2a_8, iters, init_flow):
     import os
     _prepack_encoders(lib, model.cnet, model.fnet)
     # cnet beside fnet on a side stream (round 4): at the training crop an encoder launch fills a fraction of the chip, and
@@ -1035,14 +1103,13 @@ def _train_forward_body(model, lib, B, i1, i2, i1b, i2b, coords0, g_a2b_8, g_b2a
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
     with torch.cuda.stream(side):
-        cnet = encoder_forward(model.cnet, torch.cat([i1, i1b], 0))                             # :133-142
-        net_a, inp_a = torch.tanh(cnet[:B, :128]), torch.relu(cnet[:B, 128:])
-        net_b, inp_b = torch.tanh(cnet[B:, :128]), torch.relu(cnet[B:, 128:])
-    fm = encoder_forward(model.fnet, torch.cat([i1, i2, i1b, i2b], 0)).float()                  # :144-149
+        cnet = encoder_forward(model.cnet, img_c)                                               # :133-142
+        net_a, inp_a, net_b, inp_b = ContextSplit.apply(cnet, B)
+    fm = encoder_forward(model.fnet, img_f).float()                                             # :144-149
     torch.cuda.current_stream().wait_stream(side)
     for t in (net_a, inp_a, net_b, inp_b):
         t.record_stream(torch.cuda.current_stream())
-    f1a, f2a, f1b, f2b = fm[:B], fm[B:2 * B], fm[2 * B:3 * B], fm[3 * B:]
+    f1a, f2a, f1b, f2b = SplitBatch.apply(fm, 4)
     pyr_a = corr_pyramid(f1a, f2a)                                                              # :151-159
     pyr_b = corr_pyramid(f1b, f2b)
 
