@@ -403,6 +403,14 @@ int pf_region_sums(const float* epe, const float* sd, const float* weight, const
 int pf_seq_loss(const float* pred, const float* gt, const float* valid, const float* weight, float i_weight,
                 float max_flow, float* grad, double* partials, int nblk, int B, int N, void* stream);
 
+/* n <= 32 terms of the same `uniform_loss.__call__` (train_flow.py:62-71: the predictions of all iterations of one branch) in ONE
+ * launch: term i = pf_seq_loss(preds[i], gt, valid, weight, i_weights[i], max_flow, grads[i], partials + i * B * nblk * 6, ...),
+ * bit for bit.  preds / grads / i_weights are HOST arrays of n device pointers / floats (grads, or single entries of it, may be
+ * NULL); partials is [n][B][nblk][6].  (Round 6: the training step's loss was 24 launches of ~13 us one behind the other.) */
+int pf_seq_loss_batch(const float* const* preds, const float* gt, const float* valid, const float* weight,
+                      const float* i_weights, float max_flow, float* const* grads, double* partials, int nblk, int n,
+                      int B, int N, void* stream);
+
 /* partials[k] = sum of squares of chunk k of x[0..n): the total norm of `clip_grad_norm_` (train_flow.py:137). */
 int pf_sum_squares(const float* x, long n, double* partials, int nblk, void* stream);
 

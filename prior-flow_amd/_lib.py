@@ -136,6 +136,7 @@ _SIGNATURES = {
     "pf_dccl_lookup_bwd": [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_conv2d_wgrad": [_fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_seq_loss": [_fp, _fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, _i, _i, _i, _fp],
+    "pf_seq_loss_batch": [_fp, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_sum_squares": [_fp, C.c_long, _fp, _i, _fp],
     "pf_adamw_step": [_fp, _fp, _fp, _fp, C.c_long, C.c_double, C.c_float, C.c_float, C.c_float, C.c_double, _i,
                       C.c_float, _fp],
@@ -705,6 +706,25 @@ class PfLib:
         self._rc(self._dll.pf_seq_loss(_ptr(pred), _ptr(gt), _ptr(valid), _ptr(weight), i_weight, max_flow, _ptr(grad),
                                        C.c_void_p(partials.data_ptr()), partials.shape[1], B, N, self._stream(pred)),
                  "pf_seq_loss")
+
+    def seq_loss_batch(self, preds, gt, valid, weight, i_weights, max_flow, grads, partials):
+        """The n <= 32 terms seq_loss(preds[i], ..., i_weights[i], grads[i], partials[i]) in one launch; grads: list of tensors or
+        None; partials float64 [n, B, nblk, 6]."""
+        n = len(preds)
+        self._chk(gt, valid, weight, *preds, *(grads or ()))
+        B = gt.shape[0]
+        N = gt.shape[2] * gt.shape[3]
+        if partials.dtype != torch.float64 or tuple(partials.shape[:2]) != (n, B) or partials.shape[3] != 6 or not partials.is_contiguous():
+            raise PfError("seq_loss_batch: partials must be contiguous float64 [n, B, nblk, 6]")
+        if any(p.shape != gt.shape or not p.is_contiguous() or p.dtype != torch.float32 for p in preds) or valid.numel() != B * N \
+                or weight.numel() != N or (grads is not None and (len(grads) != n or any(g.shape != gt.shape for g in grads))):
+            raise PfError("seq_loss_batch: shape mismatch")
+        pa = (C.c_void_p * n)(*[p.data_ptr() for p in preds])
+        ga = (C.c_void_p * n)(*[g.data_ptr() for g in grads]) if grads is not None else None
+        wa = (C.c_float * n)(*[float(w) for w in i_weights])
+        self._rc(self._dll.pf_seq_loss_batch(pa, _ptr(gt), _ptr(valid), _ptr(weight), wa, max_flow, ga,
+                                             C.c_void_p(partials.data_ptr()), partials.shape[2], n, B, N, self._stream(gt)),
+                 "pf_seq_loss_batch")
 
     def sum_squares(self, x, partials):
         self._chk(x)

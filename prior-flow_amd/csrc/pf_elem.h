@@ -1141,6 +1141,18 @@ struct PfSeqLossArgs {
     double* partials;            // [B][nblk][6]
     int B, N, nblk; float i_weight, max_flow;
 };
+constexpr int PF_SEQ_LOSS_MAX = 32;
+struct PfSeqLossBatch {           // n terms sharing gt / valid / weight: term i = PfSeqLossArgs{pred[i], ..., grad[i], partials + i * B * nblk * 6, i_weight[i]}
+    const float* pred[PF_SEQ_LOSS_MAX]; float* grad[PF_SEQ_LOSS_MAX]; float i_weight[PF_SEQ_LOSS_MAX];
+    PfSeqLossArgs common;         // pred / grad / i_weight unused
+    int n;
+};
+PF_HD PfSeqLossArgs pf_seq_loss_term(const PfSeqLossBatch& t, int i) {
+    PfSeqLossArgs a = t.common;
+    a.pred = t.pred[i]; a.grad = t.grad[i]; a.i_weight = t.i_weight[i];
+    a.partials = t.common.partials + (long)i * t.common.B * t.common.nblk * 6;
+    return a;
+}
 PF_HD void pf_seq_loss_pixel(const PfSeqLossArgs& a, long b, int n, double (&sums)[6]) {
     const long N = a.N;
     const float gu = a.gt[(b * 2 + 0) * N + n], gv = a.gt[(b * 2 + 1) * N + n];

@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(256) pf_region_sum_kernel(const PfRegionSumArg
 }
 
 // block (k, b): pixels [k*chunk, (k+1)*chunk) of image b; deterministic two-stage sums as above
-__global__ void __launch_bounds__(256) pf_seq_loss_kernel(const PfSeqLossArgs a) {
+__device__ __forceinline__ void pf_seq_loss_block(const PfSeqLossArgs& a) {
     __shared__ double red[4][6];
     const int k = blockIdx.x, b = blockIdx.y;
     const int chunk = (a.N + a.nblk - 1) / a.nblk;
@@ -885,8 +885,19 @@ __global__ void __launch_bounds__(256) pf_seq_loss_kernel(const PfSeqLossArgs a)
         a.partials[((long)b * a.nblk + k) * 6 + threadIdx.x] =
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
+__global__ void __launch_bounds__(256) pf_seq_loss_kernel(const PfSeqLossArgs a) { pf_seq_loss_block(a); }
+// blockIdx.z = the term (round 6: all predictions of a branch in one launch)
+__global__ void __launch_bounds__(256) pf_seq_loss_batch_kernel(const PfSeqLossBatch t) {
+    const PfSeqLossArgs a = pf_seq_loss_term(t, blockIdx.z);
+    pf_seq_loss_block(a);
+}
 int launch_seq_loss(const PfSeqLossArgs& a, void* stream) {
     hipLaunchKernelGGL(pf_seq_loss_kernel, dim3((unsigned)a.nblk, (unsigned)a.B), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+int launch_seq_loss_batch(const PfSeqLossBatch& t, void* stream) {
+    hipLaunchKernelGGL(pf_seq_loss_batch_kernel, dim3((unsigned)t.common.nblk, (unsigned)t.common.B, (unsigned)t.n), dim3(256), 0,
+                       (hipStream_t)stream, t);
     return (int)hipGetLastError();
 }
 
@@ -1202,6 +1213,7 @@ static int pf_lookup_dispatch(const PfLookupArgs& a, long total, void* stream) {
 #endif
 #define PF_REGION_SUM_LAUNCH(a, stream) launch_region_sums(a, stream)
 #define PF_SEQ_LOSS_LAUNCH(a, stream) launch_seq_loss(a, stream)
+#define PF_SEQ_LOSS_BATCH_LAUNCH(t, stream) launch_seq_loss_batch(t, stream)
 #define PF_SUMSQ_LAUNCH(a, stream) launch_sumsq(a, stream)
 #define PF_FLOW_OUT_LAUNCH(a, total, stream) launch_flow_out(a, total, stream)
 #define PF_NORM_ACT_LAUNCH(a, total, stream) launch_norm_act(a, total, stream)

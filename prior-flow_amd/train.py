@@ -51,16 +51,14 @@ class uniform_loss:
         vd = valid.float().contiguous()
         B = gt.shape[0]
         part = torch.empty(n, B, self.NBLK, 6, dtype=torch.float64, device=gt.device)
-        self.grads = []
-        weights = []
-        for i, p in enumerate(flow_preds):
-            i_weight = gamma ** (n - i - 1)
-            weights.append(i_weight)
-            g = torch.empty_like(gt) if need_grads else None
-            self.lib.seq_loss(p.float().contiguous(), gt, vd, self.uniform_mask.view(-1), i_weight, float(max_flow),
-                              g, part[i])
-            if need_grads:
-                self.grads.append(g)
+        weights = [gamma ** (n - i - 1) for i in range(n)]
+        preds = [p.float().contiguous() for p in flow_preds]
+        self.grads = [torch.empty_like(gt) for _ in range(n)] if need_grads else []
+        # all terms of a branch in ONE launch (round 6; the 24 launches of a step were 0.5 ms one behind the other), 32 at a time
+        for lo in range(0, n, 32):
+            hi = min(n, lo + 32)
+            self.lib.seq_loss_batch(preds[lo:hi], gt, vd, self.uniform_mask.view(-1), weights[lo:hi], float(max_flow),
+                                    self.grads[lo:hi] if need_grads else None, part[lo:hi])
         tot = part.sum(dim=(1, 2))                                     # [n, 6]
         wk = (n, float(gamma), str(gt.device))
         if wk not in self._w:                                          # (built outside any graph capture: a host -> device copy)

@@ -40,6 +40,14 @@ static int emu_sumsq(const PfSumSqArgs& a, void*) {
     return PF_OK;
 }
 #define PF_SEQ_LOSS_LAUNCH(a, stream) emu_seq_loss(a, stream)
+static int emu_seq_loss_batch(const PfSeqLossBatch& t, void* s) {
+    for (int i = 0; i < t.n; ++i) {
+        const int rc = emu_seq_loss(pf_seq_loss_term(t, i), s);
+        if (rc != PF_OK) return rc;
+    }
+    return PF_OK;
+}
+#define PF_SEQ_LOSS_BATCH_LAUNCH(t, stream) emu_seq_loss_batch(t, stream)
 #define PF_SUMSQ_LAUNCH(a, stream) emu_sumsq(a, stream)
 
 // host statement of pf_channel_stats_final

@@ -103,3 +103,40 @@ def test_batchnorm_batch_statistics_on_hip_matches_torch():
     conv = nn.Conv2d(64, 64, 3, padding=2, dilation=2).cuda()
     with pytest.raises(PfError):
         ag.conv2d(x.detach(), conv)
+
+
+@pytest.mark.gpu
+def test_seq_loss_batch_equals_the_single_launches_bitwise():
+    """Round 6: uniform_loss hands all predictions of a branch to ONE pf_seq_loss_batch launch (train_flow.py:62-71; 24 launches of
+    ~13 us per step before).  Term i must equal pf_seq_loss of that prediction bit for bit: gradient seeds and fp64 partial sums --
+    with invalid pixels, flows above max_flow, exact zeros of pred - gt (sign 0) and a ragged pixel count."""
+    from prior_flow_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B, H, W, n = 2, 37, 53, 5
+    g = torch.Generator().manual_seed(5)
+    gt = (torch.rand(B, 2, H, W, generator=g) * 40 - 20)
+    gt[0, :, :3] = 500.0                                      # |gt| >= max_flow: masked
+    valid = (torch.rand(B, H, W, generator=g) > 0.2).float()
+    weight = torch.rand(H * W, generator=g)
+    preds = [gt + torch.randn(B, 2, H, W, generator=g) * (i + 1) for i in range(n)]
+    preds[2][1, :, 5:9] = gt[1, :, 5:9]                       # pred == gt: the gradient seed is exactly 0 there
+    gt, valid, weight = gt.to(dev), valid.to(dev), weight.to(dev)
+    preds = [p.to(dev).contiguous() for p in preds]
+    ws = [0.8 ** (n - i - 1) for i in range(n)]
+    part1 = torch.full((n, B, 64, 6), float("nan"), dtype=torch.float64, device=dev)
+    grads1 = [torch.full_like(gt, float("nan")) for _ in range(n)]
+    for i in range(n):
+        lib.seq_loss(preds[i], gt, valid, weight, ws[i], 400.0, grads1[i], part1[i])
+    part2 = torch.full_like(part1, float("nan"))
+    grads2 = [torch.full_like(gt, float("nan")) for _ in range(n)]
+    lib.seq_loss_batch(preds, gt, valid, weight, ws, 400.0, grads2, part2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(part2).all() and float(part2[:, :, :, 0].sum()) > 0
+    assert torch.equal(part1, part2)
+    for a, b in zip(grads1, grads2):
+        assert torch.equal(a, b)
+    part3 = torch.full_like(part1, float("nan"))
+    lib.seq_loss_batch(preds, gt, valid, weight, ws, 400.0, None, part3)          # the gradient seeds are optional
+    torch.cuda.synchronize()
+    assert torch.equal(part1, part3)
