@@ -27,6 +27,13 @@ python3 profiles/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $O/pmc_tra
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o t -- python3 bench.py --steps 2 --warmup 1 --no-graph $B > /dev/null 2>&1
 python3 profiles/mfma_busy.py $O/pmc_mfma > $O/mfma_busy.json
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
+# the bench line quotes `in_replay_us`, `traffic` and the MFMA-busy fractions from the COMMITTED profile files: put this run's
+# summaries in their place first (in this box's copy of the tree; profiles/adopt_final.sh does the same at home afterwards), so
+# that the committed bench line and the committed profiles are of the same run
+R=6
+cp $O/kernel_stats.csv profiles/r${R}_final_kernel_stats.csv
+cp $O/pmc_traffic.json profiles/r${R}_final_pmc_traffic.json
+cp $O/mfma_busy.json profiles/r${R}_final_mfma_busy.json
 python bench.py 2> $O/bench_stderr.log | tail -1 > $O/bench_n1.json
 python bench.py --batch 32 --steps 5 --warmup 2 --no-train-step 2>/dev/null | tail -1 > $O/bench_batch32.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof32 -o t -- python3 bench.py --batch 32 --steps 3 --warmup 1 --no-cpu-baseline --no-train-step > /dev/null 2>&1
