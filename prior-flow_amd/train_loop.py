@@ -96,6 +96,19 @@ def _side_stream(model) -> torch.cuda.Stream:
     return s
 
 
+def _b_stream(model) -> torch.cuda.Stream:
+    s = getattr(model, "_loop_b_stream", None)
+    if s is None:
+        s = model._loop_b_stream = torch.cuda.Stream()
+    return s
+
+
+def _split_on() -> bool:
+    """Round 6: branch A's and branch B's chains of the loop on two queues (forward and backward), as in the inference engine's
+    Engine.iteration_split.  PRIORFLOW_TRAIN_SPLIT=0: both branches as groups of one chain of launches (round 4)."""
+    return os.environ.get("PRIORFLOW_TRAIN_SPLIT", "1") != "0"
+
+
 def _flat(t: torch.Tensor) -> torch.Tensor:
     """[iters][N][C] -> [iters * N][C] (the iterations as extra images of the deferred weight gradient)."""
     return t.view(-1, t.shape[-1])
@@ -178,6 +191,93 @@ class LoopFn(torch.autograd.Function):
         main, side = torch.cuda.current_stream(), _side_stream(model)
         side.wait_stream(main)
         n_launch = 0
+        if _split_on():
+            # ---- two chains (round 6).  Per iteration: A's lookup -> combine -> convc1 -> convc2 on the calling stream, B's on its own
+            # stream, the flow / confidence chain (pf_motion_prep, 7x7 stems, 3x3s) and the previous iteration's upsampling on the
+            # side stream; both motion-encoder output convolutions wait for the flow chain; then each branch's conv -> SepConvGRU ->
+            # heads -> coords1 update as launches of ONE group with pf_conv_desc.co_groups = 1.  Capture order = queue assignment
+            # (engine.Engine.iteration_split): A's head, B's head (ordered behind A's previous tail so that it is that node's
+            # SECOND-captured successor), the side chain (third), then the tails.  B's tail learns of the flow chain through an
+            # event recorded on the calling stream: two forked streams must not wait on each other's events under capture.
+            sb = _b_stream(model)
+
+            def cv1(name, x, o0, c0, out, oo, epi, **kw):
+                d = P.fwd[name].desc(x, o0, c0, out, oo, epi, **kw)
+                d.co_groups = 1
+                lib.conv2d([d], B, H8, W8, x)
+
+            def head(t, S, pyr_own, pyr_other, g_w2c, i):
+                lib.dccl_lookup(S["c"][i], pyr_own[0], pyr_other[0], g_w2c, S["own"], S["raw"])
+                lib.dccl_combine(S["own"], S["raw"], g_w2c, S["corr"][i], B, H8, W8)
+                cv1(t + ".c1", S["corr"][i], 0, 324, S["c1"][i], 0, EPI_RELU)
+                cv1(t + ".c2", S["c1"][i], 0, 256, S["cat"][i], 0, EPI_RELU)
+
+            def tail(t, S, i):
+                cv1(t + ".out", S["cat"][i], 0, 272 if t == "a" else 256, S["x"][i], 128, EPI_RELU)
+                for k, hin, hout in (("1", "h", "h1"), ("2", "h1", "h")):
+                    hi = S[hin][i]
+                    ho = S[hout][i + 1] if hout == "h" else S[hout][i]
+                    cv1(t + ".zr" + k, hi, 0, 128, S["z" + k][i], 0, EPI_GRU_ZR, in1=S["x"][i], off1=0, c1=256, h=hi,
+                       aux=S["rhr" + k][i], save_gates=True)
+                    cv1(t + ".q" + k, S["rhr" + k][i], 0, 128, ho, 0, EPI_GRU_Q, in1=S["x"][i], off1=0, c1=256, h=hi, z=S["z" + k][i],
+                       aux=S["q" + k][i], save_gates=True)
+                cv1(t + ".fh1", S["h"][i + 1], 0, 128, S["fh"][i], 0, EPI_RELU)
+                cv1(t + ".fh2", S["fh"][i], 0, 256, S["delta"][i], 0, EPI_LINEAR)
+                cv1(t + ".m0", S["h"][i + 1], 0, 128, S["mh"][i], 0, EPI_RELU)
+                cv1(t + ".m2", S["mh"][i], 0, 256, S["mask"][i], 0, EPI_LINEAR, scale=0.25)
+                lib.coords_add(S["c"][i + 1], S["delta"][i], src=S["c"][i])
+
+            ev_b_end = None
+            for i in range(iters):
+                ev_start = torch.cuda.Event()
+                ev_start.record(main)                       # A's previous tail (iteration 0: everything in front of the loop)
+                head("a", A, pyr_a, pyr_b, g_b2a_8, i)
+                sb.wait_event(ev_start)
+                with torch.cuda.stream(sb):
+                    head("b", Bb, pyr_b, pyr_a, g_a2b_8, i)
+                side.wait_event(ev_start)
+                if ev_b_end is not None:
+                    side.wait_event(ev_b_end)
+                with torch.cuda.stream(side):
+                    lib.motion_prep(A["c"][i], Bb["c"][i], g_a2b_8, g_b2a_8, f1r, f2r, A["flow4"][i], Bb["flow2"][i], A["conf_in"][i],
+                                    A["x"][i], 252, Bb["x"][i], 254)
+                    for name, src, off, dst in (("a.f1a", A["flow4"][i], 0, A["t_a"][i]), ("a.f1b", A["flow4"][i], 2, A["t_ba"][i]),
+                                                ("b.f1", Bb["flow2"][i], 0, Bb["t"][i])):
+                        w, bias = P.stem_w[name]
+                        lib.conv2d_small(src, False, off, 2, w, bias, dst, 0, 128, 7, 7, 1, True, B, H8, W8)
+                    cv(("a.f2a", A["t_a"][i], 0, 128, A["cat"][i], 128, EPI_RELU, {}), ("a.f2b", A["t_ba"][i], 0, 128, A["cat"][i], 192, EPI_RELU, {}),
+                       ("b.f2", Bb["t"][i], 0, 128, Bb["cat"][i], 192, EPI_RELU, {}))
+                    cv(("a.cf1", A["conf_in"][i], 0, 8, A["cf1"][i], 0, EPI_RELU, {}))
+                    cv(("a.cf2", A["cf1"][i], 0, 32, A["cat"][i], 256, EPI_RELU, {}))
+                    stems_done = torch.cuda.Event()
+                    stems_done.record(side)
+                    if i > 0:                               # the previous iteration's predictions (prior_raft.py:200-208)
+                        lib.upsample_flow(A["c"][i], A["mask"][i - 1], preds_a[i - 1])
+                        lib.upsample_flow(Bb["c"][i], Bb["mask"][i - 1], preds_b[i - 1])
+                main.wait_event(stems_done)
+                relay = torch.cuda.Event()
+                relay.record(main)
+                tail("a", A, i)
+                sb.wait_event(relay)
+                with torch.cuda.stream(sb):
+                    tail("b", Bb, i)
+                    ev_b_end = torch.cuda.Event()
+                    ev_b_end.record(sb)
+                n_launch += 5 + 2 + 3 + 5 + 4 + 4 + 4 + 9
+            ev_end = torch.cuda.Event()
+            ev_end.record(main)
+            side.wait_event(ev_end)
+            side.wait_event(ev_b_end)
+            with torch.cuda.stream(side):
+                lib.upsample_flow(A["c"][iters], A["mask"][iters - 1], preds_a[iters - 1])
+                lib.upsample_flow(Bb["c"][iters], Bb["mask"][iters - 1], preds_b[iters - 1])
+            main.wait_stream(side)
+            main.wait_stream(sb)
+            STATS["hip"] += n_launch
+            ctx.cfg, ctx.bufs, ctx.generation = cfg, bufs, bufs.generation
+            ctx.save_for_backward(f1r, f2r)
+            ctx.n_rest = len(rest)
+            return (*preds_a, *preds_b)
         for i in range(iters):
             c1a, c1b = A["c"][i], Bb["c"][i]
             # flows, flo_rotate(flow_B), both feature warps + groupwise correlations: one launch (prior_raft.py:171-182)
@@ -271,7 +371,92 @@ class LoopFn(torch.autograd.Function):
         main, side = torch.cuda.current_stream(), _side_stream(cfg["model"])
         side.wait_stream(main)
         n_launch = 0
-        for i in range(iters - 1, -1, -1):
+        split = _split_on()
+        if split:
+            # ---- two chains (round 6): the hidden-state chain of branch A on the calling stream, branch B's on its own stream -- they
+            # share nothing --, every data-gradient convolution a launch of ONE group with co_groups = 1; the motion encoders', DCCL
+            # and warp backwards of iteration i on the side stream behind BOTH chains of that iteration.  Capture order = queue
+            # assignment (forward): the chains of iteration i - 1 are captured BEFORE the side work of iteration i, and B's chain of
+            # iteration i - 1 is ordered behind A's chain of iteration i, so that A's last kernel of an iteration has the successors
+            # A's next kernel (same queue), B's next chain (queue + 1), the side work (queue + 2), in that order.
+            sb = _b_stream(cfg["model"])
+
+            def dg1(name, x, o0, c0, out, oo, epi, **kw):
+                d = P.dg[name].desc(x, o0, c0, out, oo, epi, **kw)
+                d.co_groups = 1
+                lib.conv2d([d], B, H8, W8, x)
+
+            def chain(t, S, i):
+                """heads -> GRU (vertical, then horizontal half-step) of one branch and one iteration; leaves gh[t] for iteration i - 1."""
+                Fq2, Fq1 = S["F"][2 * (i & 1)], S["F"][2 * (i & 1) + 1]
+                if gh[t] is None:
+                    Fq1[:, 384:].zero_()
+                    ghv = Fq1[:, 384:]
+                else:
+                    ghv = gh[t]
+                if gp[t][i] is None:
+                    S["d_mask"][i].zero_(); S["d_mh"][i].zero_(); S["d_delta"][i].zero_(); S["d_fh"][i].zero_()
+                else:
+                    lib.upsample_flow_bwd(S["c"][i + 1], S["mask"][i], gp[t][i].contiguous(), S["d_mask"][i], S["d_flow"][i])
+                    lib.to_channel_last(S["d_flow"][i], 0, 2, S["d_delta"][i], 0)
+                    dg1(t + ".m2", S["d_mask"][i], 0, 576, S["d_mh"][i], 0, EPI_MASK, h=S["mh"][i], scale=0.25)
+                    dg1(t + ".m0", S["d_mh"][i], 0, 256, ghv, 0, EPI_ADD, h=ghv)
+                    dg1(t + ".fh2", S["d_delta"][i], 0, 4, S["d_fh"][i], 0, EPI_MASK, h=S["fh"][i])
+                    dg1(t + ".fh1", S["d_fh"][i], 0, 256, ghv, 0, EPI_ADD, h=ghv)
+                for k, F, hname in (("2", Fq2, "h1"), ("1", Fq1, "h")):
+                    g_in = ghv if k == "2" else Fq2[:, 384:]
+                    lib.gru_q_bwd(g_in, S["z" + k][i], S["q" + k][i], S[hname][i], S["d_q" + k][i], S["dz"], F[:, 384:])
+                    dg1(f"{t}.q{k}", S["d_q" + k][i], 0, 128, F, 0, EPI_LINEAR)
+                    lib.gru_zr_bwd(S["dz"], F[:, :128], S["z" + k][i], S["rhr" + k][i][:, 128:], S[hname][i], S["d_zr" + k][i], F[:, 384:])
+                    dg1(f"{t}.zr{k}", S["d_zr" + k][i], 0, 256, F, 128, EPI_ADD, h=F[:, 128:])
+                gh[t] = Fq1[:, 384:]
+                lib.gru_dx_finish(Fq1[:, 128:384], Fq2[:, 128:384], S["x"][i], d_inp[t], S["d_out"][i], 128, 124 if t == "a" else 126)
+
+            def side_work(i):
+                dg(("a.out", A["d_out"][i], 0, 124, A["d_cat"][i], 0, EPI_MASK, dict(h=A["cat"][i])))
+                dg(("b.out", Bb["d_out"][i], 0, 128, Bb["d_cat"][i], 0, EPI_MASK, dict(h=Bb["cat"][i])))
+                dg(("a.c2", A["d_cat"][i], 0, 128, A["d_c1"][i], 0, EPI_MASK, dict(h=A["c1"][i])))
+                dg(("b.c2", Bb["d_cat"][i], 0, 192, Bb["d_c1"][i], 0, EPI_MASK, dict(h=Bb["c1"][i])))
+                dg(*[(t + ".c1", S["d_c1"][i], 0, 256, S["d_corr"], 0, EPI_LINEAR, {}) for t, S in SS])
+                dg(("a.f2a", A["d_cat"][i], 128, 64, A["d_t_a"][i], 0, EPI_MASK, dict(h=A["t_a"][i])),
+                   ("a.f2b", A["d_cat"][i], 192, 64, A["d_t_ba"][i], 0, EPI_MASK, dict(h=A["t_ba"][i])),
+                   ("b.f2", Bb["d_cat"][i], 192, 64, Bb["d_t"][i], 0, EPI_MASK, dict(h=Bb["t"][i])))
+                dg(("a.cf2", A["d_cat"][i], 256, 16, A["d_cf1"][i], 0, EPI_MASK, dict(h=A["cf1"][i])))
+                dg(("a.cf1", A["d_cf1"][i], 0, 32, A["d_conf"], 0, EPI_LINEAR, {}))
+                for t, S in SS:
+                    g_back = g_b2a_8 if t == "a" else g_a2b_8
+                    lib.dccl_combine_bwd(S["d_corr"], g_back, S["d_raw"], B, H8, W8)
+                    lib.dccl_lookup_bwd(S["c"][i], g_back, S["d_corr"], S["d_raw"], pg_a if t == "a" else pg_b, pg_b if t == "a" else pg_a,
+                                        clear_raw=True)
+                lib.warp_gcorr_bwd(f1r, f2r, A["c"][i], False, A["d_conf"], 0, d_f1, d_f2)
+                lib.to_nchw(A["flow4"][i], 2, 2, A["flow_ba"])
+                lib.warp_gcorr_bwd(f1r, f2r, A["flow_ba"], True, A["d_conf"], 4, d_f1, d_f2)
+
+            sb.wait_stream(main)
+            pending = None                          # (iteration, event after A's chain, event after B's chain) whose side work is not captured yet
+            for i in range(iters - 1, -1, -1):
+                chain("a", A, i)
+                ev_a = torch.cuda.Event()
+                ev_a.record(main)
+                if pending is not None:
+                    sb.wait_event(pending[1])       # queue steering only: B's chain of iteration i behind A's chain of iteration i + 1
+                with torch.cuda.stream(sb):
+                    chain("b", Bb, i)
+                    ev_b = torch.cuda.Event()
+                    ev_b.record(sb)
+                if pending is not None:
+                    side.wait_event(pending[1])
+                    side.wait_event(pending[2])
+                    with torch.cuda.stream(side):
+                        side_work(pending[0])
+                pending = (i, ev_a, ev_b)
+                n_launch += 2 * (2 + 4 + 6 + 1) + 8 + 4 + 3 - 2
+            side.wait_event(pending[1])
+            side.wait_event(pending[2])
+            with torch.cuda.stream(side):
+                side_work(pending[0])
+            main.wait_stream(sb)
+        for i in (range(iters - 1, -1, -1) if not split else ()):
             Fq2 = {t: S["F"][2 * (i & 1)] for t, S in SS}             # ping-pong: gh of iteration i + 1 lives in the other pair
             Fq1 = {t: S["F"][2 * (i & 1) + 1] for t, S in SS}
             ghv = {}
