@@ -48,6 +48,13 @@ int pf_img_rotate(const float* img, const float* grid, float* out, int B, int C,
 int pf_normalise_images(const float* image1, const float* image2, float* f1, float* f2, float* c1,
                         long count, void* stream);
 
+/* The input stage of a forward in one launch (core/prior_raft.py:121-127): both images normalised as pf_normalise_images does and
+ * resampled into view B as pf_img_rotate does with `grid` ([2,H,W], generate_samplegrid of R_A2B), written into the encoders'
+ * batches img_f = [im1 | im2 | im1_B | im2_B] ([4B,3,H,W]) and, optionally, img_c = [im1 | im1_B] ([2B,3,H,W]; NULL to skip).
+ * Bit-identical to pf_normalise_images + pf_img_rotate on the normalised pair.  image1, image2: [B,3,H,W], values 0..255. */
+int pf_prepare_images(const float* image1, const float* image2, const float* grid, float* img_f, float* img_c,
+                      int B, int H, int W, void* stream);
+
 /* flow = coords1 - coords_grid (core/prior_raft.py:172,177).  coords1: planar.  flow_out
  * (planar) and the two channel-last destinations are optional (NULL to skip). */
 int pf_flow_prep(const float* coords1, float* flow_out,

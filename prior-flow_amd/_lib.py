@@ -84,6 +84,7 @@ _SIGNATURES = {
     "pf_sample_grid": [_fp, _i, _i, C.POINTER(C.c_float), _fp],
     "pf_img_rotate": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pf_normalise_images": [_fp, _fp, _fp, _fp, _fp, C.c_long, _fp],
+    "pf_prepare_images": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pf_flow_prep": [_fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_flo_rotate": [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, _fp],
     "pf_corr_pyramid": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
@@ -250,6 +251,16 @@ class PfLib:
             raise PfError("normalise_images: operand sizes differ")
         self._rc(self._dll.pf_normalise_images(_ptr(image1), _ptr(image2), _ptr(f1), _ptr(f2), _ptr(c1), n,
                                                self._stream(image1)), "pf_normalise_images")
+
+    def prepare_images(self, image1, image2, grid, img_f, img_c=None):
+        """Normalise + rotate into view B in one launch: img_f = [im1 | im2 | im1_B | im2_B], img_c = [im1 | im1_B] (optional)."""
+        self._chk(image1, image2, grid, img_f, img_c)
+        B, Cc, H, W = image1.shape
+        if not (Cc == 3 and image2.shape == image1.shape and tuple(grid.shape) == (2, H, W) and
+                tuple(img_f.shape) == (4 * B, 3, H, W) and (img_c is None or tuple(img_c.shape) == (2 * B, 3, H, W))):
+            raise PfError("prepare_images: operand shapes do not fit")
+        self._rc(self._dll.pf_prepare_images(_ptr(image1), _ptr(image2), _ptr(grid), _ptr(img_f), _ptr(img_c), B, H, W,
+                                             self._stream(image1)), "pf_prepare_images")
 
     def flow_prep(self, coords1, flow_out=None, d0=None, d0_off=0, d1=None, d1_off=0):
         self._chk(coords1, flow_out, d0, d1)

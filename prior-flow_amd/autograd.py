@@ -1060,13 +1060,11 @@ def train_forward(model, image1: torch.Tensor, image2: torch.Tensor, iters: int 
     with torch.no_grad():
         # Input stage as in the inference engine (Engine.prepare_images; round 6 -- eleven elementwise / cat / copy kernels of
         # PyTorch's before): 2 * (image / 255) - 1 of both images straight into the encoders' batches img_f = [im1 | im2 |
-        # im1_B | im2_B] and img_c = [im1 | im1_B] (pf_normalise_images: numpy's IEEE arithmetic bit for bit), img_rotate of
-        # [im1 | im2] as a batch of 2B three-channel images into the other half of fnet's batch (:121-127), one copy.
+        # im1_B | im2_B] and img_c = [im1 | im1_B] (numpy's IEEE arithmetic bit for bit) and img_rotate of [im1 | im2] as 2B
+        # three-channel images into the other half of fnet's batch (:121-127): one launch, pf_prepare_images.
         img_f = torch.empty(4 * B, 3, H, W, device=dev)
         img_c = torch.empty(2 * B, 3, H, W, device=dev)
-        lib.normalise_images(image1.float().contiguous(), image2.float().contiguous(), img_f[:B], img_f[B:2 * B], img_c[:B])
-        lib.img_rotate(img_f[:2 * B], g_a2b, img_f[2 * B:])
-        img_c[B:].copy_(img_f[2 * B:3 * B])
+        lib.prepare_images(image1.float().contiguous(), image2.float().contiguous(), g_a2b, img_f, img_c)
         coords0 = _coords0(B, H8, W8, dev)                                                      # :50-56
 
     _TAPE.gates = {}

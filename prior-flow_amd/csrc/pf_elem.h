@@ -273,6 +273,50 @@ PF_HD void pf_normalise_images_elem(long idx, const PfNormImgArgs& a) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// The whole input stage in one pass over the pixels (round 6; core/prior_raft.py:121-127): normalise both images and resample
+// them into view B, written straight into the encoders' batches
+//     f = [im1 | im2 | im1_B | im2_B]   ([4B,3,H,W])        c = [im1 | im1_B]   ([2B,3,H,W], optional)
+// A rotated value is sum_q w_q * norm(raw[tap q]): the values pf_img_rotate reads from the normalised image, the same products
+// in the same order -- bit-identical to pf_normalise_images + pf_img_rotate (+ the copy of im1_B into c) --, one launch instead of
+// three at the head of every forward, where nothing else runs.
+// ----------------------------------------------------------------------------------------------
+struct PfPrepImgArgs { const float* image1; const float* image2; const float* grid; float* f; float* c; int B, H, W; };
+PF_HD void pf_prepare_images_elem(long idx, const PfPrepImgArgs& a) {   // idx over B*3*H*W: one plane position of both images
+    const long hw = (long)a.H * a.W;
+    const long plane = (idx / hw) * hw;
+    long pix = idx % hw;
+    // 64 consecutive indices = an 8 x 8 tile of pixels, not 64 pixels of a row: view B is view A turned by 90 degrees, a row
+    // segment of B is a column-like curve in A -- up to 64 cache lines per gather instruction, the whole launch bound by the
+    // texture cache's tag rate (31 us) --, while an 8 x 8 tile samples an ~8 x 8 region (which thread takes which pixel
+    // changes nothing in the results)
+    // (8 x 8: 24 us; 4 x 16 and 2 x 32: 27 us; 16 x 4: 34 us; rows: 31 us -- profiles/r6_ab_head_of_forward.txt)
+    if (!((a.H | a.W) & 7)) {
+        const long tile = pix >> 6;
+        const int in = (int)(pix & 63), tpr = a.W >> 3;
+        pix = ((tile / tpr) * 8 + (in >> 3)) * a.W + (tile % tpr) * 8 + (in & 7);
+    }
+    const float gx = pf_pymod(a.grid[pix], (float)a.W);
+    const float gy = a.grid[hw + pix];
+    const PfTaps t = pf_taps0(gx, gy, a.H, a.W);
+    const long img = (long)a.B * 3 * hw;            // elements of one batch of B three-channel images
+    const float* p1 = a.image1 + plane;
+    const float* p2 = a.image2 + plane;
+    // the ten loads first, then the arithmetic, then the six stores (a load behind a possibly aliasing store would wait for it)
+    const float o1 = p1[pix], o2 = p2[pix];
+    float t1[4], t2[4];
+    for (int q = 0; q < 4; ++q) { t1[q] = p1[t.idx[q]]; t2[q] = p2[t.idx[q]]; }
+    float r1 = pf_norm255(t1[0]) * t.w[0], r2 = pf_norm255(t2[0]) * t.w[0];      // pf_apply's products and order
+    for (int q = 1; q < 4; ++q) { r1 = r1 + pf_norm255(t1[q]) * t.w[q]; r2 = r2 + pf_norm255(t2[q]) * t.w[q]; }
+    const float v1 = pf_norm255(o1), v2 = pf_norm255(o2);
+    const long o = plane + pix;
+    a.f[o] = v1;
+    a.f[img + o] = v2;
+    a.f[2 * img + o] = r1;
+    a.f[3 * img + o] = r2;
+    if (a.c) { a.c[o] = v1; a.c[img + o] = r1; }
+}
+
+// ----------------------------------------------------------------------------------------------
 // flow = coords1 - coords0, scattered to planar + up to two channel-last destinations
 // (core/prior_raft.py:172,177; coords_grid core/utils/utils.py:98-101)
 // ----------------------------------------------------------------------------------------------

@@ -441,17 +441,16 @@ class Engine:
     def prepare_images(self, ws: Workspace, image1: torch.Tensor, image2: torch.Tensor):
         """Input stage (core/prior_raft.py:121-127): 2 * (image / 255) - 1 of both images and img_rotate of the pair into
         view B, written straight into the encoders' batches ws.img_f = [im1 | im2 | im1_B | im2_B] and
-        ws.img_c = [im1 | im1_B]: three launches (normalise, rotate, one copy) and no torch arithmetic."""
+        ws.img_c = [im1 | im1_B]: ONE launch (pf_prepare_images; round 6 -- normalise, rotate and a copy before, bit-identical)
+        and no torch arithmetic."""
         B = ws.B
         if tuple(image1.shape) != tuple(ws.img_f[:B].shape) or image2.shape != image1.shape:
             raise PfError(f"prepare_images: images {tuple(image1.shape)} / {tuple(image2.shape)} do not fit the workspace")
         image1 = image1.contiguous().float()
         image2 = image2.contiguous().float()
-        self.lib.normalise_images(image1, image2, ws.img_f[:B], ws.img_f[B:2 * B], ws.img_c[:B])
-        # rotating [im1 | im2] as a batch of 2B three-channel images gives [im1_B | im2_B] in place of the reference's
-        # six-channel stack: the sample grid has no batch dimension
-        self.lib.img_rotate(ws.img_f[:2 * B], ws.g_a2b, ws.img_f[2 * B:])
-        ws.img_c[B:].copy_(ws.img_f[2 * B:3 * B])
+        # rotating [im1 | im2] as 2B three-channel images gives [im1_B | im2_B] in place of the reference's six-channel stack:
+        # the sample grid has no batch dimension
+        self.lib.prepare_images(image1, image2, ws.g_a2b, ws.img_f, ws.img_c)
 
     # ---- stage 1: corr volumes + pyramids (the encoders write the channel-last features themselves) ----------
     def build_pyramids(self, ws: Workspace, precision: int = PREC_F32):

@@ -131,7 +131,7 @@ class PriOr_RAFT(nn.Module):
     def _encode(self, image1, image2, ws: Workspace, eng: Engine, init_flow=None):
         """Normalise, rotate to view B, run cnet / fnet (core/prior_raft.py:109-149) and leave the
         features in the workspace (channel-last): f1A,f2A,f1B,f2B; net = tanh(cnet[:128]),
-        inp = relu(cnet[128:]) for both views."""
+        inp = relu(cnet[128:]) for both views; then the two corr volumes and their pyramids (:150-158)."""
         from ._lib import EPI_LINEAR, EPI_TANH_RELU
         B = ws.B
         ws.pre_ready = False                        # `inp` is about to be rewritten (Engine.hoist_context)
@@ -150,29 +150,38 @@ class PriOr_RAFT(nn.Module):
         P = self._weights()
         if self.use_streams and int(os.environ.get("PRIORFLOW_FORKS", "15")) & 1:
             # cnet and fnet are independent: two queues (inside the HIP graph: parallel branches).  Round 6 order: the calling stream
-            # takes coords1 = coords0 (+ init_flow) -- three small copies that need nothing of the encoders --, cnet and, right behind
-            # it, the hoisted context terms of the GRU convolutions (they need only cnet's `inp`); fnet forks from an event.  cnet's
+            # takes cnet and, right behind it, the hoisted context terms of the GRU convolutions (they need only cnet's `inp`); fnet forks from an event.  cnet's
             # chain is short, so the 90 us of hoisted convolutions run inside the encoder phase, which is bound by the SUM of the
             # two encoders' work whatever their order (rounds 4 and 5: profiles/r4_encoder_order.txt), and the two corr + pyramid
             # launches then have the chip to themselves: 134 / 142 -> 90 / 87 us per launch in the replay, first lookup 26 us earlier,
             # 154.0 -> 155.1 pairs/s same box (profiles/r6_ab_cnet_first.txt).  Before, fnet came first, cnet only got CUs at
             # t = 1.3 ms, and the hoisted convolutions shared the chip with the corr build: both were slowed (157 us for a 45 us launch).
             cur = torch.cuda.current_stream()
-            s1 = self._streams()[0]
+            s1, s2 = self._streams()[:2]
             ev = torch.cuda.Event()
             ev.record(cur)
-            eng.init_coords(ws, init_flow)
             cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
             eng.hoist_context(ws, P)
             s1.wait_event(ev)
             with torch.cuda.stream(s1):
                 fplan.run(ws.img_f, ws.f_all, EPI_LINEAR, **fsplit)
+                # the corr volumes + pyramids need fnet's features only: on fnet's queue, right behind its last convolution (the
+                # hop back to the calling stream cost 14 us in front of the first corr launch; cnet and the hoisted
+                # convolutions are long done by then, so the launches still have the chip to themselves)
+                eng.build_pyramids(ws, P["precision"])
+            # coords1 = coords0 (+ init_flow): two small copies nobody needs before the first lookup -- on a queue of their own,
+            # not in front of cnet's stem (19 us of an otherwise idle chip at the head of every forward)
+            s2.wait_event(ev)
+            with torch.cuda.stream(s2):
+                eng.init_coords(ws, init_flow)
             cur.wait_stream(s1)
+            cur.wait_stream(s2)
         else:
             eng.init_coords(ws, init_flow)
             cplan.run(ws.img_c, ws.net0_ab, EPI_TANH_RELU, **ctx)
             fplan.run(ws.img_f, ws.f_all, EPI_LINEAR, **fsplit)
             eng.hoist_context(ws, P)               # iteration-invariant part of the GRU convs (pre-split path only)
+            eng.build_pyramids(ws, P["precision"])
 
     def _streams(self):
         if self._side_streams is None:
@@ -184,8 +193,8 @@ class PriOr_RAFT(nn.Module):
         P = self._weights()
         # (joining cnet in front of the iterations instead of after the encoders -- its tail beside the corr build -- measured
         # 133.1 / 133.3 against 133.7 / 133.3 pairs/s in round 3 and was removed)
-        self._encode(image1, image2, ws, eng, init_flow)       # incl. coords1 = coords0 (+ init_flow) and the hoisted context terms
-        eng.build_pyramids(ws, P["precision"])
+        self._encode(image1, image2, ws, eng, init_flow)       # incl. coords1 = coords0 (+ init_flow), the hoisted context terms
+        #                                                         and the corr volumes + pyramids
         cur = 0
         for it in range(iters):
             last = it == iters - 1

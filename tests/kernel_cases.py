@@ -102,6 +102,33 @@ def case_normalise_images(lib, dev):
     assert np.array_equal(f[4:6].cpu().numpy(), r1) and np.array_equal(f[6:].cpu().numpy(), r2)
 
 
+def case_prepare_images(lib, dev):
+    """pf_prepare_images (the input stage in one launch) against pf_normalise_images + pf_img_rotate + the copy it replaces, bit
+    for bit: on the real A->B grid and on a grid of nasty coordinates (seam crossers, out-of-range rows, negatives), with and
+    without the context batch."""
+    g = gc.load("grids")
+    gen = torch.Generator().manual_seed(11)
+    Bn, Hh, Ww = 2, 64, 128
+    i1 = (torch.rand(Bn, 3, Hh, Ww, generator=gen) * 255).round().to(dev)
+    i2 = (torch.rand(Bn, 3, Hh, Ww, generator=gen) * 300 - 20).to(dev)
+    grids = [T(g["a2b_64x128"]).to(dev).contiguous()]
+    grids.append(gc.nasty_coords("prep_img", B=1, h=Hh, w=Ww)[0].to(dev).contiguous())    # pixel coordinates, some far outside
+    for grid in grids:
+        f_ref = torch.full((4 * Bn, 3, Hh, Ww), 7.0, device=dev)
+        c_ref = torch.full((2 * Bn, 3, Hh, Ww), 7.0, device=dev)
+        lib.normalise_images(i1, i2, f_ref[:Bn], f_ref[Bn:2 * Bn], c_ref[:Bn])
+        lib.img_rotate(f_ref[:2 * Bn], grid, f_ref[2 * Bn:])
+        c_ref[Bn:].copy_(f_ref[2 * Bn:3 * Bn])
+        f = torch.full_like(f_ref, 5.0)
+        c = torch.full_like(c_ref, 5.0)
+        lib.prepare_images(i1, i2, grid, f, c)
+        assert torch.equal(f, f_ref), "img_f"
+        assert torch.equal(c, c_ref), "img_c"
+        f2 = torch.full_like(f_ref, 5.0)
+        lib.prepare_images(i1, i2, grid, f2, None)
+        assert torch.equal(f2, f_ref), "img_f without the context batch"
+
+
 def case_flow_prep(lib, dev):
     co = gc.nasty_coords("prep", B=2)
     flow = torch.empty(2, 2, H8, W8, device=dev)
@@ -768,7 +795,7 @@ def case_add_relu(lib, dev):
         assert torch.equal(dx, torch.where(out > 0, g, torch.zeros_like(g)))
 
 
-ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_normalise_images, case_flow_prep, case_flo_rotate, case_dccl,
+ELEMENTWISE_CASES = [case_sample_grid, case_img_rotate, case_normalise_images, case_prepare_images, case_flow_prep, case_flo_rotate, case_dccl,
                      case_warp_gcorr, case_motion_prep, case_conf_stem, case_upsample, case_coords_add, case_layout,
                      case_channel_stats_and_norm_act, case_small_conv_stem, case_flow_head_out, case_split_bf16, case_pack_conv_weights,
                      case_flow_metrics, case_training_pieces, case_dccl_backward, case_upsample_backward,
