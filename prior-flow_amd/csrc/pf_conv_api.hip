@@ -72,7 +72,7 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // Tile choice: the packed weights are zero-padded to a multiple of 128 output channels, so any
 // BN in {32,64,128} is legal.  Small problems (one 512x1024 pair = 8192 pixels per branch) need
 // the smaller tile to put >= 1 workgroup on each of the 256 CUs.
-// 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)
+// 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)   7: 128x96 (WM4 WN1 NT3)
 // 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3; any map size: edge tiles may be partial)
 // 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, enough pixels to fill the chip)
 // `ngroups` here and in conv_dma_choice is the number of groups the chip sees at once: the launch's own plus pf_conv_desc.co_groups.
@@ -88,6 +88,9 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision
     }
     const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;
     if (max_cout <= 32) return 0;
+    // 7: 128 px x 96 channels (WM4 WN1 NT3; round 6) -- the encoders' layer 2 has 96 output channels, which the 128-channel tile
+    // covers with a quarter of its weight loads and MFMAs on padding
+    if (max_cout > 64 && max_cout <= 96 && ((long)g.M + 127) / 128 * ngroups >= 256) return 7;
     if (max_cout <= 64 || m_tiles64 * ((max_cout + 127) / 128) < 512) return 1;
     return 2;
 }
@@ -96,7 +99,7 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision
 // a shape / option it does not implement), else the pf_conv2d_roles code (1: 128-px tile, 2: 256 px x 64 channels).
 // (The engine's PRIORFLOW_PRESPLIT=0 is the A/B against the register-staged kernels: it hands over fp32 operands.)
 static int conv_dma_choice(const ConvGroups& grp, int ngroups, const ConvGeom& g, int max_cout, int tile_id) {
-    if (!grp.d[0].in0_split || tile_id < 3) return 0;
+    if (!grp.d[0].in0_split || tile_id < 3 || tile_id == 7) return 0;
     const bool shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1);
     if (!shape || g.stride != 1) return 0;
     for (int i = 0; i < ngroups; ++i)
@@ -127,8 +130,8 @@ extern "C" int pf_conv2d_stats_blocks(const pf_conv_desc* descs, int ngroups, in
     const int tile = conv_tile(g, ngroups + descs[0].co_groups, max_cout, descs[0].precision);
     const bool split = descs[0].precision == PF_PREC_BF16X3;
     if ((tile == 5 || tile == 3) && pf_enc_conv64_applies(grp, ngroups, g, max_cout)) return pf_enc_conv64_stats_blocks(g);
-    if (tile >= 3) { const int th = tile == 5 ? 8 : 4; return ((g.H + th - 1) / th) * ((g.W + 31) / 32); }
-    const int bm = tile == 0 ? 128 : 64;             // generic kernel: tiles of bm consecutive pixels, which must not straddle images
+    if (tile >= 3 && tile != 7) { const int th = tile == 5 ? 8 : 4; return ((g.H + th - 1) / th) * ((g.W + 31) / 32); }
+    const int bm = (tile == 0 || tile == 7) ? 128 : 64;  // generic kernel: tiles of bm consecutive pixels, which must not straddle images
     return (split && g.N % bm == 0) ? g.N / bm : 0;
 }
 
@@ -148,10 +151,11 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
     hipStream_t s = (hipStream_t)stream;
     const bool split = descs[0].precision == PF_PREC_BF16X3;
     const int tile_id = conv_tile(g, ngroups + descs[0].co_groups, max_cout, descs[0].precision);
+    const bool generic = tile_id < 3 || tile_id == 7;
     for (int i = 0; i < ngroups; ++i) {     // the input affine is implemented by the halo kernel only; the fused statistics by the
-        if (descs[i].in_scale && tile_id < 3) return PF_ERR_BAD_SHAPE;      // halo kernel and (round 4) by the generic one when its
+        if (descs[i].in_scale && generic) return PF_ERR_BAD_SHAPE;          // halo kernel and (round 4) by the generic one when its
         if (descs[i].stats_out && descs[i].epilogue != PF_EPI_LINEAR) return PF_ERR_BAD_SHAPE;     // M tiles do not straddle images
-        if (descs[i].stats_out && tile_id < 3 && (!split || (g.N % (tile_id == 0 ? 128 : 64)) != 0)) return PF_ERR_BAD_SHAPE;
+        if (descs[i].stats_out && generic && (!split || (g.N % ((tile_id == 0 || tile_id == 7) ? 128 : 64)) != 0)) return PF_ERR_BAD_SHAPE;
     }
     if (const int roles = conv_dma_choice(grp, ngroups, g, max_cout, tile_id))      // pre-split operands: the all-DMA kernel
         return pf_conv_dma_launch(grp, ngroups, g, max_cout, tile_id == 4 ? 2 : 1, roles, s);
@@ -162,7 +166,7 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
     // tile 5 (Cout <= 64 on a big map) with 64 input channels: the weights-stationary kernel, bit-identical to the halo kernel
     if ((tile_id == 5 || tile_id == 3) && pf_enc_conv64_applies(grp, ngroups, g, max_cout)) return pf_enc_conv64_launch(grp, g, s);
     switch (tile_id) {
-        case 0: case 1: case 2: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
+        case 0: case 1: case 2: case 7: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
         case 3: return pf_conv_part1_launch(grp, ngroups, g, max_cout, s);
         case 4: return pf_conv_part2_launch(grp, ngroups, g, max_cout, s);
         default: return pf_conv_part3_launch(grp, ngroups, g, max_cout, s);

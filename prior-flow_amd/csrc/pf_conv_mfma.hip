@@ -1252,6 +1252,7 @@ int pf_conv_part0_launch(int tile_id, const pfconv::ConvGroups& grp, int ngroups
     switch (tile_id) {
         case 0: return launch_conv<4, 1, 1>(grp, ngroups, g, max_cout, split, s);
         case 1: return launch_conv<2, 2, 1>(grp, ngroups, g, max_cout, split, s);
+        case 7: return launch_conv<4, 1, 3>(grp, ngroups, g, max_cout, split, s);
         default: return launch_conv<2, 2, 2>(grp, ngroups, g, max_cout, split, s);
     }
 }
@@ -1279,7 +1280,7 @@ int pf_conv_ws256_launch(const pfconv::ConvGroups& grp, int ngroups, const pfcon
 int pf_conv_kernels_launch(int tile_id, const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout,
                            bool split, hipStream_t s) {
     switch (tile_id) {
-        case 0: case 1: case 2: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
+        case 0: case 1: case 2: case 7: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
         case 3: return pf_conv_part1_launch(grp, ngroups, g, max_cout, s);
         case 4: return pf_conv_part2_launch(grp, ngroups, g, max_cout, s);
         default: return pf_conv_part3_launch(grp, ngroups, g, max_cout, s);

@@ -100,6 +100,13 @@ def test_conv_launch_plan_is_host_logic(built_lib, monkeypatch):
     assert plan(desc(cin=96, cout=96), 4, 128, 256)[0] == 4
     assert plan(desc(), 4, 256, 496)[0] == 5
     assert plan(desc(out_split=fake, lds_out=2), 4, 256, 512)[0] == 5
+    # round 6: the stride-2 convolutions into layer 2 (64 -> 96; core/extractor.py:29-38) take the generic kernel's 128 px x 96
+    # channel tile (code 7: no padding channels) when the map fills the chip -- partials per 128 consecutive pixels --, the
+    # 64 x 128 tile (or 64 x 64 on a small map) otherwise; layer 3's 128 channels keep theirs
+    assert plan(desc(cout=96, stride=2), 4, 128, 256) == (7, 128 * 256 // 128)
+    assert plan(desc(cout=96, k=1, stride=2), 2, 128, 256) == (7, 128 * 256 // 128)
+    assert plan(desc(cout=96, stride=2), 4, 32, 64)[0] == 1                             # 64 work items of 128 px: too few
+    assert plan(desc(cin=96, cout=128, stride=2), 4, 64, 128)[0] in (1, 2)
     # bad descriptors are refused by the same validation pf_conv2d runs
     assert lib._dll.pf_conv2d_stats_blocks(desc(cin=62), 1, 1, 64, 128) < 0
 

@@ -431,6 +431,44 @@ def test_conv_stride2_and_input_affine(lib, dev):
     _check_fused_stats(lib, dev, Conv(wp, bp, 3, 3, 64, 96, PREC_BF16X3), xin, 64, 96, 2, 16, 64, expect_tile=3)
 
 
+def test_conv_stride2_into_96_channels_takes_the_128x96_tile(lib, dev):
+    """Round 6: the generic kernel's 128 px x 96 channel tile (pf_conv2d_tile 7) for the stride-2 convolutions into the encoders'
+    layer 2 (core/extractor.py:29-38: 3x3 / 2 and the 1x1 / 2 downsample, 64 -> 96) on a map that fills the chip: against
+    torch's fp32 convolution, bit for bit against the same image run alone (a launch of one image is too small for the tile and
+    takes the 64-pixel one: per output the K order is the same), and its fused InstanceNorm partials (one per 128 pixels)."""
+    from prior_flow_amd._lib import EPI_LINEAR, PREC_BF16X3
+    from prior_flow_amd.engine import Conv, pack_mfma
+    B, h, w = 2, 64, 256                                   # output map; input 128 x 512
+    x = gc.uni("s2t/x", (B, 64, 2 * h, 2 * w), -1, 1)
+    xin = kc.cl(x).to(dev)
+    for name, k in (("3x3s2", 3), ("1x1s2", 1)):
+        wt = gc.uni(f"s2t/{name}/w", (96, 64, k, k), -0.1, 0.1)
+        bs = gc.uni(f"s2t/{name}/b", (96,), -0.1, 0.1)
+        want = torch.nn.functional.conv2d(x, wt, bs, stride=2, padding=k // 2)
+        wp, bp = pack_mfma(wt.to(dev), bs.to(dev))
+        cv = Conv(wp, bp, k, k, 64, 96, PREC_BF16X3)
+        out = torch.full((B * h * w, 98), 5.0, device=dev)
+        d = cv.desc(xin, 0, 64, out, 1, EPI_LINEAR, stride=2)
+        assert lib.conv2d_tile([d], B, h, w) == 7
+        nblk = lib.conv2d_stats_blocks([d], B, h, w)
+        assert nblk == h * w // 128
+        part = torch.full((B, nblk, 96, 2), float("nan"), dtype=torch.float64, device=dev)
+        d.stats_out = part.data_ptr()
+        lib.conv2d([d], B, h, w, xin)
+        kc.check(kc.uncl(out[:, 1:97].cpu(), B, h, w), want, 1.5e-4, name)
+        assert float((out[:, 0] - 5.0).abs().max()) == 0.0 and float((out[:, 97] - 5.0).abs().max()) == 0.0, "wrote outside its columns"
+        y = out[:, 1:97].reshape(B, h * w, 96).double()
+        assert float((part.sum(1)[..., 0] - y.sum(1)).abs().max()) < 1e-9 * h * w
+        assert float((part.sum(1)[..., 1] - (y * y).sum(1)).abs().max()) < 1e-9 * h * w
+        # one image alone: another tile, the same bits
+        one = torch.empty(h * w, 96, device=dev)
+        x1 = xin[:4 * h * w].contiguous()
+        d1 = cv.desc(x1, 0, 64, one, 0, EPI_LINEAR, stride=2)
+        assert lib.conv2d_tile([d1], 1, h, w) in (1, 2)
+        lib.conv2d([d1], 1, h, w, x1)
+        assert torch.equal(one, out[:h * w, 1:97]), f"{name}: tile 7 differs from the 64-pixel tile"
+
+
 def _check_fused_stats(lib, dev, cv, xin, cin, cout, B, h, w, expect_tile):
     """InstanceNorm statistics fused into the conv epilogue == pf_channel_stats of the stored output."""
     from prior_flow_amd._lib import EPI_LINEAR
