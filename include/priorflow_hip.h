@@ -215,8 +215,8 @@ typedef struct pf_conv_desc {
     const float* in_scale; const float* in_shift; int in_relu;
     /* optional InstanceNorm statistics of THIS conv's output, fused into its epilogue (PF_EPI_LINEAR only):
      * stats_out[((image*nblk + tile)*cout + c)*2 + {0,1}] = fp64 sum / sum of squares of output channel c over one workgroup
-     * tile.  nblk = pf_conv2d_stats_blocks(...).  Halo-kernel tiles 3/4/5: nblk = tiles per image = ceil(H8/TH)*ceil(W8/32), TH = 8 for
-     * tile 5 else 4; tile 6: one partial per (segment of rows, row phase of the 4-row step, strip).  Generic
+     * tile.  nblk = pf_conv2d_stats_blocks(...).  Halo-kernel tiles 3/4/5/8: nblk = tiles per image = ceil(H8/TH)*ceil(W8/32), TH = 8 for
+     * tiles 5 and 8 else 4; tile 6: one partial per (segment of rows, row phase of the 4-row step, strip).  Generic
      * kernel (pf_conv2d_tile 0/1/2/7, bf16x3; the stride-2 layers): tiles of BM = 128/64/64/128 consecutive pixels, nblk = H8*W8/BM,
      * which must divide (PF_ERR_BAD_SHAPE otherwise).  Finish with pf_channel_stats_final.  NULL = none. */
     double* stats_out;
@@ -278,7 +278,7 @@ int pf_dccl_combine_conv1x1(const pf_combine_conv_desc* descs, int ngroups, int 
 int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8, void* stream);
 
 /* Host-only introspection: which workgroup tile pf_conv2d would use for this launch -- generic kernel 0: 128x32,
- * 1: 64x64, 2: 64x128, 7: 128x96 (pixels x channels; 7 = round 6, for the 96 output channels of the encoders' layer 2); halo kernel 3: 128x64, 4: 128x128, 5: 256x64 (8-row tile); 6: the
+ * 1: 64x64, 2: 64x128, 7: 128x96 (pixels x channels; 7 = round 6, for the 96 output channels of the encoders' layer 2); halo kernel 3: 128x64, 4: 128x128, 5: 256x64 (8-row tile), 8: 256x96 (8-row tile, 3x3 with 64 < Cout <= 96; round 6); 6: the
  * weights-stationary kernel of the encoders' 3x3 64 -> 64 convolutions (round 5; core/extractor.py:16-17 at 1/2 resolution:
  * strips of 32 columns walked in 4-row steps, outputs bit-identical to tile 5) -- or a negative PF_ERR_* code.  Lets a profiler attribute measured time to the right kernel instantiation; launches nothing. */
 int pf_conv2d_tile(const pf_conv_desc* descs, int ngroups, int B, int H8, int W8);

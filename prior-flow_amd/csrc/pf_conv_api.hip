@@ -74,7 +74,7 @@ static int conv_prepare(const pf_conv_desc* descs, int ngroups, int B, int H8, i
 // the smaller tile to put >= 1 workgroup on each of the 256 CUs.
 // 0: 128x32 (WM4 WN1 NT1)   1: 64x64 (WM2 WN2 NT1)   2: 64x128 (WM2 WN2 NT2)   7: 128x96 (WM4 WN1 NT3)
 // 3: halo kernel 128x64     4: halo kernel 128x128   (bf16x3; any map size: edge tiles may be partial)
-// 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, enough pixels to fill the chip)
+// 5: halo kernel 256x64 (8-row tile, Cout <= 64, 3x3 / 4x4, enough pixels to fill the chip)   8: halo kernel 256x96 (8-row tile, 3x3)
 // `ngroups` here and in conv_dma_choice is the number of groups the chip sees at once: the launch's own plus pf_conv_desc.co_groups.
 static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision) {
     const bool halo_shape = (g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 5) || (g.kh == 5 && g.kw == 1) ||
@@ -84,6 +84,8 @@ static int conv_tile(const ConvGeom& g, int ngroups, int max_cout, int precision
         const long tiles4 = B * ((g.H + 3) / 4) * ((g.W + 31) / 32), tiles8 = B * ((g.H + 7) / 8) * ((g.W + 31) / 32);
         const long wgs128 = tiles4 * ngroups * ((max_cout + 127) / 128);
         if (max_cout <= 64 && g.kh == g.kw && g.kh > 1 && tiles8 * ngroups >= 512) return 5;
+        // 8: 256 px x 96 channels (TH 8, NT 3; round 6) -- the 3x3 96 -> 96 convolutions of the encoders' layer 2: no padding channels
+        if (max_cout > 64 && max_cout <= 96 && g.kh == 3 && g.kw == 3 && tiles8 * ngroups >= 256) return 8;
         return (max_cout > 64 && wgs128 >= 256) ? 4 : 3;
     }
     const long m_tiles64 = ((long)g.M + 63) / 64 * ngroups;
@@ -130,7 +132,7 @@ extern "C" int pf_conv2d_stats_blocks(const pf_conv_desc* descs, int ngroups, in
     const int tile = conv_tile(g, ngroups + descs[0].co_groups, max_cout, descs[0].precision);
     const bool split = descs[0].precision == PF_PREC_BF16X3;
     if ((tile == 5 || tile == 3) && pf_enc_conv64_applies(grp, ngroups, g, max_cout)) return pf_enc_conv64_stats_blocks(g);
-    if (tile >= 3 && tile != 7) { const int th = tile == 5 ? 8 : 4; return ((g.H + th - 1) / th) * ((g.W + 31) / 32); }
+    if (tile >= 3 && tile != 7) { const int th = (tile == 5 || tile == 8) ? 8 : 4; return ((g.H + th - 1) / th) * ((g.W + 31) / 32); }
     const int bm = (tile == 0 || tile == 7) ? 128 : 64;  // generic kernel: tiles of bm consecutive pixels, which must not straddle images
     return (split && g.N % bm == 0) ? g.N / bm : 0;
 }
@@ -169,6 +171,7 @@ extern "C" int pf_conv2d(const pf_conv_desc* descs, int ngroups, int B, int H8, 
         case 0: case 1: case 2: case 7: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
         case 3: return pf_conv_part1_launch(grp, ngroups, g, max_cout, s);
         case 4: return pf_conv_part2_launch(grp, ngroups, g, max_cout, s);
+        case 8: return pf_conv_part4_launch(grp, ngroups, g, max_cout, s);
         default: return pf_conv_part3_launch(grp, ngroups, g, max_cout, s);
     }
 }

@@ -288,8 +288,11 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     //         stem / layer 1) this gives every wave two accumulators per staged K-step instead of one.
     static_assert(TH == 4 || TH == 8, "");
     constexpr int TW = 32, WN = (TH == 4) ? 2 : 1, BN = 32 * NT * WN, TAPS = KH * KW;
-    static_assert(BN % 64 == 0, "weight loader moves 64 rows per pass");
-    constexpr int B_V4 = BN / 64;             // weight float4 per thread per K-step
+    static_assert(BN % 32 == 0, "");
+    // weight loader: 64 rows per pass of the 512 threads.  BN = 96 (TH = 8, NT = 3: the encoders' layer 2): the second pass has 32
+    // rows left -- both halves of the workgroup load and store rows 64..95 (the same bits to the same place twice) instead of
+    // half of the threads branching around the pass, which would cost the K loop its counted waits
+    constexpr int B_V4 = (BN + 63) / 64;      // weight float4 per thread per K-step
     constexpr int HW = TW + KW - 1, HH = TH + KH - 1;
     constexpr int A_V4 = (HH * HW + 63) / 64; // halo float4 per thread (64 rows per pass of 512 threads)
     constexpr int HALO_ROWS = 64 * A_V4;      // rows past HH*HW get zeros
@@ -310,7 +313,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
 #endif
     constexpr int B_SLOTS = DMA_B ? 4 : 3;
     constexpr int B_ROW = DMA_B ? 128 : LDS_LD * 4;     // bytes per weight row in LDS
-    constexpr int B_DMA = BN / 64;                      // 1-KiB DMA pieces per wave per K-step
+    constexpr int B_DMA = (BN + 63) / 64;               // 1-KiB DMA pieces per wave per K-step (DMA_B: TH = 4 only, BN % 64 == 0)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ah = smem;                                   // [2][HALO_ROWS][LDS_LD]
     float* Bs = smem + 2 * HALO_ROWS * LDS_LD;          // [B_SLOTS][BN][B_ROW bytes]  (ring)
@@ -456,7 +459,7 @@ pf_conv_halo_kernel(const ConvGroups groups, const ConvGeom g) {
     // same moment, was measured: no effect.)
 #pragma unroll
     for (int q = 0; q < B_V4; ++q) {
-        const int r = (tid + 512 * q) >> 3;
+        const int r = (BN % 64 != 0 && q == B_V4 - 1) ? 64 * q + ((tid & 255) >> 3) : (tid + 512 * q) >> 3;
         b_goff[q] = (unsigned)(((long)(n0 + r) * wrow + c4) * 4);
         b_loff[q] = (unsigned)((r * LDS_LD + c4) * 4);
     }
@@ -1235,7 +1238,7 @@ int launch_conv_ws_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int 
 
 }  // namespace
 
-// The product build compiles this file as four translation units in parallel (-DPF_CONV_PART=0..3, __graft_entry__.py):
+// The product build compiles this file as five translation units in parallel (-DPF_CONV_PART=0..4, __graft_entry__.py):
 // each instantiates only the kernels its launcher names.  Without the macro (diagnostic builds: profiles/stamp_conv.py,
 // profiles/ablate_conv.sh) everything is one unit.
 #ifndef PF_CONV_PART
@@ -1243,6 +1246,16 @@ int launch_conv_ws_t(const ConvGroups& grp, int ngroups, const ConvGeom& g, int 
 #endif
 #define PF_PART(k) (PF_CONV_PART == -1 || PF_CONV_PART == (k))
 
+#if PF_PART(4)      // tile 8: halo kernel 256 px x 96 channels, 3x3 (round 6: the encoders' layer 2)
+int pf_conv_part4_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t s) {
+    if (g.kh != 3 || g.kw != 3) return PF_ERR_BAD_SHAPE;             // (the 4x4 halo of this tile would not fit the LDS)
+    const bool affine = grp.d[0].in_scale != nullptr;
+    for (int i = 1; i < ngroups; ++i)
+        if ((grp.d[i].in_scale != nullptr) != affine) return PF_ERR_BAD_ARG;
+    return affine ? launch_conv_halo_t<3, 3, 3, true, 8>(grp, ngroups, g, max_cout, s)
+                  : launch_conv_halo_t<3, 3, 3, false, 8>(grp, ngroups, g, max_cout, s);
+}
+#endif
 #if PF_PART(0)      // generic kernel (stride 2, exact fp32, small problems); the wave-organisation rule
 int pf_conv_ws_choice(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout) {
     return conv_ws_choice(grp, ngroups, g, max_cout);
@@ -1283,6 +1296,7 @@ int pf_conv_kernels_launch(int tile_id, const pfconv::ConvGroups& grp, int ngrou
         case 0: case 1: case 2: case 7: return pf_conv_part0_launch(tile_id, grp, ngroups, g, max_cout, split, s);
         case 3: return pf_conv_part1_launch(grp, ngroups, g, max_cout, s);
         case 4: return pf_conv_part2_launch(grp, ngroups, g, max_cout, s);
+        case 8: return pf_conv_part4_launch(grp, ngroups, g, max_cout, s);
         default: return pf_conv_part3_launch(grp, ngroups, g, max_cout, s);
     }
 }

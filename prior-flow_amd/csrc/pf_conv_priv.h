@@ -346,6 +346,7 @@ int pf_conv_part0_launch(int tile_id, const pfconv::ConvGroups& grp, int ngroups
 int pf_conv_part1_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t stream);
 int pf_conv_part2_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t stream);
 int pf_conv_part3_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t stream);
+int pf_conv_part4_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t stream);
 int pf_conv_ws256_launch(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout, hipStream_t stream);
 int pf_conv_ws_choice(const pfconv::ConvGroups& grp, int ngroups, const pfconv::ConvGeom& g, int max_cout);
 

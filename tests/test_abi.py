@@ -97,7 +97,9 @@ def test_conv_launch_plan_is_host_logic(built_lib, monkeypatch):
     t, n = plan(desc(), 1, 128, 256)                               # 128 work items: too few
     assert t in (3, 5) and n == (128 // (8 if t == 5 else 4)) * 8
     assert plan(desc(), 4, 128, 256)[0] == 6                       # 512 items
-    assert plan(desc(cin=96, cout=96), 4, 128, 256)[0] == 4
+    assert plan(desc(cin=96, cout=96), 4, 128, 256) == (8, 16 * 8)  # round 6: layer 2's 96 channels on the 256 px x 96 channel tile
+    assert plan(desc(cin=96, cout=96), 1, 64, 128)[0] in (3, 4)     # a small map keeps the 4-row tiles
+    assert plan(desc(cin=96, cout=128), 4, 128, 256)[0] == 4
     assert plan(desc(), 4, 256, 496)[0] == 5
     assert plan(desc(out_split=fake, lds_out=2), 4, 256, 512)[0] == 5
     # round 6: the stride-2 convolutions into layer 2 (64 -> 96; core/extractor.py:29-38) take the generic kernel's 128 px x 96

@@ -469,6 +469,42 @@ def test_conv_stride2_into_96_channels_takes_the_128x96_tile(lib, dev):
         assert torch.equal(one, out[:h * w, 1:97]), f"{name}: tile 7 differs from the 64-pixel tile"
 
 
+def test_conv_96_channels_takes_the_256x96_halo_tile(lib, dev):
+    """Round 6: pf_conv_halo_kernel<3,3,3,.,8> (pf_conv2d_tile 8: 256 px x 96 channels) for the 3x3 96 -> 96 convolutions of the
+    encoders' layer 2 (core/extractor.py:16-17 at 1/4 resolution) on a map that fills the chip: against torch's fp32 convolution
+    with and without the folded input norm + ReLU, bit for bit against one image run alone (too small for the tile: the
+    128 px x 128 channel one, a quarter of it padding -- per output the K order is the same), and its fused statistics."""
+    from prior_flow_amd._lib import EPI_LINEAR, PREC_BF16X3
+    from prior_flow_amd.engine import Conv, pack_mfma
+    B, h, w = 2, 128, 256
+    x = gc.uni("t8/x", (B, 96, h, w), -1, 1)
+    wt = gc.uni("t8/w", (96, 96, 3, 3), -0.1, 0.1)
+    bs = gc.uni("t8/b", (96,), -0.1, 0.1)
+    sc = gc.uni("t8/sc", (B, 96), 0.5, 1.5)
+    sh = gc.uni("t8/sh", (B, 96), -0.5, 0.5)
+    wp, bp = pack_mfma(wt.to(dev), bs.to(dev))
+    cv = Conv(wp, bp, 3, 3, 96, 96, PREC_BF16X3)
+    xin = kc.cl(x).to(dev)
+    for affine in (False, True):
+        kw = dict(in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True) if affine else {}
+        xr = torch.relu(x * sc[:, :, None, None] + sh[:, :, None, None]) if affine else x
+        want = torch.nn.functional.conv2d(xr, wt, bs, padding=1)
+        out = torch.full((B * h * w, 98), 5.0, device=dev)
+        d = cv.desc(xin, 0, 96, out, 1, EPI_LINEAR, **kw)
+        assert lib.conv2d_tile([d], B, h, w) == 8
+        lib.conv2d([d], B, h, w, xin)
+        kc.check(kc.uncl(out[:, 1:97].cpu(), B, h, w), want, 2e-4, f"tile 8, affine={affine}")
+        assert float((out[:, 0] - 5.0).abs().max()) == 0.0 and float((out[:, 97] - 5.0).abs().max()) == 0.0, "wrote outside its columns"
+        one = torch.empty(h * w, 96, device=dev)
+        x1 = xin[h * w:].contiguous()                                     # the SECOND image alone
+        kw1 = dict(in_scale=sc[1:].contiguous().to(dev), in_shift=sh[1:].contiguous().to(dev), in_relu=True) if affine else {}
+        d1 = cv.desc(x1, 0, 96, one, 0, EPI_LINEAR, **kw1)
+        assert lib.conv2d_tile([d1], 1, h, w) == 4
+        lib.conv2d([d1], 1, h, w, x1)
+        assert torch.equal(one, out[h * w:, 1:97]), f"affine={affine}: tile 8 differs from tile 4"
+    _check_fused_stats(lib, dev, cv, xin, 96, 96, B, h, w, expect_tile=8)
+
+
 def _check_fused_stats(lib, dev, cv, xin, cin, cout, B, h, w, expect_tile):
     """InstanceNorm statistics fused into the conv epilogue == pf_channel_stats of the stored output."""
     from prior_flow_amd._lib import EPI_LINEAR
@@ -477,8 +513,8 @@ def _check_fused_stats(lib, dev, cv, xin, cin, cout, B, h, w, expect_tile):
     tile = lib.conv2d_tile([d], B, h, w)
     assert tile == expect_tile
     nblk = lib.conv2d_stats_blocks([d], B, h, w)
-    if tile in (3, 4, 5):
-        th = 8 if tile == 5 else 4
+    if tile in (3, 4, 5, 8):
+        th = 8 if tile in (5, 8) else 4
         assert nblk == ((h + th - 1) // th) * ((w + 31) // 32)
     part = torch.full((B, nblk, cout, 2), float("nan"), dtype=torch.float64, device=dev)
     d.stats_out = part.data_ptr()
