@@ -1138,10 +1138,11 @@ class EncoderPlan:
             # block inputs / outputs exist in both forms (fp32: residual operand, stride-2 convs, final 1x1; twin: the 3x3 convs);
             # the intermediate y1 as a twin only; r = the folded downsample branch of a stride-2 block
             b[f"x{lvl}"] = [z(rows, c), z(rows, c)]
-            # level 0's twins (the largest maps: 3 x 0.27 GB per image pair at 512x1024) only when layer 1 does not run on fp32
-            # rows (_run_folded allocates them then): ADVICE r5 -- they were allocated and never used
-            b[f"xs{lvl}"] = [split_twin(rows, c, self.dev), split_twin(rows, c, self.dev)] if lvl else None
-            b[f"y{lvl}"] = split_twin(rows, c, self.dev) if lvl else None
+            # a level's twins (xs: block outputs, y: conv1's output) or its fp32 intermediate (yr) are allocated by _run_folded
+            # when it knows which form the level's 3x3 convolutions take (level 0's twins were allocated and never used)
+            b[f"xs{lvl}"] = None
+            b[f"y{lvl}"] = None
+            b[f"yr{lvl}"] = None
             b[f"r{lvl}"] = z(rows, c)
         self._bufs = self._bufs_by_key[key] = b
 
@@ -1180,6 +1181,7 @@ class EncoderPlan:
             lib.space_to_depth2(images, bufs["s2d"])
             lib.conv2d([self.f_stem.desc(bufs["s2d"], 0, 12, x, 0, EPI_RELU, outs=None if l0_rows else xs)], Bn, h, w, x)
         lvl, cur = 0, 0
+        rows_lvl = l0_rows                                  # this level's 3x3 convolutions read and write fp32 rows only
         for f in self.f_blocks:
             cin, cout, st = f["cin"], f["cout"], f["stride"]
             if st == 1 and lvl == 0 and l0_rows:
@@ -1193,19 +1195,39 @@ class EncoderPlan:
                 lvl += 1
                 h, w = h // 2, w // 2
                 cur = 0
-                y, r = bufs[f"y{lvl}"], bufs[f"r{lvl}"]
-                o, os_ = bufs[f"x{lvl}"][0], bufs[f"xs{lvl}"][0]
-                lib.conv2d([f["c1"].desc(x_in, 0, cin, None, 0, EPI_RELU, stride=st, outs=y)], Bn, h, w, x_in)
+                r, o = bufs[f"r{lvl}"], bufs[f"x{lvl}"][0]
+                # Layer 2 (96 channels) on fp32 rows when pf_conv2d gives its 3x3 convolutions the halo kernel's 256 px x 96 channel
+                # tile (pf_conv2d_tile 8, round 6): the all-DMA kernel that twins would select has 64-channel tiles -- one and a
+                # half of them, a quarter of the MFMAs on padding: 48 against 35 us per launch on cnet's two images
+                # (profiles/r6_ab_96_channel_tiles.txt).  Same products, same order: same bits.
+                rows_lvl = lib.conv2d_tile([f["c2"].desc(o, 0, cout, o, 0, EPI_RELU_RES, h=r)], Bn, h, w) == 8
+                rows = Bn * h * w
+                if rows_lvl and bufs[f"yr{lvl}"] is None:
+                    bufs[f"yr{lvl}"] = torch.zeros(rows, cout, dtype=torch.float32, device=self.dev)
+                if not rows_lvl and bufs[f"y{lvl}"] is None:
+                    bufs[f"xs{lvl}"] = [split_twin(rows, cout, self.dev), split_twin(rows, cout, self.dev)]
+                    bufs[f"y{lvl}"] = split_twin(rows, cout, self.dev)
+                if rows_lvl:
+                    lib.conv2d([f["c1"].desc(x_in, 0, cin, bufs[f"yr{lvl}"], 0, EPI_RELU, stride=st)], Bn, h, w, x_in)
+                else:
+                    lib.conv2d([f["c1"].desc(x_in, 0, cin, None, 0, EPI_RELU, stride=st, outs=bufs[f"y{lvl}"])], Bn, h, w, x_in)
                 lib.conv2d([f["ds"].desc(x_in, 0, cin, r, 0, EPI_LINEAR, stride=st)], Bn, h, w, x_in)
                 res = r
             else:
-                y = bufs[f"y{lvl}"]
-                o, os_ = bufs[f"x{lvl}"][cur ^ 1], bufs[f"xs{lvl}"][cur ^ 1]
-                lib.conv2d([f["c1"].desc(None, 0, cin, None, 0, EPI_RELU, in0s=xs, outs=y)], Bn, h, w, x)
+                o = bufs[f"x{lvl}"][cur ^ 1]
+                if rows_lvl:
+                    lib.conv2d([f["c1"].desc(x, 0, cin, bufs[f"yr{lvl}"], 0, EPI_RELU)], Bn, h, w, x)
+                else:
+                    lib.conv2d([f["c1"].desc(None, 0, cin, None, 0, EPI_RELU, in0s=xs, outs=bufs[f"y{lvl}"])], Bn, h, w, x)
                 res = x
                 cur ^= 1
             # conv2 + folded norm2 + ReLU, residual add + ReLU in the epilogue (core/extractor.py:44-47)
-            lib.conv2d([f["c2"].desc(None, 0, cout, o, 0, EPI_RELU_RES, in0s=y, h=res, outs=os_)], Bn, h, w, o)
-            x, xs = o, os_
+            if rows_lvl:
+                lib.conv2d([f["c2"].desc(bufs[f"yr{lvl}"], 0, cout, o, 0, EPI_RELU_RES, h=res)], Bn, h, w, o)
+                x, xs = o, None
+            else:
+                os_ = bufs[f"xs{lvl}"][cur]
+                lib.conv2d([f["c2"].desc(None, 0, cout, o, 0, EPI_RELU_RES, in0s=bufs[f"y{lvl}"], h=res, outs=os_)], Bn, h, w, o)
+                x, xs = o, os_
         d = self.final.desc(x, 0, 128, out, 0, epilogue, aux=aux, outs=outs, auxs=auxs)
         lib.conv2d([d], Bn, h, w, x)
