@@ -18,6 +18,7 @@ python3 profiles/summarize_trace.py $(find $O/prof -name "t_kernel_trace.csv" | 
 python3 profiles/iteration_timeline.py $(find $O/prof -name "t_kernel_trace.csv" | head -1) 100 > $O/iteration_timeline.txt
 python3 profiles/encoder_timeline.py $(find $O/prof -name "t_kernel_trace.csv" | head -1) 100 > $O/encoder_timeline.txt
 python3 profiles/tail_timeline.py $(find $O/prof -name "t_kernel_trace.csv" | head -1) 5 > $O/tail_timeline.txt
+python3 profiles/chain_gaps.py $(find $O/prof -name "t_kernel_trace.csv" | head -1) > $O/chain_gaps.txt     # medians over all steady-state iterations
 rm -rf $O/prof
 # PMC passes: counters in their own runs, never together with a trace
 for c in FETCH_SIZE WRITE_SIZE; do
