@@ -15,8 +15,9 @@ if len(sys.argv) > 2:
 else:
     # the shortest complete window = a steady-state HIP-graph replay (bench.py also runs warm-up,
     # eager kernel-profiling and capture forwards, which are longer)
+    # (windows of a few kernels are bench.py's back-to-back corr launches for roofline_corr, not forwards)
     spans = [int(rows[starts[j + 1] - 1]["End_Timestamp"]) - int(rows[starts[j]]["Start_Timestamp"]) for j in range(len(starts) - 1)]
-    k = min(range(len(spans)), key=lambda j: spans[j])
+    k = min((j for j in range(len(spans)) if starts[j + 1] - starts[j] >= 100), key=lambda j: spans[j])
 seg = rows[starts[k]:starts[k + 1]]
 agg = collections.OrderedDict()
 for r in seg:
