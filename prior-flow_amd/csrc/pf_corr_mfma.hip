@@ -408,7 +408,8 @@ __device__ __forceinline__ void ring_for(F&& f) {
 //
 // PF_RS_ABL (compile-time, timing-only diagnosis builds of profiles/; results are garbage): 1 no global stores, 2 no DMA,
 // 4 no MFMA and no fragment reads, 8 no store-wave work, 16 no staging dump, 32 no barriers, 64 MFMA waves leave at once,
-// 256 no pooled-level stores, 512 no level-0 stores, 1024 fragment reads without MFMAs
+// 256 no pooled-level stores, 512 no level-0 stores, 1024 fragment reads without MFMAs, 2048 store addresses of a workgroup's tiles
+// rotated by a per-workgroup amount (do the workgroups, walking their items in step, pile onto the same memory channels? -- no)
 // ----------------------------------------------------------------------------------------------
 #ifndef PF_RS_ABL
 #define PF_RS_ABL 0
@@ -784,7 +785,10 @@ pf_corr_rs_kernel(const CorrArgs a, const int RB) {
 
     auto pass = [&](auto P, const int dt) __attribute__((always_inline)) {       // pass p of data tile dt
         constexpr int p = decltype(P)::value;
-        const int rp = tile_rp(dt), ch = tile_ch(dt);
+        // (PF_RS_ABL & 2048, timing only: every workgroup addresses the tiles of its item in an order of its own -- do the workgroups,
+        // which all walk their items in step, pile their stores onto the same address bits 8..12 = the same memory channels?)
+        const int dta = (ablate & 2048) ? ((dt + (int)((blockIdx.x * 5u) & 15u)) % NT) : dt;
+        const int rp = tile_rp(dta), ch = tile_ch(dta);
         f32x4 r0 = raw[p][0], r1 = raw[p][1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { r0[i] = scaled(r0[i]); r1[i] = scaled(r1[i]); }

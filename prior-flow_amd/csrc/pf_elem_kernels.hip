@@ -811,7 +811,10 @@ __global__ void __launch_bounds__(256) pf_flow_out_tile(const PfFlowOutArgs a, c
     }
 }
 int launch_flow_out(const PfFlowOutArgs& a, long total, void* stream) {
-    if (a.C % 4 == 0 && a.ld % 4 == 0 && (long)a.B * a.H * a.W >= 65536) {      // >= 8 pairs of 512x1024: the tile form
+#ifndef PF_FLOW_OUT_TILE_MIN
+#define PF_FLOW_OUT_TILE_MIN 65536
+#endif
+    if (a.C % 4 == 0 && a.ld % 4 == 0 && (long)a.B * a.H * a.W >= PF_FLOW_OUT_TILE_MIN) {      // >= 8 pairs of 512x1024: the tile form
         const int tpr = (a.W + 3) / 4, tpc = (a.H + 3) / 4;
         const long tiles = (long)a.B * tpc * tpr;
         long blocks = (tiles + 3) / 4;
