@@ -62,10 +62,31 @@ __device__ __forceinline__ float dpp_get(float v) {
 // 181 us with plain stores, 109 us with nt stores, same instruction stream; the tile kernel 149 -> 144 us at B = 1 and
 // 1287 -> 1062 us at B = 8).  Only for stores of whole 128-byte lines (16- / 32-byte pieces took 360 us as nt
 // stores instead of 155).  -DPF_CORR_PLAIN_STORES restores plain stores (profiles/ab_corr_libs.py).
+// -DPF_CORR_STORE_POLICY=n (timing / A-B builds): 1 "sc1", 2 "sc0 sc1", 3 "nt sc1", 4 "nt sc0 sc1", 5 "sc0", 6 "nt sc0" on the store
+// instruction instead of the plain "nt" (round 6: none beats it, profiles/r6_corr_store_floor.txt).
 template <class V>
 __device__ __forceinline__ void vol_store(V* p, const V& v) {
-#ifdef PF_CORR_PLAIN_STORES
+#if defined(PF_CORR_PLAIN_STORES)
     *p = v;
+#elif defined(PF_CORR_STORE_POLICY) && defined(__HIP_DEVICE_COMPILE__)
+#define PF_ST_STR2(x) #x
+#define PF_ST_STR(x) PF_ST_STR2(x)
+#if PF_CORR_STORE_POLICY == 1
+#define PF_ST_BITS "sc1"
+#elif PF_CORR_STORE_POLICY == 2
+#define PF_ST_BITS "sc0 sc1"
+#elif PF_CORR_STORE_POLICY == 3
+#define PF_ST_BITS "nt sc1"
+#elif PF_CORR_STORE_POLICY == 4
+#define PF_ST_BITS "nt sc0 sc1"
+#elif PF_CORR_STORE_POLICY == 5
+#define PF_ST_BITS "sc0"
+#else
+#define PF_ST_BITS "nt sc0"
+#endif
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off " PF_ST_BITS :: "v"(p), "v"(v) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, off " PF_ST_BITS :: "v"(p), "v"(v) : "memory");
+    else __builtin_nontemporal_store(v, p);
 #else
     __builtin_nontemporal_store(v, p);
 #endif
