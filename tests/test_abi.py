@@ -62,6 +62,7 @@ def test_null_and_shape_errors_are_reported_without_a_gpu(built_lib):
     assert dll.pf_sample_grid(None, 16, 32, None, None) == -1           # PF_ERR_BAD_ARG
     assert dll.pf_conv2d(None, 1, 1, 16, 32, None) == -1
     assert dll.pf_corr_pyramid(None, None, None, None, None, None, 1, 16, 32, 256, None) == -1
+    assert dll.pf_prepare_images(None, None, None, None, None, 1, 128, 256, None) == -1
 
 
 def test_conv_launch_plan_is_host_logic(built_lib, monkeypatch):
