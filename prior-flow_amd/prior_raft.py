@@ -189,7 +189,7 @@ class PriOr_RAFT(nn.Module):
             self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
         return self._side_streams
 
-    def _run(self, ws: Workspace, image1, image2, iters, init_flow, test_mode, out_a, out_b):
+    def _run(self, ws: Workspace, image1, image2, iters, init_flow, test_mode, out_a, out_b, upsample_last=True):
         eng = Engine(self._lib(), self._streams() if self.use_streams else None)
         P = self._weights()
         # (joining cnet in front of the iterations instead of after the encoders -- its tail beside the corr build -- measured
@@ -205,7 +205,7 @@ class PriOr_RAFT(nn.Module):
                 # branch B's last update are never observable.
                 cur = eng.iteration(ws, P, cur, need_b=not last, mask_a=last, mask_b=False,
                                     defer_b_join=not last)
-                if last:
+                if last and upsample_last:
                     eng.upsample(ws, "a", out_a[0])
             else:
                 cur = eng.iteration(ws, P, cur, need_b=True, mask_a=True, mask_b=True)
@@ -252,24 +252,25 @@ class PriOr_RAFT(nn.Module):
         key = (ws.B, ws.H, ws.W, iters, str(image1.device))
         # The input stage (pf_prepare_images: normalise + rotate into the encoders' batches) runs OUTSIDE the graph, straight from the
         # caller's tensors into the workspace, and the capture starts behind it: a replay needs no copy of the images into static
-        # buffers (round 6: two copies and their gaps, 16 us per forward)
+        # buffers (round 6: two copies and their gaps, 16 us per forward).  The last launch, the convex upsampling, runs BEHIND the replay
+        # into a fresh tensor for the same reason at the other end: no static output buffer to clone from.
         eng = Engine(self._lib(), None)
-        entry = self._graphs.get(key)
-        if entry is None:
-            static_out = [torch.empty(ws.B, 2, ws.H, ws.W, dtype=torch.float32, device=image1.device)]
+        graph = self._graphs.get(key)
+        if graph is None:
+            scratch_out = [torch.empty(ws.B, 2, ws.H, ws.W, dtype=torch.float32, device=image1.device)]
             # warm-up on a side stream (lazy initialisations -- function attributes, module loads -- happen here)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(2):
-                    self._run(ws, image1, image2, iters, None, True, static_out, [])
+                    self._run(ws, image1, image2, iters, None, True, scratch_out, [])
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                self._run(ws, None, None, iters, None, True, static_out, [])
-            entry = (graph, static_out)
-            self._graphs[key] = entry
-        graph, static_out = entry
+                self._run(ws, None, None, iters, None, True, None, [], upsample_last=False)
+            self._graphs[key] = graph
         eng.prepare_images(ws, image1, image2)
         graph.replay()
-        return static_out[0].clone()
+        out = torch.empty(ws.B, 2, ws.H, ws.W, dtype=torch.float32, device=image1.device)
+        eng.upsample(ws, "a", out)
+        return out

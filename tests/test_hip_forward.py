@@ -489,11 +489,11 @@ def test_workspaces_and_graphs_of_several_shapes_stay_resident(params):
                 if rnd == 0:
                     first[s] = out.clone()
                     ws_ids[s] = id(model._ws[key])
-                    graph_ids[s] = id(model._graphs[(s[0], s[1], s[2], 2, str(out.device))][0])
+                    graph_ids[s] = id(model._graphs[(s[0], s[1], s[2], 2, str(out.device))])
                 else:
                     assert torch.equal(out, first[s])
                     assert id(model._ws[key]) == ws_ids[s], "the workspace was re-allocated"
-                    assert id(model._graphs[(s[0], s[1], s[2], 2, str(out.device))][0]) == graph_ids[s], "the graph was re-captured"
+                    assert id(model._graphs[(s[0], s[1], s[2], 2, str(out.device))]) == graph_ids[s], "the graph was re-captured"
         assert len(model._ws) == 3
         # a fourth shape pushes the least recently used one (and its graph) out
         model(*(t.cuda() for t in gc.synthetic_pair(1, 128, 384, seed=5)), iters=2, test_mode=True)
