@@ -31,10 +31,13 @@ span = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e3
 # union of busy intervals: time during which at least one kernel is running; the rest is idle gaps
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in seg)
 union, gaps, cur_s, cur_e = 0, [], iv[0][0], iv[0][1]
+where = []                                   # (gap us, offset of its start in the window us, kernel that ends it)
+byst = {int(r["Start_Timestamp"]): r["Kernel_Name"] for r in seg}
 for a, b in iv[1:]:
     if a > cur_e:
         union += cur_e - cur_s
         gaps.append((a - cur_e) / 1e3)
+        where.append(((a - cur_e) / 1e3, (cur_e - iv[0][0]) / 1e3, byst.get(a, "?")))
         cur_s, cur_e = a, b
     else:
         cur_e = max(cur_e, b)
@@ -44,3 +47,7 @@ print(f"# forward {k}: kernels {len(seg)}, span {span:.1f} us, sum of kernel dur
       f"(median {sorted(gaps)[len(gaps) // 2] if gaps else 0:.1f} us, max {max(gaps) if gaps else 0:.1f} us)")
 for name, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-102s n=%4d  %9.1f us  avg %8.1f us  %5.1f%%" % (name, v[0], v[1], v[1] / v[0], 100 * v[1] / tot))
+if where:
+    print("# idle gaps of the window (us, at us from the window's start, next kernel):")
+    for g_, at, nxt in sorted(where, reverse=True)[:12]:
+        print(f"#   {g_:6.1f}  at {at:8.1f}  before {nxt.replace('(anonymous namespace)::', '')[:80]}")
